@@ -1,0 +1,316 @@
+"""Generate the golden vectors under tests/golden/ by running the REAL reference (imported from
+/root/reference/src, never copied) on seeded synthetic inputs.  Runs only in the build container.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/*.npz
+
+What is captured: F1 sample_pdf (+ searchsorted indices), F2 MLP.forward, F3
+volume_rendering / convert_depth_from_ndc / compute_other_view_dirs, F4 render_rays in eval mode, F5 one
+training step (outputs, the four losses at iter 0 and 40000, gradient digests, parameters after one Adam
+step).  The reference draws its random numbers on the CPU generator inside the loop; they are recorded by
+wrapping torch.rand / torch.randn while the reference runs and stored in the fixture so that the oracle and
+the HIP path can be fed the same draws.
+
+Parameters are produced by oracle.vipnerf_oracle.init_params (numpy PCG64, platform independent) and
+loaded into the reference model with load_state_dict, so fixtures only need to store the seed.
+"""
+import contextlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference/src')
+
+from oracle import vipnerf_oracle as vo  # noqa: E402
+from models.ModelFactory import get_model  # noqa: E402  (reference)
+from models.VipNeRF01 import VipNeRF, MLP  # noqa: E402  (reference)
+from loss_functions.LossComputer01 import LossComputer  # noqa: E402  (reference)
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+os.makedirs(GOLD, exist_ok=True)
+
+
+@contextlib.contextmanager
+def record_rng(log):
+    r0, n0 = torch.rand, torch.randn
+
+    def rand(*a, **k):
+        t = r0(*a, **k)
+        log.append(('rand', t.clone()))
+        return t
+
+    def randn(*a, **k):
+        t = n0(*a, **k)
+        log.append(('randn', t.clone()))
+        return t
+
+    torch.rand, torch.randn = rand, randn
+    try:
+        yield
+    finally:
+        torch.rand, torch.randn = r0, n0
+
+
+@contextlib.contextmanager
+def record_searchsorted(log):
+    s0 = torch.searchsorted
+
+    def ss(*a, **k):
+        t = s0(*a, **k)
+        log.append(t.clone())
+        return t
+
+    torch.searchsorted = ss
+    try:
+        yield
+    finally:
+        torch.searchsorted = s0
+
+
+def ref_configs(ndc, depth=8, width=256, n_coarse=64, n_fine=128, netchunk=4096, chunk=4096, sparse=False):
+    def mlp(ns):
+        return {'num_samples': ns, 'netdepth': depth, 'netwidth': width,
+                'points_positional_encoding_degree': 10, 'views_positional_encoding_degree': 4,
+                'use_view_dirs': True, 'view_dependent_rgb': True, 'predict_visibility': True}
+    model = {'name': 'VipNeRF01', 'coarse_mlp': mlp(n_coarse), 'chunk': chunk, 'lindisp': False,
+             'netchunk': netchunk, 'perturb': True, 'raw_noise_std': 1.0, 'white_bkgd': False}
+    if n_fine > 0:
+        model['fine_mlp'] = mlp(n_fine)
+    losses = [{'name': 'MSE01', 'weight': 1}, {'name': 'VisibilityLoss01', 'weight': 0.1},
+              {'name': 'VisibilityPriorLoss01', 'iter_weights': {'0': 0, '30000': 0.001}}]
+    if sparse:
+        losses.append({'name': 'SparseDepthMSE01', 'weight': 0.1})
+    return {'data_loader': {'ndc': ndc}, 'model': model, 'losses': losses, 'device': [0]}
+
+
+def ref_model(cfg, params):
+    m = get_model(cfg, None)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in params.items()}
+    m.load_state_dict(sd, strict=True)
+    return m
+
+
+def ref_batch(b, iter_num):
+    """oracle synthetic batch -> the reference's batch dict (DataPreprocessor01.py:498-529, 576-615)."""
+    rb = {k: v for k, v in b.items() if k not in ('poses', 'ndc')}
+    rb['common_data'] = {'poses': b['poses'][None].clone()}
+    rb['iter_num'] = iter_num
+    return rb
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(GOLD, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('%-34s %8.1f KB' % (name + '.npz', os.path.getsize(path) / 1024))
+
+
+def digest(t: torch.Tensor):
+    """Compact pin of a large tensor: [sum, l2, first 64 flat, 192 strided samples]."""
+    f = t.detach().reshape(-1).double()
+    n = f.numel()
+    idx = (torch.arange(192, dtype=torch.long) * 7919) % n
+    return torch.cat([f.sum()[None], f.norm()[None], f[:64] if n >= 64 else torch.cat([f, f.new_zeros(64 - n)]),
+                      f[idx]]).numpy()
+
+
+# ------------------------------------------------------------------------------------------------ F1
+def gen_f1():
+    g = np.random.default_rng(101)
+    n = 96
+    z = np.sort(g.uniform(0, 1, size=(n, 64)).astype(np.float32), axis=1)
+    bins = torch.from_numpy(.5 * (z[:, 1:] + z[:, :-1]))
+    w = g.random((n, 62), dtype=np.float32) ** 4
+    w[:8] = 0.                       # flat cdf rows
+    w[8:16, 5:] = 0.                 # mass in the first bins only
+    w[16:24, :] = 0.
+    w[16:24, 40] = 1.                # a single spike
+    w = torch.from_numpy(w)
+    # perturb mode: the reference draws u itself
+    rlog, slog = [], []
+    torch.manual_seed(7)
+    with record_rng(rlog), record_searchsorted(slog):
+        s_rand = VipNeRF.sample_pdf(bins, w, 128, det=False)
+    u_rand, inds_rand = rlog[0][1], slog[0]
+    slog = []
+    with record_searchsorted(slog):
+        s_det = VipNeRF.sample_pdf(bins, w, 128, det=True)
+    inds_det = slog[0]
+    # margin of each u to the nearest cdf entry (fp64) so tests can select rows that are not ulp-fragile
+    wd = (w.double() + 1e-5)
+    cdf = torch.cat([torch.zeros(n, 1, dtype=torch.float64), torch.cumsum(wd / wd.sum(-1, keepdim=True), -1)], -1)
+    margin = (u_rand.double()[:, :, None] - cdf[:, None, :]).abs().min(-1).values
+    npz('f1_sample_pdf', bins=bins, weights=w, u=u_rand, samples_rand=s_rand, inds_rand=inds_rand,
+        samples_det=s_det, inds_det=inds_det, margin=margin.float())
+
+
+# ------------------------------------------------------------------------------------------------ F2
+def gen_f2():
+    for V, seed in ((1, 201), (2, 202)):
+        params = vo.init_params(seed, levels=('coarse',))
+        cfg = ref_configs(True)
+        mlp = MLP(cfg, cfg['model']['coarse_mlp'])
+        mlp.load_state_dict({k[len('coarse_model.'):]: torch.from_numpy(v.copy()) for k, v in params.items()})
+        g = np.random.default_rng(seed)
+        P = 256
+        pts = torch.from_numpy(g.uniform(-1.2, 1.2, size=(P, 3)).astype(np.float32))
+        vd = g.standard_normal((P, 3)).astype(np.float32)
+        vd /= np.linalg.norm(vd, axis=-1, keepdims=True)
+        vd2 = g.standard_normal((P, V, 3)).astype(np.float32)
+        vd2 /= np.linalg.norm(vd2, axis=-1, keepdims=True)
+        inp = {'pts': pts, 'view_dirs': torch.from_numpy(vd), 'view_dirs2': torch.from_numpy(vd2)}
+        mlp.train()
+        rlog = []
+        torch.manual_seed(seed)
+        with record_rng(rlog):
+            out_t = mlp({k: v.clone() for k, v in inp.items()})
+        noise = rlog[0][1][:, 0]
+        mlp.eval()
+        out_e = mlp({k: v.clone() for k, v in inp.items()})
+        enc = mlp.pts_pos_enc_fn(pts)
+        npz(f'f2_mlp_v{V}', seed=seed, pts=pts, view_dirs=vd, view_dirs2=vd2, noise=noise, enc_pts=enc,
+            sigma_train=out_t['sigma'][:, 0], rgb_train=out_t['rgb'], vis_train=out_t['visibility'][:, 0],
+            vis2_train=out_t['visibility2'][..., 0],
+            sigma_eval=out_e['sigma'][:, 0], rgb_eval=out_e['rgb'], vis_eval=out_e['visibility'][:, 0],
+            vis2_eval=out_e['visibility2'][..., 0])
+
+
+# ------------------------------------------------------------------------------------------------ F3
+def gen_f3():
+    for scene, nf in (('fern', 2), ('dtu', 3)):
+        b = vo.synthetic_batch(40, 300 + nf, scene=scene, nf=nf)
+        ndc = b['ndc']
+        cfg = ref_configs(ndc)
+        model = ref_model(cfg, vo.init_params(1))
+        g = np.random.default_rng(31 + nf)
+        n, S, V = 40, 64, nf - 1
+        if ndc:
+            z = np.sort(g.uniform(0, 1, size=(n, S)).astype(np.float32), axis=1)
+            z[:4, -1] = 1.0                                      # exact z_ndc == 1 guard
+        else:
+            z = np.sort(g.uniform(0.09, 5.0, size=(n, S)).astype(np.float32), axis=1)
+        z = torch.from_numpy(z)
+        sigma = g.gamma(0.6, 8.0, size=(n, S)).astype(np.float32)
+        sigma[:, ::5] = 0.                                       # zero-density samples
+        sigma[4:8, 10] = 1e4                                     # alpha -> 1 saturation
+        rgb = g.random((n, S, 3), dtype=np.float32)
+        vis2 = g.random((n, S, V, 1), dtype=np.float32)
+        net = {'sigma': torch.from_numpy(sigma)[..., None], 'rgb': torch.from_numpy(rgb),
+               'visibility2': torch.from_numpy(vis2)}
+        o2 = vo.secondary_origins(b['poses'], b['pixel_id'][:, 0].long(), nf)
+        if ndc:
+            out = model.volume_rendering(net, z_vals_ndc=z, rays_d_ndc=b['rays_d_ndc'], rays_o=b['rays_o'],
+                                         rays_d=b['rays_d'], sec_views_vis=True)
+            metric = VipNeRF.convert_depth_from_ndc(z, b['rays_o'], b['rays_d'])
+        else:
+            out = model.volume_rendering(net, z_vals=z, rays_d=b['rays_d'], sec_views_vis=True)
+            metric = z
+        dirs2 = model.compute_other_view_dirs(z, b['rays_o'], b['rays_d'], o2)
+        extra = {k: b[k] for k in ('rays_o', 'rays_d') + (('rays_o_ndc', 'rays_d_ndc') if ndc else ())}
+        npz(f'f3_composite_{scene}', ndc=int(ndc), z=z, sigma=sigma, rgb=rgb, vis2=vis2[..., 0], rays_o2=o2,
+            metric_depth=metric, dirs2=dirs2, **extra, **{'out_' + k: v for k, v in out.items()})
+
+
+# ------------------------------------------------------------------------------------------------ F4 / F5
+PER_RAY = ['rgb', 'acc', 'depth', 'depth_var', 'depth_ndc', 'depth_var_ndc', 'visibility2']
+PER_SAMPLE = ['z_vals', 'alpha', 'visibility', 'weights', 'raw_sigma', 'raw_rgb', 'raw_visibility',
+              'raw_visibility2']
+
+
+def pack_outputs(out, levels):
+    d = {}
+    for lv in levels:
+        for k in PER_RAY + PER_SAMPLE:
+            kk = f'{k}_{lv}'
+            if kk in out:
+                d['out_' + kk] = out[kk]
+    return d
+
+
+def split_rng(rlog, n, n_coarse, n_fine):
+    """Reassemble the recorded draws (order: rand(N,Sc), randn per coarse netchunk..., rand(N,Sf), randn per
+    fine netchunk...) into (N,S) tensors."""
+    rands = [t for k, t in rlog if k == 'rand']
+    randns = [t for k, t in rlog if k == 'randn']
+    rng = {'t_rand': rands[0]}
+    flat = torch.cat([t.reshape(-1) for t in randns]) if randns else None
+    pc = n * n_coarse
+    if flat is not None:
+        rng['noise_coarse'] = flat[:pc].reshape(n, n_coarse)
+    if n_fine > 0:
+        rng['u'] = rands[1]
+        if flat is not None:
+            rng['noise_fine'] = flat[pc:].reshape(n, n_coarse + n_fine)
+    return rng
+
+
+def gen_f4():
+    n = 48
+    b = vo.synthetic_batch(n, 400, scene='fern', nf=2)
+    cfg = ref_configs(True, netchunk=2048, chunk=32)            # exercise both host loops
+    params = vo.init_params(11, scale=1.6)
+    model = ref_model(cfg, params).eval()
+    with torch.no_grad():
+        out_plain = model(ref_batch(b, 0))                                   # retraw False, no secondary
+        out_raw = model(ref_batch(b, 0), retraw=True, sec_views_vis=True)    # validation of a train frame
+    keys_plain = sorted(out_plain.keys())
+    d = pack_outputs(out_raw, ('coarse', 'fine'))
+    npz('f4_eval_fern', seed_params=11, scale_params=1.6, seed_batch=400, n=n,
+        keys_plain=np.array(keys_plain), **{'plain_' + k: v for k, v in out_plain.items()}, **d)
+
+
+def gen_f5(tag, scene, nf, n, n_sparse, seed, depth=8, width=256, n_fine=128, pscale=1.6):
+    b = vo.synthetic_batch(n, seed, scene=scene, nf=nf, n_sparse=n_sparse)
+    ndc = b['ndc']
+    levels = ('coarse', 'fine') if n_fine > 0 else ('coarse',)
+    cfg = ref_configs(ndc, depth=depth, width=width, n_fine=n_fine, netchunk=1024, chunk=4096,
+                      sparse=n_sparse > 0)
+    params = vo.init_params(seed + 1, depth=depth, width=width, levels=levels, scale=pscale)
+    model = ref_model(cfg, params).train()
+    lossc = LossComputer(cfg)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.999))
+    rlog = []
+    torch.manual_seed(seed)
+    with record_rng(rlog):
+        out = model(ref_batch(b, 40000))
+    rng = split_rng(rlog, n + n_sparse, 64, n_fine)
+    l40k = lossc.compute_losses(ref_batch(b, 40000), out)
+    l0 = lossc.compute_losses(ref_batch(b, 0), out)
+    opt.zero_grad(set_to_none=True)
+    l40k['TotalLoss'].backward()
+    grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+    opt.step()
+    after = {k: p.detach().clone() for k, p in model.named_parameters()}
+    d = pack_outputs(out, levels)
+    for nm, lv in (('l40k', l40k), ('l0', l0)):
+        for k, v in lv.items():
+            d[f'{nm}_{k}'] = (v['loss_value'] if isinstance(v, dict) else v).detach().reshape(())
+    for k, v in grads.items():
+        if v.numel() <= 4096:
+            d['grad_' + k] = v
+        d['gdig_' + k] = digest(v)
+    for k, v in after.items():
+        d['adig_' + k] = digest(v)
+    npz(f'f5_train_{tag}', scene=scene, nf=nf, n=n, n_sparse=n_sparse, seed_batch=seed, seed_params=seed + 1,
+        scale_params=pscale, depth=depth, width=width, n_fine=n_fine,
+        **{'rng_' + k: v for k, v in rng.items()}, **d)
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(8)
+    gen_f1()
+    gen_f2()
+    gen_f3()
+    gen_f4()
+    gen_f5('llff', 'fern', 2, 32, 0, 500)
+    gen_f5('realestate', 'realestate', 3, 16, 16, 510)
+    gen_f5('dtu', 'dtu', 3, 24, 0, 520)
+    gen_f5('toy', 'toy', 2, 64, 0, 530, depth=4, width=64, n_fine=0, pscale=1.0)

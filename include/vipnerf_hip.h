@@ -1,0 +1,240 @@
+/*
+ * vipnerf_hip.h -- C ABI of libvipnerf_hip.so: the MI355X (gfx950) implementation of ViP-NeRF's per-ray
+ * volumetric-rendering hot path.
+ *
+ * The reference (NagabhushanSN95/ViP-NeRF v1.0) is pure Python/PyTorch and has NO FFI of its own for this
+ * path; the boundary it offers is the Python module contract of src/models/VipNeRF01.py and
+ * src/loss_functions/ modules.  This header is the C surface a binding for that contract calls into; each entry
+ * point cites the reference function(s) it replaces (paths relative to the reference repo root).  The ctypes
+ * binding that implements the reference's module contract on top of it lives in
+ * vip-nerf_amd/vipnerf_hip/ and vip-nerf_amd/src/{models,loss_functions}/ (see INTEGRATION.md).
+ *
+ * Conventions
+ *   - plain C structs of device pointers and sizes; no torch types.  All tensors are row-major contiguous
+ *     fp32 unless noted (int32 sample indices, uint8 masks).
+ *   - the library BORROWS every pointer for the duration of the call (asynchronously: until the work queued
+ *     on `stream` has run).  It allocates nothing the caller must free; outputs and workspaces are caller
+ *     allocated (sizes from vipnerf_query_workspace).
+ *   - every function returns 0 on success, <0 on error (VIPNERF_E_*); vipnerf_last_error() gives the text
+ *     (thread local).  Nothing throws, nothing synchronises the device.
+ *   - re-entrant; all state is in the arguments.  One MLP topology is supported: 8x256 trunk, skip into
+ *     layer 5, positional-encoding degrees 10 (points) / 4 (directions), 128-wide view branch with an
+ *     rgb(3)+visibility(1) head -- the only topology any shipped reference config uses.
+ */
+#ifndef VIPNERF_HIP_H
+#define VIPNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIPNERF_ABI_VERSION 1
+
+#define VIPNERF_OK             0
+#define VIPNERF_E_ARG         (-1)   /* null / inconsistent argument */
+#define VIPNERF_E_UNSUPPORTED (-2)   /* configuration outside the supported topology / sizes */
+#define VIPNERF_E_HIP         (-3)   /* a HIP runtime call failed (text in vipnerf_last_error) */
+
+#define VIPNERF_MAX_SEC 3            /* secondary views V = nf-1 <= 3 (reference configs use nf in {2,3,4}) */
+#define VIPNERF_N_PARAMS 24          /* tensors of one MLP */
+
+typedef void *vipnerf_stream_t;      /* hipStream_t */
+
+/* Static configuration of one render call.  Mirrors the keys VipNeRF01.py reads from its `configs` dict
+ * (src/models/VipNeRF01.py:16-19,53,180-185,206-207,363,470). */
+typedef struct vipnerf_config {
+    int32_t ndc;          /* configs['data_loader']['ndc']: sample in NDC space, depths converted back */
+    int32_t n_coarse;     /* coarse_mlp.num_samples (64); multiple of 32, <= 256 */
+    int32_t n_fine;       /* fine_mlp.num_samples (128); 0 = coarse pass only; n_coarse+n_fine mult. of 32, <= 256 */
+    int32_t n_sec;        /* V: secondary views whose visibility is predicted this call (0 if !sec_views_vis) */
+    int32_t train;        /* model.training: stratified jitter (perturb) + sigma noise */
+    int32_t lindisp;      /* configs['model']['lindisp'] */
+    int32_t white_bkgd;   /* configs['model']['white_bkgd'] */
+    int32_t save_acts;    /* keep layer activations in the `acts` workspace for vipnerf_render_backward */
+    float   noise_std;    /* configs['model']['raw_noise_std'] (used when train) */
+    int32_t given_z_fine; /* parity tests (teacher forcing): out->fine.z_vals already holds the fine depths on
+                             entry; importance sampling is skipped.  0 in production. */
+    int32_t reserved[6];
+} vipnerf_config;
+
+/* One ray batch (render_rays' input_dict, src/models/VipNeRF01.py:74-98).  N = n_rays. */
+typedef struct vipnerf_rays {
+    int64_t n_rays;
+    const float *rays_o;      /* (N,3) world-space origin        input_dict['rays_o'] */
+    const float *rays_d;      /* (N,3) world-space direction     input_dict['rays_d'] */
+    const float *rays_o_s;    /* (N,3) sampling-space origin: rays_o_ndc if ndc else rays_o */
+    const float *rays_d_s;    /* (N,3) sampling-space direction: rays_d_ndc if ndc else rays_d */
+    const float *view_dirs;   /* (N,3) unit viewing direction    input_dict['view_dirs'] */
+    const float *near;        /* (N)   near_ndc if ndc else near */
+    const float *far;         /* (N)   far_ndc  if ndc else far */
+    const float *rays_o2;     /* (N,V,3) secondary camera centres (VipNeRF01.py:84-98); NULL if n_sec == 0 */
+} vipnerf_rays;
+
+/* Random numbers.  The reference draws them on the CPU generator inside the loop (VipNeRF01.py:200,242,551);
+ * here they are either supplied (parity tests feed the reference's recorded draws) or, where a pointer is
+ * NULL and cfg.train != 0, generated on device from a Philox4x32-10 stream keyed by (seed, offset). */
+typedef struct vipnerf_rng {
+    const float *t_rand;        /* (N,n_coarse) U[0,1)  stratified jitter */
+    const float *u;             /* (N,n_fine)   U[0,1)  inverse-CDF draws */
+    const float *noise_coarse;  /* (N,n_coarse) N(0,1)  sigma noise, coarse pass */
+    const float *noise_fine;    /* (N,n_coarse+n_fine)  sigma noise, fine pass */
+    uint64_t seed;
+    uint64_t offset;
+} vipnerf_rng;
+
+/* The 24 parameter tensors of one MLP in the reference's construction order (VipNeRF01.py:472-491),
+ * nn.Linear layout weight[out,in], bias[out]:
+ *   0..15  pts_linears[i].weight, pts_linears[i].bias, i = 0..7   (256x63, 256x256 x4, 256x319, 256x256 x2)
+ *   16,17  views_linears[0].weight (128x283), .bias
+ *   18,19  pts_output_linear.weight (1x256), .bias
+ *   20,21  feature_linear.weight (256x256), .bias
+ *   22,23  views_output_linear.weight (4x128), .bias */
+typedef struct vipnerf_mlp_params {
+    const float *p[VIPNERF_N_PARAMS];
+} vipnerf_mlp_params;
+
+typedef struct vipnerf_mlp_grads {
+    float *g[VIPNERF_N_PARAMS];  /* same shapes; OVERWRITTEN with dLoss/dparam */
+} vipnerf_mlp_grads;
+
+/* Outputs of one level (coarse or fine), S = samples of that level (n_coarse, or n_coarse+n_fine).
+ * Keys of render_rays' return dict (VipNeRF01.py:128-133,161-166 and volume_rendering :366-383). */
+typedef struct vipnerf_level_out {
+    float *z_vals;         /* (N,S)   z_vals_L */
+    float *raw_sigma;      /* (N,S)   raw_sigma_L[...,0]  (post-ReLU density) */
+    float *raw_rgb;        /* (N,S,3) raw_rgb_L */
+    float *raw_vis;        /* (N,S)   raw_visibility_L[...,0] */
+    float *raw_vis2;       /* (N,S,V) raw_visibility2_L[...,0]; NULL if n_sec == 0 */
+    float *alpha;          /* (N,S) */
+    float *visibility;     /* (N,S)   transmittance T */
+    float *weights;        /* (N,S) */
+    float *rgb;            /* (N,3) */
+    float *acc;            /* (N) */
+    float *depth;          /* (N)   metric depth */
+    float *depth_var;      /* (N) */
+    float *depth_ndc;      /* (N)   only if ndc, else may be NULL */
+    float *depth_var_ndc;  /* (N)   only if ndc */
+    float *vis2;           /* (N,V) visibility2_L; NULL if n_sec == 0 */
+} vipnerf_level_out;
+
+typedef struct vipnerf_outputs {
+    vipnerf_level_out coarse;
+    vipnerf_level_out fine;     /* ignored if n_fine == 0 */
+    int32_t *sample_inds;       /* (N,n_fine) searchsorted(cdf,u,right=True) indices, for the bit-exact check; may be NULL */
+    float   *z_samples;         /* (N,n_fine) importance samples before the merge; may be NULL */
+} vipnerf_outputs;
+
+/* dLoss/d(output) for the outputs the reference's losses differentiate.  Any pointer may be
+ * NULL (= zero gradient).  Same shapes as vipnerf_level_out. */
+typedef struct vipnerf_level_grads {
+    const float *rgb;          /* (N,3) */
+    const float *acc;          /* (N) */
+    const float *depth;        /* (N) */
+    const float *depth_ndc;    /* (N) */
+    const float *vis2;         /* (N,V) */
+    const float *visibility;   /* (N,S) dLoss/dT */
+    const float *weights;      /* (N,S) */
+    const float *alpha;        /* (N,S) */
+    const float *raw_sigma;    /* (N,S) */
+    const float *raw_rgb;      /* (N,S,3) */
+    const float *raw_vis;      /* (N,S) */
+    const float *raw_vis2;     /* (N,S,V) */
+} vipnerf_level_grads;
+
+typedef struct vipnerf_out_grads {
+    vipnerf_level_grads coarse;
+    vipnerf_level_grads fine;
+} vipnerf_out_grads;
+
+/* Loss inputs/outputs for the fused loss kernel (src/loss_functions/{MSE01,VisibilityLoss01,
+ * VisibilityPriorLoss01,SparseDepthMSE01}.py). */
+typedef struct vipnerf_loss_in {
+    const float   *target_rgb;        /* (N,3)   input_dict['target_rgb'] */
+    const uint8_t *mask_nerf;         /* (N)     input_dict['indices_mask_nerf'] */
+    const float   *prior;             /* (N,V)   visibility_prior_masks / _weights; NULL = ones */
+    const uint8_t *mask_sparse;       /* (N)     indices_mask_sparse_depth; NULL = SparseDepthMSE is 0 */
+    const float   *sparse_depth;      /* (N)     sparse_depth_values[:,0] */
+} vipnerf_loss_in;
+
+/* loss_values[8]: [0] MSE coarse, [1] MSE fine, [2] VisibilityLoss coarse, [3] fine, [4] VisibilityPrior
+ * coarse, [5] fine, [6] SparseDepthMSE, [7] unused.  Seeds are the UNWEIGHTED dLoss_k/d(output), written into
+ * caller buffers with vipnerf_level_out shapes: seed_rgb (N,3), seed_T (N,S), seed_raw_vis (N,S),
+ * seed_vis2 (N,V), seed_depth (N, fine level only). */
+typedef struct vipnerf_loss_level_seeds {
+    float *rgb; float *visibility; float *raw_vis; float *vis2; float *depth;
+} vipnerf_loss_level_seeds;
+
+typedef struct vipnerf_loss_out {
+    float *loss_values;               /* (8) device */
+    vipnerf_loss_level_seeds coarse, fine;
+    float *scratch;                   /* (8 * N) device scratch for the deterministic two-pass reduction */
+} vipnerf_loss_out;
+
+/* ---- library / error ------------------------------------------------------------------------------------ */
+int32_t vipnerf_abi_version(void);
+/* copies the calling thread's last error text (NUL terminated, truncated to n) */
+int32_t vipnerf_last_error(char *buf, size_t n);
+
+/* ---- weights -------------------------------------------------------------------------------------------- */
+/* Bytes of the packed (MFMA fragment order) image of one MLP. */
+size_t  vipnerf_packed_weights_bytes(void);
+/* Re-lay one MLP's nn.Linear tensors into the streaming order the kernels consume (forward image, transposed
+ * image for dgrad, LDS-resident heads/biases).  Replaces nothing in the reference; it is what lets
+ * MLP.forward (VipNeRF01.py:509-596) run as one kernel.  Call after every optimizer step. */
+int32_t vipnerf_pack_weights(const vipnerf_mlp_params *params, void *packed, vipnerf_stream_t stream);
+
+/* ---- workspace ------------------------------------------------------------------------------------------ */
+/* acts_bytes: per-call activation store written by render_forward when cfg.save_acts (0 otherwise), read by
+ * render_backward.  bwd_bytes: scratch of render_backward.  Both cover coarse + fine. */
+int32_t vipnerf_query_workspace(const vipnerf_config *cfg, int64_t n_rays, size_t *acts_bytes, size_t *bwd_bytes);
+
+/* ---- the hot path --------------------------------------------------------------------------------------- */
+/* VipNeRF.render_rays (src/models/VipNeRF01.py:74-171) for any number of rays (subsumes batchify_rays
+ * :47-72 and batchify :295-329): coarse depths -> MLP -> compositing -> inverse-CDF sampling -> fine MLP ->
+ * compositing.  `rng` may be NULL when !cfg.train. `acts` may be NULL when !cfg.save_acts. */
+int32_t vipnerf_render_forward(const vipnerf_config *cfg, const vipnerf_rays *rays, const vipnerf_rng *rng,
+                               const void *packed_coarse, const void *packed_fine,
+                               const vipnerf_outputs *out, void *acts, vipnerf_stream_t stream);
+
+/* Backward of the above w.r.t. the MLP parameters (autograd of VipNeRF01.py:74-171; no gradient flows to
+ * rays, depths or sampling, VipNeRF01.py:213).  `out` must hold the forward's outputs, `acts` its activation
+ * store. */
+int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *rays,
+                                const void *packed_coarse, const void *packed_fine,
+                                const vipnerf_outputs *out, const vipnerf_out_grads *gout,
+                                const void *acts, void *bwd_ws,
+                                const vipnerf_mlp_grads *grads_coarse, const vipnerf_mlp_grads *grads_fine,
+                                vipnerf_stream_t stream);
+
+/* MSE01.compute_loss, VisibilityLoss01.compute_loss, VisibilityPriorLoss01.compute_loss and
+ * SparseDepthMSE01.compute_loss in one pass: unweighted loss values + unweighted gradient seeds. */
+int32_t vipnerf_losses_forward(const vipnerf_config *cfg, int64_t n_rays, const vipnerf_loss_in *in,
+                               const vipnerf_outputs *out, const vipnerf_loss_out *lout,
+                               vipnerf_stream_t stream);
+
+/* ---- stage-wise entry points (used by the parity tests; each is also a valid standalone op) ------------- */
+/* VipNeRF.get_z_vals_coarse (VipNeRF01.py:173-203).  t_rand NULL = no jitter. */
+int32_t vipnerf_coarse_depths(int64_t n_rays, int32_t n_samples, int32_t lindisp, const float *near,
+                              const float *far, const float *t_rand, float *z_out, vipnerf_stream_t stream);
+/* VipNeRF.get_z_vals_fine + sample_pdf (VipNeRF01.py:205-262): u NULL = deterministic linspace.
+ * z_fine (N,n_coarse+n_fine) ascending; inds (N,n_fine) int32; z_samples (N,n_fine). */
+int32_t vipnerf_sample_fine(int64_t n_rays, int32_t n_coarse, int32_t n_fine, const float *z_coarse,
+                            const float *weights_coarse, const float *u, float *z_fine, int32_t *inds,
+                            float *z_samples, vipnerf_stream_t stream);
+/* MLP.forward (VipNeRF01.py:509-596) on explicit points: pts (P,3), view_dirs (P,3), view_dirs2 (P,V,3) or
+ * NULL, noise (P) or NULL -> sigma (P), rgb (P,3), vis (P), vis2 (P,V). */
+int32_t vipnerf_mlp_forward(int64_t n_points, int32_t n_sec, const float *pts, const float *view_dirs,
+                            const float *view_dirs2, const float *noise, float noise_std, const void *packed,
+                            float *sigma, float *rgb, float *vis, float *vis2, vipnerf_stream_t stream);
+/* VipNeRF.volume_rendering (+ convert_depth_from_ndc) (VipNeRF01.py:331-403) on explicit network outputs
+ * held in lvl->raw_* and lvl->z_vals; fills the remaining fields of *lvl. */
+int32_t vipnerf_composite(const vipnerf_config *cfg, const vipnerf_rays *rays, int32_t n_samples,
+                          const vipnerf_level_out *lvl, vipnerf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIPNERF_HIP_H */

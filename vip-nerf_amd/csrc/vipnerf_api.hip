@@ -1,0 +1,288 @@
+// C ABI of libvipnerf_hip.so (include/vipnerf_hip.h): argument checking and kernel sequencing.  No device
+// synchronisation, no allocation; everything is queued on the caller's stream.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "vipnerf_mlp.h"
+#include "vipnerf_ray.h"
+#include "vipnerf_wgrad.h"
+
+namespace vn {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static int check_cfg(const vipnerf_config *cfg) {
+    if (!cfg) { set_error("cfg is NULL"); return VIPNERF_E_ARG; }
+    if (cfg->n_coarse < 32 || cfg->n_coarse > 256 || cfg->n_coarse % 32) {
+        set_error("n_coarse=%d unsupported (multiple of 32 in [32,256])", cfg->n_coarse); return VIPNERF_E_UNSUPPORTED; }
+    if (cfg->n_fine < 0 || (cfg->n_fine > 0 && ((cfg->n_coarse + cfg->n_fine) % 32 || cfg->n_coarse + cfg->n_fine > 256))) {
+        set_error("n_fine=%d unsupported (n_coarse+n_fine multiple of 32, <= 256)", cfg->n_fine); return VIPNERF_E_UNSUPPORTED; }
+    if (cfg->n_sec < 0 || cfg->n_sec > VIPNERF_MAX_SEC) {
+        set_error("n_sec=%d unsupported (0..%d)", cfg->n_sec, VIPNERF_MAX_SEC); return VIPNERF_E_UNSUPPORTED; }
+    return VIPNERF_OK;
+}
+
+static int check_rays(const vipnerf_config *cfg, const vipnerf_rays *r) {
+    if (!r) { set_error("rays is NULL"); return VIPNERF_E_ARG; }
+    if (r->n_rays < 0) { set_error("n_rays < 0"); return VIPNERF_E_ARG; }
+    if (r->n_rays == 0) return VIPNERF_OK;
+    if (!r->rays_o || !r->rays_d || !r->rays_o_s || !r->rays_d_s || !r->view_dirs || !r->near || !r->far) {
+        set_error("a required ray pointer is NULL"); return VIPNERF_E_ARG; }
+    if (cfg->n_sec > 0 && !r->rays_o2) { set_error("n_sec > 0 but rays_o2 is NULL"); return VIPNERF_E_ARG; }
+    return VIPNERF_OK;
+}
+
+static int check_level(const vipnerf_config *cfg, const vipnerf_level_out *l, const char *name) {
+    if (!l->z_vals || !l->raw_sigma || !l->raw_rgb || !l->raw_vis || !l->alpha || !l->visibility || !l->weights ||
+        !l->rgb || !l->acc || !l->depth || !l->depth_var || (cfg->n_sec > 0 && (!l->raw_vis2 || !l->vis2))) {
+        set_error("a required output pointer of level '%s' is NULL", name); return VIPNERF_E_ARG; }
+    return VIPNERF_OK;
+}
+
+static PointSrc ray_points(const vipnerf_config *cfg, const vipnerf_rays *r, int S, const float *z) {
+    PointSrc s;
+    memset(&s, 0, sizeof(s));
+    s.P = r->n_rays * S; s.S = S; s.V = cfg->n_sec; s.rays_mode = 1; s.ndc = cfg->ndc;
+    s.z = z; s.rays_o = r->rays_o; s.rays_d = r->rays_d; s.rays_o_s = r->rays_o_s; s.rays_d_s = r->rays_d_s;
+    s.view_dirs = r->view_dirs; s.rays_o2 = r->rays_o2;
+    return s;
+}
+
+struct LevelWs { size_t acts_off, bwd_off; };   // float offsets of the fine level inside the workspaces
+
+static size_t bwd_total(size_t P, int V) { return bwd_layout(P, V).total; }
+
+}  // namespace vn
+
+using namespace vn;
+
+extern "C" {
+
+int32_t vipnerf_abi_version(void) { return VIPNERF_ABI_VERSION; }
+
+int32_t vipnerf_last_error(char *buf, size_t n) {
+    if (!buf || n == 0) return VIPNERF_E_ARG;
+    strncpy(buf, g_err, n - 1);
+    buf[n - 1] = 0;
+    return VIPNERF_OK;
+}
+
+size_t vipnerf_packed_weights_bytes(void) { return PK_TOTAL_F * sizeof(float); }
+
+int32_t vipnerf_pack_weights(const vipnerf_mlp_params *params, void *packed, vipnerf_stream_t stream) {
+    if (!params || !packed) { set_error("pack_weights: NULL argument"); return VIPNERF_E_ARG; }
+    for (int i = 0; i < VIPNERF_N_PARAMS; ++i)
+        if (!params->p[i]) { set_error("pack_weights: parameter %d is NULL", i); return VIPNERF_E_ARG; }
+    return launch_pack(params, packed, (hipStream_t)stream);
+}
+
+int32_t vipnerf_query_workspace(const vipnerf_config *cfg, int64_t n_rays, size_t *acts_bytes, size_t *bwd_bytes) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (n_rays < 0) { set_error("n_rays < 0"); return VIPNERF_E_ARG; }
+    const size_t Pc = (size_t)n_rays * cfg->n_coarse;
+    const size_t Pf = cfg->n_fine > 0 ? (size_t)n_rays * (cfg->n_coarse + cfg->n_fine) : 0;
+    if (acts_bytes)
+        *acts_bytes = cfg->save_acts ? (act_layout(Pc, cfg->n_sec).total + (Pf ? act_layout(Pf, cfg->n_sec).total : 0)) * sizeof(float) : 0;
+    if (bwd_bytes) {
+        const size_t a = bwd_total(Pc, cfg->n_sec), b = Pf ? bwd_total(Pf, cfg->n_sec) : 0;
+        *bwd_bytes = (a > b ? a : b) * sizeof(float);       // levels run one after the other
+    }
+    return VIPNERF_OK;
+}
+
+int32_t vipnerf_coarse_depths(int64_t n_rays, int32_t n_samples, int32_t lindisp, const float *near,
+                              const float *far, const float *t_rand, float *z_out, vipnerf_stream_t stream) {
+    if (!near || !far || !z_out) { set_error("coarse_depths: NULL argument"); return VIPNERF_E_ARG; }
+    if (n_samples < 2) { set_error("coarse_depths: n_samples < 2"); return VIPNERF_E_UNSUPPORTED; }
+    return launch_coarse_z(n_rays, n_samples, lindisp, near, far, t_rand, 0, 0, 0, z_out, (hipStream_t)stream);
+}
+
+int32_t vipnerf_sample_fine(int64_t n_rays, int32_t n_coarse, int32_t n_fine, const float *z_coarse,
+                            const float *weights_coarse, const float *u, float *z_fine, int32_t *inds,
+                            float *z_samples, vipnerf_stream_t stream) {
+    if (!z_coarse || !weights_coarse || !z_fine) { set_error("sample_fine: NULL argument"); return VIPNERF_E_ARG; }
+    if (n_coarse < 3 || n_fine < 1 || n_coarse + n_fine > 1024) { set_error("sample_fine: unsupported sizes"); return VIPNERF_E_UNSUPPORTED; }
+    SampleArgs a;
+    memset(&a, 0, sizeof(a));
+    a.N = n_rays; a.Sc = n_coarse; a.Sf = n_fine; a.z_coarse = z_coarse; a.w_coarse = weights_coarse; a.u = u;
+    a.z_fine = z_fine; a.inds = inds; a.z_samples = z_samples;
+    return launch_sample_fine(a, (hipStream_t)stream);
+}
+
+int32_t vipnerf_mlp_forward(int64_t n_points, int32_t n_sec, const float *pts, const float *view_dirs,
+                            const float *view_dirs2, const float *noise, float noise_std, const void *packed,
+                            float *sigma, float *rgb, float *vis, float *vis2, vipnerf_stream_t stream) {
+    if (!pts || !view_dirs || !packed || !sigma || !rgb || !vis || (n_sec > 0 && (!view_dirs2 || !vis2))) {
+        set_error("mlp_forward: NULL argument"); return VIPNERF_E_ARG; }
+    if (n_sec < 0 || n_sec > VIPNERF_MAX_SEC) { set_error("mlp_forward: n_sec=%d unsupported", n_sec); return VIPNERF_E_UNSUPPORTED; }
+    MlpFwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src.P = n_points; a.src.S = 1; a.src.V = n_sec; a.src.rays_mode = 0;
+    a.src.pts = pts; a.src.dirs = view_dirs; a.src.dirs2 = view_dirs2;
+    a.ns.noise = noise; a.ns.std = noise_std;
+    a.packed = (const float *)packed;
+    a.sigma = sigma; a.rgb = rgb; a.vis = vis; a.vis2 = vis2;
+    return launch_mlp_fwd(a, (hipStream_t)stream);
+}
+
+int32_t vipnerf_composite(const vipnerf_config *cfg, const vipnerf_rays *rays, int32_t n_samples,
+                          const vipnerf_level_out *lvl, vipnerf_stream_t stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (!rays || !lvl) { set_error("composite: NULL argument"); return VIPNERF_E_ARG; }
+    if ((rc = check_level(cfg, lvl, "composite"))) return rc;
+    CompositeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.N = rays->n_rays; a.S = n_samples; a.V = cfg->n_sec; a.ndc = cfg->ndc; a.white_bkgd = cfg->white_bkgd;
+    a.rays_o = rays->rays_o; a.rays_d = rays->rays_d; a.rays_d_s = rays->rays_d_s; a.lvl = *lvl;
+    return launch_composite(a, (hipStream_t)stream);
+}
+
+int32_t vipnerf_render_forward(const vipnerf_config *cfg, const vipnerf_rays *rays, const vipnerf_rng *rng,
+                               const void *packed_coarse, const void *packed_fine,
+                               const vipnerf_outputs *out, void *acts, vipnerf_stream_t stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if ((rc = check_rays(cfg, rays))) return rc;
+    if (!out || !packed_coarse || (cfg->n_fine > 0 && !packed_fine)) { set_error("render_forward: NULL argument"); return VIPNERF_E_ARG; }
+    if ((rc = check_level(cfg, &out->coarse, "coarse"))) return rc;
+    if (cfg->n_fine > 0 && (rc = check_level(cfg, &out->fine, "fine"))) return rc;
+    if (cfg->save_acts && !acts) { set_error("render_forward: save_acts set but acts is NULL"); return VIPNERF_E_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t N = rays->n_rays;
+    if (N == 0) return VIPNERF_OK;
+    const int Sc = cfg->n_coarse, Sf = cfg->n_fine, V = cfg->n_sec;
+    const bool train = cfg->train != 0;
+    const uint64_t seed = rng ? rng->seed : 0, offset = rng ? rng->offset : 0;
+
+    // 1. coarse depths
+    const float *t_rand = (train && rng) ? rng->t_rand : nullptr;
+    rc = launch_coarse_z(N, Sc, cfg->lindisp, rays->near, rays->far, t_rand, train && !t_rand, seed, offset,
+                         out->coarse.z_vals, st);
+    if (rc) return rc;
+
+    for (int lv = 0; lv < (Sf > 0 ? 2 : 1); ++lv) {
+        const vipnerf_level_out &L = lv ? out->fine : out->coarse;
+        const int S = lv ? Sc + Sf : Sc;
+        if (lv == 1 && !cfg->given_z_fine) {
+            // 4. importance sampling + sorted merge
+            SampleArgs sa;
+            memset(&sa, 0, sizeof(sa));
+            sa.N = N; sa.Sc = Sc; sa.Sf = Sf; sa.z_coarse = out->coarse.z_vals; sa.w_coarse = out->coarse.weights;
+            sa.u = (train && rng) ? rng->u : nullptr;
+            sa.device_rng = train && !sa.u; sa.seed = seed; sa.offset = offset;
+            sa.z_fine = L.z_vals; sa.inds = out->sample_inds; sa.z_samples = out->z_samples;
+            if ((rc = launch_sample_fine(sa, st))) return rc;
+        }
+        // 2./5. MLP
+        MlpFwdArgs ma;
+        memset(&ma, 0, sizeof(ma));
+        ma.src = ray_points(cfg, rays, S, L.z_vals);
+        if (train && cfg->noise_std > 0.f) {
+            ma.ns.noise = rng ? (lv ? rng->noise_fine : rng->noise_coarse) : nullptr;
+            ma.ns.device_rng = !ma.ns.noise;
+            ma.ns.std = cfg->noise_std;
+            ma.ns.stream = lv ? RS_NOISE_F : RS_NOISE_C;
+            ma.ns.seed = seed; ma.ns.offset = offset;
+        }
+        ma.packed = (const float *)(lv ? packed_fine : packed_coarse);
+        ma.sigma = L.raw_sigma; ma.rgb = L.raw_rgb; ma.vis = L.raw_vis; ma.vis2 = L.raw_vis2;
+        if (cfg->save_acts) {
+            const size_t Pc = (size_t)N * Sc;
+            ma.al = act_layout((size_t)N * S, V);
+            ma.acts = (float *)acts + (lv ? act_layout(Pc, V).total : 0);
+        }
+        if ((rc = launch_mlp_fwd(ma, st))) return rc;
+        // 3./6. compositing
+        CompositeArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.N = N; ca.S = S; ca.V = V; ca.ndc = cfg->ndc; ca.white_bkgd = cfg->white_bkgd;
+        ca.rays_o = rays->rays_o; ca.rays_d = rays->rays_d; ca.rays_d_s = rays->rays_d_s; ca.lvl = L;
+        if ((rc = launch_composite(ca, st))) return rc;
+    }
+    return VIPNERF_OK;
+}
+
+int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *rays,
+                                const void *packed_coarse, const void *packed_fine,
+                                const vipnerf_outputs *out, const vipnerf_out_grads *gout,
+                                const void *acts, void *bwd_ws,
+                                const vipnerf_mlp_grads *grads_coarse, const vipnerf_mlp_grads *grads_fine,
+                                vipnerf_stream_t stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if ((rc = check_rays(cfg, rays))) return rc;
+    if (!out || !gout || !acts || !bwd_ws || !packed_coarse || !grads_coarse || (cfg->n_fine > 0 && (!packed_fine || !grads_fine))) {
+        set_error("render_backward: NULL argument"); return VIPNERF_E_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t N = rays->n_rays;
+    const int Sc = cfg->n_coarse, Sf = cfg->n_fine, V = cfg->n_sec;
+    for (int lv = (Sf > 0 ? 1 : 0); lv >= 0; --lv) {
+        const vipnerf_level_out &L = lv ? out->fine : out->coarse;
+        const vipnerf_mlp_grads *G = lv ? grads_fine : grads_coarse;
+        for (int i = 0; i < VIPNERF_N_PARAMS; ++i)
+            if (!G->g[i]) { set_error("render_backward: grad pointer %d is NULL", i); return VIPNERF_E_ARG; }
+        if (N == 0) {
+            continue;
+        }
+        const int S = lv ? Sc + Sf : Sc;
+        const size_t P = (size_t)N * S;
+        const BwdLayout bl = bwd_layout(P, V);
+        float *bw = (float *)bwd_ws;
+        // 1. compositing backward -> dLoss/d(raw network outputs)
+        CompositeBwdArgs cb;
+        memset(&cb, 0, sizeof(cb));
+        cb.N = N; cb.S = S; cb.V = V; cb.ndc = cfg->ndc; cb.white_bkgd = cfg->white_bkgd;
+        cb.rays_o = rays->rays_o; cb.rays_d = rays->rays_d; cb.rays_d_s = rays->rays_d_s; cb.lvl = L;
+        cb.g = lv ? gout->fine : gout->coarse;
+        cb.dsig = bw + bl.dsig; cb.drgb = bw + bl.drgb; cb.dvis = bw + bl.dvis; cb.dvis2 = bw + bl.dvis2;
+        if ((rc = launch_composite_bwd(cb, st))) return rc;
+        // 2. MLP data gradients (register-chained, transposed weights)
+        MlpBwdArgs mb;
+        memset(&mb, 0, sizeof(mb));
+        mb.src = ray_points(cfg, rays, S, L.z_vals);
+        mb.packed = (const float *)(lv ? packed_fine : packed_coarse);
+        mb.sigma = L.raw_sigma; mb.rgb = L.raw_rgb; mb.vis = L.raw_vis; mb.vis2 = L.raw_vis2;
+        mb.al = act_layout(P, V);
+        mb.acts = (const float *)acts + (lv ? act_layout((size_t)N * Sc, V).total : 0);
+        mb.bwd = bw; mb.bl = bl;
+        if ((rc = launch_mlp_bwd(mb, st))) return rc;
+        // 3. weight gradients: dW = dY^T H as MFMA GEMMs over the point axis
+        if ((rc = launch_wgrad(P, V, mb.acts, mb.al, bw, bl, G, st))) return rc;
+    }
+    return VIPNERF_OK;
+}
+
+int32_t vipnerf_losses_forward(const vipnerf_config *cfg, int64_t n_rays, const vipnerf_loss_in *in,
+                               const vipnerf_outputs *out, const vipnerf_loss_out *lout,
+                               vipnerf_stream_t stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (!in || !out || !lout || !in->target_rgb || !lout->loss_values || !lout->scratch) {
+        set_error("losses_forward: NULL argument"); return VIPNERF_E_ARG; }
+    if (in->mask_sparse && !in->sparse_depth) { set_error("losses_forward: mask_sparse without sparse_depth"); return VIPNERF_E_ARG; }
+    LossArgs a;
+    memset(&a, 0, sizeof(a));
+    a.N = n_rays; a.V = cfg->n_sec; a.n_levels = cfg->n_fine > 0 ? 2 : 1;
+    a.S_coarse = cfg->n_coarse; a.S_fine = cfg->n_coarse + cfg->n_fine;
+    a.in = *in; a.coarse = out->coarse; a.fine = out->fine;
+    a.seeds_coarse = lout->coarse; a.seeds_fine = lout->fine;
+    for (int lv = 0; lv < a.n_levels; ++lv) {
+        const vipnerf_loss_level_seeds &s = lv ? a.seeds_fine : a.seeds_coarse;
+        if (!s.rgb || !s.visibility || !s.raw_vis || (a.V > 0 && !s.vis2)) {
+            set_error("losses_forward: a seed pointer is NULL"); return VIPNERF_E_ARG; }
+    }
+    a.partial = lout->scratch; a.counts = lout->scratch + 7 * (size_t)n_rays; a.loss_values = lout->loss_values;
+    return launch_losses(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

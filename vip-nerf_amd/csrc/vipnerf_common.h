@@ -1,0 +1,221 @@
+// Internal definitions shared by the gfx950 kernels of libvipnerf_hip.so.
+//
+// Design in one paragraph (DESIGN.md has the long form): the MLP runs TRANSPOSED and REGISTER-CHAINED.  A
+// wave owns 32 points (MFMA columns); a layer is H_out^T[256 x 32] = W[256 x K] * H_in^T[K x 32] computed as
+// 8 row tiles of v_mfma_f32_32x32x2_f32.  In that orientation the C/D fragment of one layer (lane = point,
+// registers = output features) is, register for register, a valid B fragment of the next layer provided the
+// contraction index of that layer is enumerated in the order feat(r, h) below -- so activations never leave
+// the register file between layers and only the WEIGHTS move: they are pre-packed once per optimizer step into
+// exactly the per-lane A-fragment order (vipnerf_pack.hip) and streamed L2 -> LDS in 32 KB stages shared by
+// the 4 waves of a workgroup.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/vipnerf_hip.h"
+
+namespace vn {
+
+// ----------------------------------------------------------------------------------------------- topology
+constexpr int W = 256;          // trunk width
+constexpr int WV = 128;         // view-branch width
+constexpr int D = 8;            // trunk depth
+constexpr int LP = 10;          // positional-encoding degree, points
+constexpr int LV = 4;           // positional-encoding degree, directions
+constexpr int DPE = 3 + 6 * LP; // 63
+constexpr int DVE = 3 + 6 * LV; // 27
+constexpr int DPE_PAD = 64;
+constexpr int DVE_PAD = 32;
+constexpr int SKIP_LAYER = 5;   // layer whose input is [gamma(x), h]
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// ----------------------------------------------------------------------------------------------- fragments
+// v_mfma_f32_32x32x2_f32: D[i][j] += sum_{kk<2} A[i][kk] B[kk][j];  lane l supplies A[i = l&31][kk = l>>5] and
+// B[kk = l>>5][j = l&31]; D register r of lane l is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+// With 8 row tiles, "register index" r in [0,128) = 16*tile + reg.  feat(r, h) is the feature (row) that
+// register r of a lane in half h holds.
+__host__ __device__ inline int feat_of(int r, int h) {
+    const int t = r >> 4, rr = r & 15;
+    return 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+}
+
+// ----------------------------------------------------------------------------------------------- packed image
+// One chunk = the A operands of 4 consecutive k-steps for one 32-row tile: 64 lanes x float4 = 1 KiB.
+constexpr int CHUNK_F = 256;                    // floats per chunk
+constexpr int STAGE_CHUNKS = 32;
+constexpr int STAGE_F = CHUNK_F * STAGE_CHUNKS; // 8192 floats = 32 KiB
+
+// forward stream, in consumption order (stage indices)
+constexpr int FS_L0PE = 0;          // 2 stages: 8 tiles x 8 kgroups (K = 64: gamma(x))
+constexpr int FS_L1 = 2;            // 8 stages each for L1..L4
+constexpr int FS_L5PE = 34;         // 2 stages
+constexpr int FS_L5 = 36;           // 8 stages
+constexpr int FS_L6 = 44;
+constexpr int FS_L7 = 52;
+constexpr int FS_FEAT = 60;         // feature_linear
+constexpr int FS_VIEW = 68;         // views_linears[0][:, 0:256]: 4 tiles x 32 kgroups = 4 stages
+constexpr int F_STAGES = 72;
+
+// backward (dgrad) stream: A = W^T
+constexpr int BS_VIEW = 0;          // 4 stages: 8 tiles(k) x 16 kgroups(o in 128)
+constexpr int BS_FEAT = 4;          // 8 stages
+constexpr int BS_L7 = 12;           // then L6, L5 (h part), L4, L3, L2, L1: 8 stages each
+constexpr int B_STAGES = 68;
+
+// LDS-resident block (floats)
+constexpr int R_DIRW = 0;                       // 4 kgroups x 4 tiles chunks: views_linears[0][:, 256:283]
+constexpr int R_BIAS = R_DIRW + 16 * CHUNK_F;   // [8 layers][8 tiles][2 halves][16]
+constexpr int R_BFEAT = R_BIAS + D * W;         // [8][2][16]
+constexpr int R_BVIEW = R_BFEAT + W;            // [4][2][16]
+constexpr int R_WSIG = R_BVIEW + WV;            // [2][128]  w_sigma[feat(r,h)]
+constexpr int R_WOUT = R_WSIG + W;              // [2][4][64] W_o[c][feat(r,h)]
+constexpr int R_BHEAD = R_WOUT + 4 * WV;        // b_sigma, b_o[0..3], pad
+constexpr int R_TOTAL = R_BHEAD + 8;            // 7304 floats
+constexpr int R_TOTAL_PAD = 7424;               // multiple of 256
+
+constexpr size_t PK_FWD = 0;
+constexpr size_t PK_BWD = PK_FWD + (size_t)F_STAGES * STAGE_F;
+constexpr size_t PK_RES = PK_BWD + (size_t)B_STAGES * STAGE_F;
+constexpr size_t PK_TOTAL_F = PK_RES + R_TOTAL_PAD;
+
+// parameter slots (vipnerf_mlp_params::p)
+constexpr int P_LW0 = 0;      // pts_linears[i].weight = 2*i, bias = 2*i+1
+constexpr int P_VW = 16, P_VB = 17, P_SW = 18, P_SB = 19, P_FW = 20, P_FB = 21, P_OW = 22, P_OB = 23;
+
+__host__ __device__ inline int layer_in_dim(int i) { return i == 0 ? DPE : (i == SKIP_LAYER ? W + DPE : W); }
+
+// ----------------------------------------------------------------------------------------------- workspaces
+// Activation store of one level (floats).  P = points of the level.
+struct ActLayout {
+    size_t h[D];      // [P][256] output of pts_linears[i] (post ReLU)
+    size_t feat;      // [P][256]
+    size_t g[1 + VIPNERF_MAX_SEC];    // [P][128] view-branch hidden (post ReLU), per direction
+    size_t pex;       // [P][64]  gamma(x), zero padded
+    size_t ped[1 + VIPNERF_MAX_SEC];  // [P][32]  gamma(dir), zero padded, per direction
+    size_t total;
+};
+__host__ __device__ inline ActLayout act_layout(size_t P, int V) {
+    ActLayout a; size_t o = 0;
+    for (int i = 0; i < D; ++i) { a.h[i] = o; o += P * W; }
+    a.feat = o; o += P * W;
+    for (int k = 0; k <= VIPNERF_MAX_SEC; ++k) { a.g[k] = o; if (k <= V) o += P * WV; }
+    a.pex = o; o += P * DPE_PAD;
+    for (int k = 0; k <= VIPNERF_MAX_SEC; ++k) { a.ped[k] = o; if (k <= V) o += P * DVE_PAD; }
+    a.total = o;
+    return a;
+}
+
+// Backward scratch of one level (floats).
+struct BwdLayout {
+    size_t dy[D];     // [P][256] dLoss/d(pre-activation of pts_linears[i])
+    size_t dyf;       // [P][256] dLoss/d(feature)
+    size_t dyv[1 + VIPNERF_MAX_SEC];  // [P][128] per direction
+    size_t dyvsum;    // [P][128]
+    size_t dq[1 + VIPNERF_MAX_SEC];   // [P][8]: a=0: d(pre-sigmoid rgb,vis), d(sigma_raw); a>=1: (0,0,0,d pre-sigmoid vis2_a)
+    size_t dsig, drgb, dvis, dvis2;   // [P], [P][3], [P], [P][V]: dLoss/d(raw network outputs)
+    size_t partial;   // wgrad partial sums
+    size_t total;
+};
+// wgrad work split: the point axis is cut into chunks; every (GEMM, chunk) pair is one workgroup that writes
+// its partial product to `partial`, then an ordered reduction sums the chunks (deterministic, no atomics).
+constexpr int WGRAD_CHUNK_PTS = 4096;
+constexpr int WGRAD_MAX_CHUNKS = 256;
+__host__ __device__ inline int wgrad_chunks(size_t P) {
+    size_t c = (P + WGRAD_CHUNK_PTS - 1) / WGRAD_CHUNK_PTS;
+    return (int)(c < 1 ? 1 : (c > WGRAD_MAX_CHUNKS ? WGRAD_MAX_CHUNKS : c));
+}
+// floats of partial output per chunk: sum over GEMMs of Mp*Kp (+ Mp for the bias column sums)
+__host__ __device__ inline size_t wgrad_partial_per_chunk(int V) {
+    size_t f = 0;
+    f += 2 * (size_t)(256 * 64 + 256);          // layer 0, layer 5 gamma(x) part
+    f += 8 * (size_t)(256 * 256 + 256);         // layers 1-4, 5(h part), 6, 7, feature
+    f += (size_t)(32 * 256 + 32);               // sigma head
+    f += (size_t)(128 * 256 + 128);             // view layer, feature columns
+    f += (size_t)(1 + V) * (128 * 32 + 128);    // view layer, direction columns (per direction)
+    f += (size_t)(1 + V) * (32 * 128 + 32);     // output head (per direction)
+    return f;
+}
+__host__ __device__ inline BwdLayout bwd_layout(size_t P, int V) {
+    BwdLayout b; size_t o = 0;
+    for (int i = 0; i < D; ++i) { b.dy[i] = o; o += P * W; }
+    b.dyf = o; o += P * W;
+    for (int k = 0; k <= VIPNERF_MAX_SEC; ++k) { b.dyv[k] = o; if (k <= V) o += P * WV; }
+    b.dyvsum = o; o += P * WV;
+    for (int k = 0; k <= VIPNERF_MAX_SEC; ++k) { b.dq[k] = o; if (k <= V) o += P * 8; }
+    b.dsig = o; o += P;
+    b.drgb = o; o += 3 * P;
+    b.dvis = o; o += P;
+    b.dvis2 = o; o += P * (V > 0 ? V : 1);
+    o = (o + 63) & ~(size_t)63;
+    b.partial = o; o += (size_t)wgrad_chunks(P) * wgrad_partial_per_chunk(V);
+    b.total = o;
+    return b;
+}
+
+// ----------------------------------------------------------------------------------------------- device helpers
+#if defined(__HIPCC__)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// inclusive scans across the 64 lanes of a wave
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(v, o, 64); if (lane >= o) v *= t; }
+    return v;
+}
+__device__ __forceinline__ float wave_scan_add(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+    return v;
+}
+__device__ __forceinline__ float wave_rscan_add(float v, int lane) {   // inclusive suffix sum
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { float t = __shfl_down(v, o, 64); if (lane + o < 64) v += t; }
+    return v;
+}
+
+// Philox4x32-10 (Salmon et al. 2011): one 128-bit counter -> four 32-bit words.
+__device__ __forceinline__ uint4 philox4x32(uint4 c, uint2 k) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
+        const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += W0; k.y += W1;
+    }
+    return c;
+}
+// stream ids for the on-device generator
+enum { RS_TRAND = 1, RS_U = 2, RS_NOISE_C = 3, RS_NOISE_F = 4 };
+__device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t offset, uint32_t stream, uint64_t idx) {
+    uint4 c = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), stream, (uint32_t)offset);
+    uint4 r = philox4x32(c, make_uint2((uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32)));
+    return (float)(r.x >> 8) * (1.0f / 16777216.0f);                  // [0,1), 24 bits like torch.rand
+}
+__device__ __forceinline__ float rng_normal(uint64_t seed, uint64_t offset, uint32_t stream, uint64_t idx) {
+    uint4 c = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), stream, (uint32_t)offset);
+    uint4 r = philox4x32(c, make_uint2((uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32)));
+    const float u1 = ((float)(r.x >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0,1]
+    const float u2 = (float)(r.y >> 8) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+#endif
+
+// ----------------------------------------------------------------------------------------------- error plumbing
+void set_error(const char *fmt, ...);
+#define VN_HIP(call)                                                                                 \
+    do {                                                                                             \
+        hipError_t e__ = (call);                                                                     \
+        if (e__ != hipSuccess) {                                                                     \
+            vn::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return VIPNERF_E_HIP;                                                                    \
+        }                                                                                            \
+    } while (0)
+
+}  // namespace vn

@@ -1,0 +1,220 @@
+// Argument blocks and device building blocks shared by the forward and backward MLP kernels.
+#pragma once
+#include "vipnerf_common.h"
+
+namespace vn {
+
+// Where a workgroup's points come from.
+//  rays mode   (the render path): point p = ray n*S + k;  x = o_s[n] + d_s[n]*z[p];  dir = view_dirs[n];
+//              secondary directions computed from (z, rays_o, rays_d, rays_o2) as VipNeRF01.py:218-226.
+//  points mode (vipnerf_mlp_forward): pts[p], dirs[p], dirs2[p][v] given explicitly.
+struct PointSrc {
+    int64_t P;            // points
+    int32_t S;            // samples per ray (rays mode)
+    int32_t V;            // secondary directions
+    int32_t rays_mode;
+    int32_t ndc;
+    const float *z;       // (P)
+    const float *rays_o, *rays_d, *rays_o_s, *rays_d_s, *view_dirs, *rays_o2;
+    const float *pts, *dirs, *dirs2;
+};
+
+struct NoiseSrc {
+    const float *noise;   // (P) or NULL
+    float std;
+    int32_t device_rng;   // 1: draw N(0,1) from Philox when noise == NULL
+    uint32_t stream;
+    uint64_t seed, offset;
+};
+
+struct MlpFwdArgs {
+    PointSrc src;
+    NoiseSrc ns;
+    const float *packed;
+    float *sigma, *rgb, *vis, *vis2;   // (P), (P,3), (P), (P,V)
+    float *acts;                       // activation store base (NULL = do not save)
+    ActLayout al;
+};
+
+struct MlpBwdArgs {
+    PointSrc src;
+    const float *packed;
+    const float *sigma, *rgb, *vis, *vis2;       // forward outputs (for the activation derivatives)
+    const float *acts;
+    ActLayout al;
+    float *bwd;                                  // backward scratch base
+    BwdLayout bl;
+};
+
+constexpr int MLP_WG = 256;                 // 4 waves, one per SIMD
+constexpr int MLP_PTS_PER_WG = 128;         // 32 points per wave
+constexpr int MLP_LDS_F = R_TOTAL_PAD + 2 * STAGE_F;
+constexpr size_t MLP_LDS_BYTES = (size_t)MLP_LDS_F * 4;   // 95,232 B
+
+#if defined(__HIPCC__)
+
+// ------------------------------------------------------------------------------------------- weight stream
+// Double-buffered L2 -> LDS stream of 32 KiB stages via LDS-DMA (global_load_lds_dwordx4; the packed image is
+// already in lane order, so the DMA's lane-linear destination is exactly the fragment layout).  One
+// __syncthreads() per stage: it drains this wave's DMA (hipcc emits vmcnt(0) for pending LDS-DMA) and orders
+// every wave's reads of the buffer about to be overwritten.  A stage is 128 MFMAs per wave (>= 8192 cycles),
+// so the next stage's DMA (issued right after the barrier) has long landed by the next barrier.
+struct WStream {
+    const float *g;        // next stage to fetch (global)
+    float *buf;            // LDS stage buffers (2 * STAGE_F)
+    int n_left;            // stages not yet fetched
+    int cur;               // buffer holding the stage about to be consumed
+    int lane, wave;
+
+    __device__ __forceinline__ void fetch(int b) {
+        const float *src = g + (wave * 8) * CHUNK_F + lane * 4;
+        float *dst = buf + b * STAGE_F + (wave * 8) * CHUNK_F;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * CHUNK_F),
+                                             (__attribute__((address_space(3))) void *)(dst + i * CHUNK_F), 16, 0, 0);
+        g += STAGE_F;
+        --n_left;
+    }
+    __device__ __forceinline__ void start(const float *stream, int n_stages, float *lds_buf, int lane_, int wave_) {
+        g = stream; buf = lds_buf; n_left = n_stages; cur = 0; lane = lane_; wave = wave_;
+        fetch(0);
+    }
+    // returns the LDS address of the stage to consume now
+    __device__ __forceinline__ const float *next() {
+        __syncthreads();
+        const float *ret = buf + cur * STAGE_F;
+        cur ^= 1;
+        if (n_left > 0) fetch(cur);
+        return ret;
+    }
+};
+
+__device__ __forceinline__ floatx16 mfma(float a, float b, floatx16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// acc[0..NT) += A(stage) * B where B row r (r = 4*kg + q, kg = KG0 + gl) is the register in_r(r).
+// `stage` holds NKG kgroups x NT tiles, chunk index gl*NT + t.
+#define VN_GEMM_STAGE(stage, NT, NKG, KG0, acc, BEXPR)                                              \
+    _Pragma("unroll") for (int gl_ = 0; gl_ < (NKG); ++gl_) {                                       \
+        _Pragma("unroll") for (int t_ = 0; t_ < (NT); ++t_) {                                       \
+            const float4 a_ = *(const float4 *)((stage) + (gl_ * (NT) + t_) * CHUNK_F + lane * 4);  \
+            { const int r_ = 4 * ((KG0) + gl_) + 0; acc[t_] = mfma(a_.x, BEXPR, acc[t_]); }         \
+            { const int r_ = 4 * ((KG0) + gl_) + 1; acc[t_] = mfma(a_.y, BEXPR, acc[t_]); }         \
+            { const int r_ = 4 * ((KG0) + gl_) + 2; acc[t_] = mfma(a_.z, BEXPR, acc[t_]); }         \
+            { const int r_ = 4 * ((KG0) + gl_) + 3; acc[t_] = mfma(a_.w, BEXPR, acc[t_]); }         \
+        }                                                                                           \
+    }
+
+// ------------------------------------------------------------------------------------------- encodings
+// gamma_L(v): feature f < 3 -> v[f]; f = 3 + 6*l + 3*c + d -> (c ? cos : sin)(2^l v[d])   (VipNeRF01.py:424-448)
+template <int L, int NS>
+__device__ __forceinline__ void encode_half(const float v[3], int h, float (&out)[NS]) {
+    float val[2 * NS];
+#pragma unroll
+    for (int f = 0; f < 2 * NS; ++f) val[f] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) val[d] = v[d];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float s, c;
+            sincosf(v[d] * (float)(1 << l), &s, &c);
+            val[3 + 6 * l + d] = s;
+            val[3 + 6 * l + 3 + d] = c;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) out[s] = h ? val[2 * s + 1] : val[2 * s];
+}
+
+// Loads / computes the wave's point: position x, primary direction, and what is needed for the secondary ones.
+struct PointCtx {
+    float x[3], dir[3];
+    float o[3], d[3], z;      // world-space ray + depth (rays mode)
+    int64_t p, n;             // point, ray
+};
+__device__ __forceinline__ void load_point(const PointSrc &s, int64_t p, PointCtx &c) {
+    c.p = p;
+    if (s.rays_mode) {
+        const int64_t n = p / s.S;
+        c.n = n;
+        c.z = s.z[p];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            c.x[i] = __fadd_rn(s.rays_o_s[3 * n + i], __fmul_rn(s.rays_d_s[3 * n + i], c.z));
+            c.dir[i] = s.view_dirs[3 * n + i];
+            c.o[i] = s.rays_o[3 * n + i];
+            c.d[i] = s.rays_d[3 * n + i];
+        }
+    } else {
+        c.n = p;
+        c.z = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            c.x[i] = s.pts[3 * p + i];
+            c.dir[i] = s.dirs[3 * p + i];
+            c.o[i] = c.d[i] = 0.f;
+        }
+    }
+}
+// direction from secondary camera v to the point (VipNeRF01.py:218-226)
+__device__ __forceinline__ void secondary_dir(const PointSrc &s, const PointCtx &c, int v, float out[3]) {
+    if (!s.rays_mode) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) out[i] = s.dirs2[(c.p * s.V + v) * 3 + i];
+        return;
+    }
+    float t = c.z;
+    if (s.ndc) {
+        const float tn = __fdiv_rn(-(1.f + c.o[2]), c.d[2]);
+        const float num = __fadd_rn(c.o[2], __fmul_rn(tn, c.d[2]));
+        const float den = __fadd_rn(__fsub_rn(1.f, c.z), 1e-6f);
+        t = __fdiv_rn(__fsub_rn(__fdiv_rn(num, den), c.o[2]), c.d[2]);
+    }
+    float w[3], n2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float pt = __fadd_rn(c.o[i], __fmul_rn(t, c.d[i]));
+        w[i] = __fsub_rn(pt, s.rays_o2[(c.n * s.V + v) * 3 + i]);
+        n2 = __fadd_rn(n2, __fmul_rn(w[i], w[i]));
+    }
+    const float nrm = __fsqrt_rn(n2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[i] = __fdiv_rn(w[i], nrm);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// C/D-fragment <-> row-major [P][ld] helpers: lane (point j, half h) owns, for tile t and register group q,
+// the 4 consecutive features 32t + 8q + 4h .. +3 = registers 4q..4q+3 of acc[t].
+template <int NT>
+__device__ __forceinline__ void store_frag(float *base, int64_t p, int ld, int h, const floatx16 (&v)[NT], bool valid) {
+    if (!valid) return;
+    float *row = base + (size_t)p * ld + 4 * h;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *(float4 *)(row + 32 * t + 8 * q) = make_float4(v[t][4 * q], v[t][4 * q + 1], v[t][4 * q + 2], v[t][4 * q + 3]);
+}
+template <int NT>
+__device__ __forceinline__ void load_frag(const float *base, int64_t p, int ld, int h, floatx16 (&v)[NT]) {
+    const float *row = base + (size_t)p * ld + 4 * h;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 f = *(const float4 *)(row + 32 * t + 8 * q);
+            v[t][4 * q] = f.x; v[t][4 * q + 1] = f.y; v[t][4 * q + 2] = f.z; v[t][4 * q + 3] = f.w;
+        }
+}
+#endif
+
+int launch_mlp_fwd(const MlpFwdArgs &a, hipStream_t st);
+int launch_mlp_bwd(const MlpBwdArgs &a, hipStream_t st);
+int launch_pack(const vipnerf_mlp_params *p, void *packed, hipStream_t st);
+
+}  // namespace vn

@@ -1,0 +1,52 @@
+// Argument blocks of the per-ray kernels (vipnerf_ray.hip).
+#pragma once
+#include "vipnerf_common.h"
+
+namespace vn {
+
+struct CompositeArgs {
+    int64_t N;
+    int32_t S, V, ndc, white_bkgd;
+    const float *rays_o, *rays_d, *rays_d_s;
+    vipnerf_level_out lvl;            // reads z_vals, raw_*; writes the rest
+};
+
+struct CompositeBwdArgs {
+    int64_t N;
+    int32_t S, V, ndc, white_bkgd;
+    const float *rays_o, *rays_d, *rays_d_s;
+    vipnerf_level_out lvl;            // forward outputs (read only)
+    vipnerf_level_grads g;            // upstream gradients (nullable members)
+    float *dsig, *drgb, *dvis, *dvis2;   // dLoss/d(raw network outputs): (P), (P,3), (P), (P,V)
+};
+
+struct SampleArgs {
+    int64_t N;
+    int32_t Sc, Sf;
+    const float *z_coarse, *w_coarse, *u;
+    int32_t device_rng;
+    uint64_t seed, offset;
+    float *z_fine;
+    int32_t *inds;
+    float *z_samples;
+};
+
+struct LossArgs {
+    int64_t N;
+    int32_t V, n_levels, S_coarse, S_fine;
+    vipnerf_loss_in in;
+    vipnerf_level_out coarse, fine;
+    vipnerf_loss_level_seeds seeds_coarse, seeds_fine;
+    float *partial;                   // (7*N) + 2 counts appended by the caller
+    float *counts;                    // (2)
+    float *loss_values;               // (8)
+};
+
+int launch_coarse_z(int64_t N, int S, int lindisp, const float *near, const float *far, const float *t_rand,
+                    int device_rng, uint64_t seed, uint64_t offset, float *z_out, hipStream_t st);
+int launch_composite(const CompositeArgs &a, hipStream_t st);
+int launch_composite_bwd(const CompositeBwdArgs &a, hipStream_t st);
+int launch_sample_fine(const SampleArgs &a, hipStream_t st);
+int launch_losses(const LossArgs &a, hipStream_t st);
+
+}  // namespace vn

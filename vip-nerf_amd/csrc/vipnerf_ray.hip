@@ -1,0 +1,464 @@
+// Per-ray kernels around the MLP: stratified depths, alpha compositing (forward and backward), inverse-CDF
+// importance sampling with the sorted merge, and the fused losses.  All are one-wavefront-per-ray: the S
+// samples of a ray are spread over the 64 lanes (S/64 consecutive samples per lane, so global accesses are
+// contiguous per wave) and the transmittance product / suffix sums are wavefront scans.
+// These stages are < 1.5 % of the path's work and HBM/latency bound.
+#include "vipnerf_ray.h"
+
+namespace vn {
+
+constexpr int RAY_WG = 256;          // 4 rays per workgroup
+constexpr int MAX_IPL = 4;           // samples per lane: S <= 256
+
+// torch.linspace(0, 1, n)[i] as the CPU kernel rounds it (verified bit-for-bit against torch 2.10 for n = 64,
+// 128): start + step*i for the lower half, end - step*(n-1-i) for the upper, each as ONE fused multiply-add.
+__device__ __forceinline__ float linspace01(int i, int n) {
+    const float step = __fdiv_rn(1.0f, (float)(n - 1));
+    return (i < n / 2) ? __fmaf_rn(step, (float)i, 0.0f) : __fmaf_rn(-step, (float)(n - 1 - i), 1.0f);
+}
+
+// ------------------------------------------------------------------------------------------- coarse depths
+// VipNeRF.get_z_vals_coarse (VipNeRF01.py:173-203)
+__global__ void k_coarse_z(int64_t N, int S, int lindisp, const float *near, const float *far,
+                           const float *t_rand, int device_rng, uint64_t seed, uint64_t offset, float *z_out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * S) return;
+    const int64_t n = idx / S;
+    const int k = (int)(idx % S);
+    const float nr = near[n], fr = far[n];
+    auto zk = [&](int i) {
+        const float t = linspace01(i, S);
+        const float omt = __fsub_rn(1.0f, t);
+        if (!lindisp) return __fadd_rn(__fmul_rn(nr, omt), __fmul_rn(fr, t));
+        return __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(__fdiv_rn(1.0f, nr), omt), __fmul_rn(__fdiv_rn(1.0f, fr), t)));
+    };
+    float z = zk(k);
+    if (t_rand || device_rng) {
+        const float zl = k > 0 ? zk(k - 1) : z, zu = k < S - 1 ? zk(k + 1) : z;
+        const float lo = k > 0 ? __fmul_rn(0.5f, __fadd_rn(z, zl)) : z;
+        const float hi = k < S - 1 ? __fmul_rn(0.5f, __fadd_rn(zu, z)) : z;
+        const float t = t_rand ? t_rand[idx] : rng_uniform(seed, offset, RS_TRAND, (uint64_t)idx);
+        z = __fadd_rn(lo, __fmul_rn(__fsub_rn(hi, lo), t));
+    }
+    z_out[idx] = z;
+}
+
+// ------------------------------------------------------------------------------------------- compositing
+// VipNeRF.volume_rendering + convert_depth_from_ndc (VipNeRF01.py:331-403).
+__device__ __forceinline__ float metric_depth(float z_ndc, float oz, float dz) {
+    const float tn = __fdiv_rn(-(1.f + oz), dz);
+    const float c = (z_ndc == 1.f) ? 1e-3f : 0.f;
+    const float a = __fdiv_rn(__fadd_rn(oz, __fmul_rn(tn, dz)), dz);
+    const float b = __fsub_rn(__fdiv_rn(1.f, __fadd_rn(__fsub_rn(1.f, z_ndc), c)), 1.f);
+    return __fadd_rn(__fmul_rn(a, b), tn);
+}
+
+template <int IPL>
+__global__ __launch_bounds__(RAY_WG) void k_composite(CompositeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * (RAY_WG / 64) + (threadIdx.x >> 6);
+    if (n >= a.N) return;
+    const int S = a.S, V = a.V;
+    const int k0 = lane * IPL;
+    const float *zr = a.lvl.z_vals + n * S, *sg = a.lvl.raw_sigma + n * S;
+    const float *dn = a.rays_d_s + 3 * n;
+    const float dnorm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dn[0], dn[0]), __fmul_rn(dn[1], dn[1])), __fmul_rn(dn[2], dn[2])));
+    const float oz = a.rays_o[3 * n + 2], dz = a.rays_d[3 * n + 2];
+
+    float z[IPL + 1], al[IPL], T[IPL], w[IPL];
+    bool act[IPL];
+#pragma unroll
+    for (int i = 0; i < IPL; ++i) { act[i] = k0 + i < S; z[i] = act[i] ? zr[k0 + i] : 0.f; }
+    {
+        const float znext = __shfl_down(z[0], 1, 64);         // first sample of the next lane
+        z[IPL] = znext;
+    }
+    const float zlast = a.ndc ? 1.f : 1e10f;
+    float lp = 1.f;                                           // product of this lane's (1 - alpha + 1e-10)
+    float av[IPL];
+#pragma unroll
+    for (int i = 0; i < IPL; ++i) {
+        const float zn = (k0 + i == S - 1) ? zlast : z[i + 1];
+        const float delta = __fmul_rn(__fsub_rn(zn, z[i]), dnorm);
+        al[i] = act[i] ? __fsub_rn(1.f, expf(-__fmul_rn(sg[act[i] ? k0 + i : 0], delta))) : 0.f;
+        av[i] = act[i] ? __fadd_rn(__fsub_rn(1.f, al[i]), 1e-10f) : 1.f;
+        lp = __fmul_rn(lp, av[i]);
+    }
+    const float incl = wave_scan_mul(lp, lane);
+    float run = __shfl_up(incl, 1, 64);                       // exclusive prefix across lanes
+    if (lane == 0) run = 1.f;
+    float s_rgb[3] = {0.f, 0.f, 0.f}, s_acc = 0.f, s_z = 0.f, s_zm = 0.f, s_v2[VIPNERF_MAX_SEC] = {0.f, 0.f, 0.f};
+    float zm[IPL];
+#pragma unroll
+    for (int i = 0; i < IPL; ++i) {
+        T[i] = run;
+        w[i] = __fmul_rn(al[i], T[i]);
+        run = __fmul_rn(run, av[i]);
+        zm[i] = a.ndc ? metric_depth(z[i], oz, dz) : z[i];
+        if (act[i]) {
+            const int64_t ps = n * S + k0 + i;
+            a.lvl.alpha[ps] = al[i]; a.lvl.visibility[ps] = T[i]; a.lvl.weights[ps] = w[i];
+            s_acc += w[i];
+            s_z += w[i] * z[i];
+            s_zm += w[i] * zm[i];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) s_rgb[c] += w[i] * a.lvl.raw_rgb[3 * ps + c];
+            for (int v = 0; v < V; ++v) s_v2[v] += w[i] * a.lvl.raw_vis2[ps * V + v];
+        }
+    }
+    s_acc = wave_sum(s_acc); s_z = wave_sum(s_z); s_zm = wave_sum(s_zm);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s_rgb[c] = wave_sum(s_rgb[c]);
+    for (int v = 0; v < V; ++v) s_v2[v] = wave_sum(s_v2[v]);
+    const float den = __fadd_rn(s_acc, 1e-6f);
+    const float d_s = __fdiv_rn(s_z, den), d_m = __fdiv_rn(s_zm, den);
+    float var_s = 0.f, var_m = 0.f;
+#pragma unroll
+    for (int i = 0; i < IPL; ++i)
+        if (act[i]) {
+            const float e1 = z[i] - d_s, e2 = zm[i] - d_m;
+            var_s += w[i] * (e1 * e1);
+            var_m += w[i] * (e2 * e2);
+        }
+    var_s = wave_sum(var_s); var_m = wave_sum(var_m);
+    if (lane == 0) {
+        const float bg = a.white_bkgd ? 1.f - s_acc : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.lvl.rgb[3 * n + c] = s_rgb[c] + bg;
+        a.lvl.acc[n] = s_acc;
+        a.lvl.depth[n] = d_m;
+        a.lvl.depth_var[n] = var_m;
+        if (a.ndc) {
+            if (a.lvl.depth_ndc) a.lvl.depth_ndc[n] = d_s;
+            if (a.lvl.depth_var_ndc) a.lvl.depth_var_ndc[n] = var_s;
+        }
+        for (int v = 0; v < V; ++v) a.lvl.vis2[n * V + v] = __fdiv_rn(s_v2[v], den);
+    }
+}
+
+int launch_composite(const CompositeArgs &a, hipStream_t st) {
+    if (a.N <= 0) return VIPNERF_OK;
+    const unsigned grid = (unsigned)((a.N + 3) / 4);
+    const int ipl = (a.S + 63) / 64;
+    switch (ipl) {
+        case 1: hipLaunchKernelGGL(k_composite<1>, dim3(grid), dim3(RAY_WG), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(k_composite<2>, dim3(grid), dim3(RAY_WG), 0, st, a); break;
+        case 3: hipLaunchKernelGGL(k_composite<3>, dim3(grid), dim3(RAY_WG), 0, st, a); break;
+        case 4: hipLaunchKernelGGL(k_composite<4>, dim3(grid), dim3(RAY_WG), 0, st, a); break;
+        default: set_error("composite: n_samples %d > 256", a.S); return VIPNERF_E_UNSUPPORTED;
+    }
+    VN_HIP(hipGetLastError());
+    return VIPNERF_OK;
+}
+
+// Backward of the compositing (SURVEY.md §9 "Compositing backward", extended to every differentiable output):
+//   G_k = dL/dw_k = gw_k + g_rgb.c_k (- sum g_rgb if white_bkgd) + g_acc + g_depth (zm_k - D)/(A+eps)
+//         + g_depth_ndc (z_k - D')/(A+eps) + sum_v g_vis2_v (v2_kv - V2_v)/(A+eps)
+//   R_k = sum_{j>k} (G_j w_j + gT_j T_j)
+//   dL/dalpha_k = G_k T_k + galpha_k - R_k / (1 - alpha_k + 1e-10)
+//   dL/dsigma_k = dL/dalpha_k * delta_k * (1 - alpha_k)  (+ direct)
+template <int IPL>
+__global__ __launch_bounds__(RAY_WG) void k_composite_bwd(CompositeBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * (RAY_WG / 64) + (threadIdx.x >> 6);
+    if (n >= a.N) return;
+    const int S = a.S, V = a.V;
+    const int k0 = lane * IPL;
+    const vipnerf_level_grads &g = a.g;
+    const float *dn = a.rays_d_s + 3 * n;
+    const float dnorm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dn[0], dn[0]), __fmul_rn(dn[1], dn[1])), __fmul_rn(dn[2], dn[2])));
+    const float oz = a.rays_o[3 * n + 2], dz = a.rays_d[3 * n + 2];
+    const float A = a.lvl.acc[n], den = __fadd_rn(A, 1e-6f);
+    float g_rgb[3] = {0.f, 0.f, 0.f}, g_v2[VIPNERF_MAX_SEC] = {0.f, 0.f, 0.f}, V2[VIPNERF_MAX_SEC] = {0.f, 0.f, 0.f};
+    if (g.rgb) { g_rgb[0] = g.rgb[3 * n]; g_rgb[1] = g.rgb[3 * n + 1]; g_rgb[2] = g.rgb[3 * n + 2]; }
+    const float g_acc = (g.acc ? g.acc[n] : 0.f) - (a.white_bkgd ? (g_rgb[0] + g_rgb[1] + g_rgb[2]) : 0.f);
+    const float g_dep = g.depth ? g.depth[n] : 0.f;
+    const float g_dnd = (g.depth_ndc && a.ndc) ? g.depth_ndc[n] : 0.f;
+    const float Dm = a.lvl.depth[n];
+    const float Ds = (a.ndc && a.lvl.depth_ndc) ? a.lvl.depth_ndc[n] : 0.f;
+    for (int v = 0; v < V; ++v) { g_v2[v] = g.vis2 ? g.vis2[n * V + v] : 0.f; V2[v] = a.lvl.vis2[n * V + v]; }
+
+    float z[IPL + 1], Gw[IPL], Tt[IPL], ww[IPL], term[IPL];
+    bool act[IPL];
+#pragma unroll
+    for (int i = 0; i < IPL; ++i) { act[i] = k0 + i < S; z[i] = act[i] ? a.lvl.z_vals[n * S + k0 + i] : 0.f; }
+    z[IPL] = __shfl_down(z[0], 1, 64);
+    const float zlast = a.ndc ? 1.f : 1e10f;
+    float lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < IPL; ++i) {
+        Gw[i] = 0.f; Tt[i] = 0.f; ww[i] = 0.f; term[i] = 0.f;
+        if (act[i]) {
+            const int64_t ps = n * S + k0 + i;
+            Tt[i] = a.lvl.visibility[ps]; ww[i] = a.lvl.weights[ps];
+            const float zmv = a.ndc ? metric_depth(z[i], oz, dz) : z[i];
+            float G = g_acc + (g.weights ? g.weights[ps] : 0.f);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) G += g_rgb[c] * a.lvl.raw_rgb[3 * ps + c];
+            G += g_dep * (zmv - Dm) / den;
+            G += g_dnd * (z[i] - Ds) / den;
+            for (int v = 0; v < V; ++v) G += g_v2[v] * (a.lvl.raw_vis2[ps * V + v] - V2[v]) / den;
+            Gw[i] = G;
+            term[i] = G * ww[i] + (g.visibility ? g.visibility[ps] * Tt[i] : 0.f);
+            lsum += term[i];
+        }
+    }
+    const float incl = wave_rscan_add(lsum, lane);            // this lane's + all later lanes' terms
+    float after = incl - lsum;                                // strictly later lanes
+#pragma unroll
+    for (int i = IPL - 1; i >= 0; --i) {
+        if (act[i]) {
+            const int64_t ps = n * S + k0 + i;
+            const float R = after;                            // sum over j > k
+            after += term[i];
+            const float alpha = a.lvl.alpha[ps];
+            const float zn = (k0 + i == S - 1) ? zlast : z[i + 1];
+            const float delta = __fmul_rn(__fsub_rn(zn, z[i]), dnorm);
+            const float av = __fadd_rn(__fsub_rn(1.f, alpha), 1e-10f);
+            const float dalpha = Gw[i] * Tt[i] + (g.alpha ? g.alpha[ps] : 0.f) - R / av;
+            float dsig = dalpha * delta * (1.f - alpha);
+            if (g.raw_sigma) dsig += g.raw_sigma[ps];
+            a.dsig[ps] = dsig;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                a.drgb[3 * ps + c] = g_rgb[c] * ww[i] + (g.raw_rgb ? g.raw_rgb[3 * ps + c] : 0.f);
+            a.dvis[ps] = g.raw_vis ? g.raw_vis[ps] : 0.f;
+            for (int v = 0; v < V; ++v)
+                a.dvis2[ps * V + v] = g_v2[v] * ww[i] / den + (g.raw_vis2 ? g.raw_vis2[ps * V + v] : 0.f);
+        }
+    }
+}
+
+int launch_composite_bwd(const CompositeBwdArgs &a, hipStream_t st) {
+    if (a.N <= 0) return VIPNERF_OK;
+    const unsigned grid = (unsigned)((a.N + 3) / 4);
+    const int ipl = (a.S + 63) / 64;
+    switch (ipl) {
+        case 1: hipLaunchKernelGGL(k_composite_bwd<1>, dim3(grid), dim3(RAY_WG), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(k_composite_bwd<2>, dim3(grid), dim3(RAY_WG), 0, st, a); break;
+        case 3: hipLaunchKernelGGL(k_composite_bwd<3>, dim3(grid), dim3(RAY_WG), 0, st, a); break;
+        case 4: hipLaunchKernelGGL(k_composite_bwd<4>, dim3(grid), dim3(RAY_WG), 0, st, a); break;
+        default: set_error("composite_bwd: n_samples %d > 256", a.S); return VIPNERF_E_UNSUPPORTED;
+    }
+    VN_HIP(hipGetLastError());
+    return VIPNERF_OK;
+}
+
+// ------------------------------------------------------------------------------------------- importance sampling
+// VipNeRF.get_z_vals_fine + sample_pdf (VipNeRF01.py:205-262).  One wave per ray; LDS per wave:
+// cdf[Sc-1], bins[Sc-1], merged values [Sc+Sf].
+__global__ __launch_bounds__(RAY_WG) void k_sample_fine(SampleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sl[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * (RAY_WG / 64) + wv;
+    const int Sc = a.Sc, Sf = a.Sf, NB = Sc - 1, NW = Sc - 2, ST = Sc + Sf;
+    float *cdf = sl + wv * (2 * NB + ST), *bins = cdf + NB, *vals = bins + NB;
+    const bool live = n < a.N;
+    const int64_t nn = live ? n : a.N - 1;
+    const float *zc = a.z_coarse + nn * Sc, *wc = a.w_coarse + nn * Sc;
+
+    // pdf weights w[1..Sc-2] + 1e-5, total, serial cumsum (fp32, left to right like torch.cumsum)
+    for (int k = lane; k < NB; k += 64) bins[k] = __fmul_rn(0.5f, __fadd_rn(zc[k + 1], zc[k]));
+    for (int k = lane; k < Sc; k += 64) vals[k] = zc[k];
+    for (int k = lane; k < NW; k += 64) cdf[1 + k] = __fadd_rn(wc[1 + k], 1e-5f);   // stash w in cdf[1..]
+    __builtin_amdgcn_s_waitcnt(0);                // LDS is per wave: order only within the wave
+    __builtin_amdgcn_wave_barrier();
+    // total = torch.sum(w, -1) in the association order of ATen's CPU kernel (8 vector lanes x 4-way ILP,
+    // scalar tail added first; verified bit-for-bit), so that pdf, cdf and the searchsorted indices are
+    // bit-identical to the reference's on the same weights.
+    float tot;
+    {
+        const int nv = NW / 8, nblk = nv / 4;
+        float part = 0.f;
+        if (lane < 8) {
+            float p4[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < nblk; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) p4[k] = __fadd_rn(p4[k], cdf[1 + (i * 4 + k) * 8 + lane]);
+            for (int i = nblk * 4; i < nv; ++i) p4[0] = __fadd_rn(p4[0], cdf[1 + i * 8 + lane]);
+            part = __fadd_rn(__fadd_rn(__fadd_rn(p4[0], p4[1]), p4[2]), p4[3]);
+        }
+        float f = 0.f;
+        for (int k = nv * 8; k < NW; ++k) f = __fadd_rn(f, cdf[1 + k]);
+        for (int i = 0; i < 8; ++i) f = __fadd_rn(f, __shfl(part, i, 64));
+        tot = f;
+    }
+    // cdf = torch.cumsum(pdf): the CPU kernel accumulates float inputs in double and rounds each output
+    double run = 0.0;
+    for (int k = 0; k < NW; ++k) {
+        run += (double)__fdiv_rn(cdf[1 + k], tot);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) cdf[1 + k] = (float)run;
+    }
+    if (lane == 0) cdf[0] = 0.f;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+
+    for (int jj = lane; jj < Sf; jj += 64) {
+        float u;
+        if (a.u) u = a.u[nn * Sf + jj];
+        else if (a.device_rng) u = rng_uniform(a.seed, a.offset, RS_U, (uint64_t)(nn * Sf + jj));
+        else u = linspace01(jj, Sf);
+        int cnt = 0;                                           // searchsorted(cdf, u, right=True): #{cdf <= u}
+        for (int k = 0; k < NB; ++k) cnt += (cdf[k] <= u) ? 1 : 0;
+        const int lo = max(cnt - 1, 0), hi = min(cnt, NB - 1);
+        const float cl = cdf[lo], ch = cdf[hi], bl = bins[lo], bh = bins[hi];
+        float dnm = __fsub_rn(ch, cl);
+        if (dnm < 1e-5f) dnm = 1.f;
+        const float t = __fdiv_rn(__fsub_rn(u, cl), dnm);
+        const float smp = __fadd_rn(bl, __fmul_rn(t, __fsub_rn(bh, bl)));
+        vals[Sc + jj] = smp;
+        if (live) {
+            if (a.inds) a.inds[n * Sf + jj] = cnt;
+            if (a.z_samples) a.z_samples[n * Sf + jj] = smp;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // stable rank sort of the Sc+Sf values (torch.sort of the concatenation, values only)
+    for (int i = lane; i < ST; i += 64) {
+        const float v = vals[i];
+        int rank = 0;
+        for (int k = 0; k < ST; ++k) {
+            const float o = vals[k];
+            rank += (o < v || (o == v && k < i)) ? 1 : 0;
+        }
+        if (live) a.z_fine[n * ST + rank] = v;
+    }
+}
+
+int launch_sample_fine(const SampleArgs &a, hipStream_t st) {
+    if (a.N <= 0) return VIPNERF_OK;
+    const unsigned grid = (unsigned)((a.N + 3) / 4);
+    const size_t lds = (size_t)4 * (2 * (a.Sc - 1) + a.Sc + a.Sf) * sizeof(float);
+    hipLaunchKernelGGL(k_sample_fine, dim3(grid), dim3(RAY_WG), lds, st, a);
+    VN_HIP(hipGetLastError());
+    return VIPNERF_OK;
+}
+
+int launch_coarse_z(int64_t N, int S, int lindisp, const float *near, const float *far, const float *t_rand,
+                    int device_rng, uint64_t seed, uint64_t offset, float *z_out, hipStream_t st) {
+    if (N <= 0) return VIPNERF_OK;
+    const int64_t tot = N * S;
+    hipLaunchKernelGGL(k_coarse_z, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, S, lindisp, near, far,
+                       t_rand, device_rng, seed, offset, z_out);
+    VN_HIP(hipGetLastError());
+    return VIPNERF_OK;
+}
+
+// ------------------------------------------------------------------------------------------- fused losses
+// MSE01 / VisibilityLoss01 / VisibilityPriorLoss01 / SparseDepthMSE01 (src/loss_functions/*.py): values and
+// unweighted gradient seeds.  Three tiny launches: mask counts -> per-ray partials + seeds -> ordered final sum.
+__global__ void k_loss_counts(int64_t N, const uint8_t *m_nerf, const uint8_t *m_sd, float *counts) {
+    __shared__ float sh[2][16];
+    float c0 = 0.f, c1 = 0.f;
+    for (int64_t i = threadIdx.x; i < N; i += blockDim.x) {
+        c0 += m_nerf ? (m_nerf[i] ? 1.f : 0.f) : 1.f;
+        c1 += m_sd ? (m_sd[i] ? 1.f : 0.f) : 0.f;
+    }
+    c0 = wave_sum(c0); c1 = wave_sum(c1);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = c0; sh[1][threadIdx.x >> 6] = c1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { a0 += sh[0][i]; a1 += sh[1][i]; }
+        counts[0] = a0; counts[1] = a1;
+    }
+}
+
+// one wave per ray; partial[k*N + n], k: 0 mse_c 1 mse_f 2 vis_c 3 vis_f 4 prior_c 5 prior_f 6 sd
+__global__ __launch_bounds__(RAY_WG) void k_loss_rays(LossArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * (RAY_WG / 64) + (threadIdx.x >> 6);
+    if (n >= a.N) return;
+    const float n_m = a.counts[0], n_q = a.counts[1];
+    const bool in_m = a.in.mask_nerf ? a.in.mask_nerf[n] != 0 : true;
+    const bool in_q = a.in.mask_sparse ? a.in.mask_sparse[n] != 0 : false;
+    const int V = a.V;
+    for (int lv = 0; lv < a.n_levels; ++lv) {
+        const vipnerf_level_out &o = lv ? a.fine : a.coarse;
+        const vipnerf_loss_level_seeds &sd = lv ? a.seeds_fine : a.seeds_coarse;
+        const int S = lv ? a.S_fine : a.S_coarse;
+        // photometric MSE
+        float mse = 0.f;
+        if (lane < 3) {
+            const float e = o.rgb[3 * n + lane] - a.in.target_rgb[3 * n + lane];
+            mse = in_m ? e * e : 0.f;
+            sd.rgb[3 * n + lane] = (in_m && n_m > 0.f) ? 2.f * e / (3.f * n_m) : 0.f;
+        }
+        mse = wave_sum(mse) / 3.f;
+        // visibility: |T^ - sg(T)| + |sg(T^) - T|, mean over samples then rays (all rays)
+        float vl = 0.f;
+        const float inv = 1.f / ((float)a.N * (float)S);
+        for (int k = lane; k < S; k += 64) {
+            const float d = o.raw_vis[n * S + k] - o.visibility[n * S + k];
+            vl += fabsf(d);
+            const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            sd.raw_vis[n * S + k] = sgn * inv;
+            sd.visibility[n * S + k] = -sgn * inv;
+        }
+        vl = 2.f * wave_sum(vl) / (float)S;
+        // visibility prior
+        float pr = 0.f;
+        if (V > 0) {
+            if (lane < V) {
+                const float m = a.in.prior ? a.in.prior[n * V + lane] : 1.f;
+                pr = in_m ? m * (1.f - o.vis2[n * V + lane]) : 0.f;
+                sd.vis2[n * V + lane] = (in_m && n_m > 0.f) ? -m / n_m : 0.f;
+            }
+            pr = wave_sum(pr);
+        }
+        if (lane == 0) {
+            a.partial[(0 + lv) * a.N + n] = mse;
+            a.partial[(2 + lv) * a.N + n] = vl;
+            a.partial[(4 + lv) * a.N + n] = pr;
+        }
+        // sparse depth (on the last level only: fine if present, else coarse)
+        if (lv == a.n_levels - 1 && lane == 0) {
+            float sdl = 0.f, seed = 0.f;
+            if (a.in.mask_sparse && in_q) {
+                const float e = o.depth[n] - a.in.sparse_depth[n];
+                sdl = e * e;
+                seed = n_q > 0.f ? 2.f * e / n_q : 0.f;
+            }
+            a.partial[6 * a.N + n] = sdl;
+            if (sd.depth) sd.depth[n] = seed;
+        }
+    }
+}
+
+// ordered reduction of the 7 partial arrays (one workgroup; fixed order -> deterministic)
+__global__ void k_loss_final(LossArgs a) {
+    __shared__ float sh[16];
+    for (int k = 0; k < 7; ++k) {
+        float s = 0.f;
+        const bool used = (k == 6) || ((k & 1) < a.n_levels);
+        if (used)
+            for (int64_t i = threadIdx.x; i < a.N; i += blockDim.x) s += a.partial[(size_t)k * a.N + i];
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+            float dnm;
+            if (k < 2 || k == 4 || k == 5) dnm = a.counts[0];       // mean over nerf rays
+            else if (k < 4) dnm = (float)a.N;                        // mean over all rays
+            else dnm = a.counts[1];                                  // mean over sparse-depth rays
+            a.loss_values[k] = dnm > 0.f ? t / dnm : 0.f;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.loss_values[7] = 0.f;
+}
+
+int launch_losses(const LossArgs &a, hipStream_t st) {
+    if (a.N <= 0) return VIPNERF_OK;
+    hipLaunchKernelGGL(k_loss_counts, dim3(1), dim3(1024), 0, st, a.N, a.in.mask_nerf, a.in.mask_sparse, a.counts);
+    hipLaunchKernelGGL(k_loss_rays, dim3((unsigned)((a.N + 3) / 4)), dim3(RAY_WG), 0, st, a);
+    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(1024), 0, st, a);
+    VN_HIP(hipGetLastError());
+    return VIPNERF_OK;
+}
+
+}  // namespace vn

@@ -1,0 +1,134 @@
+"""ctypes binding of libvipnerf_hip.so (include/vipnerf_hip.h).
+
+The library is the product path; there is no fallback.  If it cannot be loaded every entry point raises
+`VipNerfHipError` -- nothing in this package routes through the CPU oracle.
+"""
+import ctypes as C
+import os
+
+VIPNERF_MAX_SEC = 3
+VIPNERF_N_PARAMS = 24
+ABI_VERSION = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libvipnerf_hip.so')
+
+c_f = C.c_void_p   # device pointers travel as plain addresses
+
+
+class VipNerfHipError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [('ndc', C.c_int32), ('n_coarse', C.c_int32), ('n_fine', C.c_int32), ('n_sec', C.c_int32),
+                ('train', C.c_int32), ('lindisp', C.c_int32), ('white_bkgd', C.c_int32), ('save_acts', C.c_int32),
+                ('noise_std', C.c_float), ('given_z_fine', C.c_int32), ('reserved', C.c_int32 * 6)]
+
+
+class Rays(C.Structure):
+    _fields_ = [('n_rays', C.c_int64), ('rays_o', c_f), ('rays_d', c_f), ('rays_o_s', c_f), ('rays_d_s', c_f),
+                ('view_dirs', c_f), ('near', c_f), ('far', c_f), ('rays_o2', c_f)]
+
+
+class Rng(C.Structure):
+    _fields_ = [('t_rand', c_f), ('u', c_f), ('noise_coarse', c_f), ('noise_fine', c_f),
+                ('seed', C.c_uint64), ('offset', C.c_uint64)]
+
+
+class MlpParams(C.Structure):
+    _fields_ = [('p', c_f * VIPNERF_N_PARAMS)]
+
+
+class MlpGrads(C.Structure):
+    _fields_ = [('g', c_f * VIPNERF_N_PARAMS)]
+
+
+LEVEL_OUT_FIELDS = ['z_vals', 'raw_sigma', 'raw_rgb', 'raw_vis', 'raw_vis2', 'alpha', 'visibility', 'weights',
+                    'rgb', 'acc', 'depth', 'depth_var', 'depth_ndc', 'depth_var_ndc', 'vis2']
+
+
+class LevelOut(C.Structure):
+    _fields_ = [(k, c_f) for k in LEVEL_OUT_FIELDS]
+
+
+class Outputs(C.Structure):
+    _fields_ = [('coarse', LevelOut), ('fine', LevelOut), ('sample_inds', c_f), ('z_samples', c_f)]
+
+
+LEVEL_GRAD_FIELDS = ['rgb', 'acc', 'depth', 'depth_ndc', 'vis2', 'visibility', 'weights', 'alpha', 'raw_sigma',
+                     'raw_rgb', 'raw_vis', 'raw_vis2']
+
+
+class LevelGrads(C.Structure):
+    _fields_ = [(k, c_f) for k in LEVEL_GRAD_FIELDS]
+
+
+class OutGrads(C.Structure):
+    _fields_ = [('coarse', LevelGrads), ('fine', LevelGrads)]
+
+
+class LossIn(C.Structure):
+    _fields_ = [('target_rgb', c_f), ('mask_nerf', c_f), ('prior', c_f), ('mask_sparse', c_f), ('sparse_depth', c_f)]
+
+
+class LossLevelSeeds(C.Structure):
+    _fields_ = [('rgb', c_f), ('visibility', c_f), ('raw_vis', c_f), ('vis2', c_f), ('depth', c_f)]
+
+
+class LossOut(C.Structure):
+    _fields_ = [('loss_values', c_f), ('coarse', LossLevelSeeds), ('fine', LossLevelSeeds), ('scratch', c_f)]
+
+
+# every symbol include/vipnerf_hip.h declares: name -> (restype, argtypes)
+P = C.POINTER
+SYMBOLS = {
+    'vipnerf_abi_version': (C.c_int32, []),
+    'vipnerf_last_error': (C.c_int32, [C.c_char_p, C.c_size_t]),
+    'vipnerf_packed_weights_bytes': (C.c_size_t, []),
+    'vipnerf_pack_weights': (C.c_int32, [P(MlpParams), c_f, c_f]),
+    'vipnerf_query_workspace': (C.c_int32, [P(Config), C.c_int64, P(C.c_size_t), P(C.c_size_t)]),
+    'vipnerf_render_forward': (C.c_int32, [P(Config), P(Rays), P(Rng), c_f, c_f, P(Outputs), c_f, c_f]),
+    'vipnerf_render_backward': (C.c_int32, [P(Config), P(Rays), c_f, c_f, P(Outputs), P(OutGrads), c_f, c_f,
+                                            P(MlpGrads), P(MlpGrads), c_f]),
+    'vipnerf_losses_forward': (C.c_int32, [P(Config), C.c_int64, P(LossIn), P(Outputs), P(LossOut), c_f]),
+    'vipnerf_coarse_depths': (C.c_int32, [C.c_int64, C.c_int32, C.c_int32, c_f, c_f, c_f, c_f, c_f]),
+    'vipnerf_sample_fine': (C.c_int32, [C.c_int64, C.c_int32, C.c_int32, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    'vipnerf_mlp_forward': (C.c_int32, [C.c_int64, C.c_int32, c_f, c_f, c_f, c_f, C.c_float, c_f, c_f, c_f, c_f,
+                                        c_f, c_f]),
+    'vipnerf_composite': (C.c_int32, [P(Config), P(Rays), C.c_int32, P(LevelOut), c_f]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the CDLL.  Raises VipNerfHipError if the library or any symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VipNerfHipError(f'{LIB_PATH} not found: build it with vip-nerf_amd/build.sh '
+                              f'(or __graft_entry__.build()); there is no CPU fallback')
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise VipNerfHipError(f'cannot load {LIB_PATH}: {e}') from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise VipNerfHipError(f'{LIB_PATH} does not export {name}') from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.vipnerf_abi_version() != ABI_VERSION:
+        raise VipNerfHipError(f'ABI mismatch: library {lib.vipnerf_abi_version()} != binding {ABI_VERSION}')
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        buf = C.create_string_buffer(512)
+        load().vipnerf_last_error(buf, 512)
+        raise VipNerfHipError(f'{what} failed (rc={rc}): {buf.value.decode(errors="replace")}')

@@ -1,0 +1,291 @@
+"""Tensor-level wrappers over the C ABI.  PyTorch is used here for device memory and the current stream only;
+all arithmetic happens in libvipnerf_hip.so."""
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+
+PARAM_ORDER = ([f'pts_linears.{i}.{wb}' for i in range(8) for wb in ('weight', 'bias')] +
+               ['views_linears.0.weight', 'views_linears.0.bias', 'pts_output_linear.weight',
+                'pts_output_linear.bias', 'feature_linear.weight', 'feature_linear.bias',
+                'views_output_linear.weight', 'views_output_linear.bias'])
+PARAM_SHAPES = ([s for i in range(8) for s in ((256, 63 if i == 0 else (319 if i == 5 else 256)), (256,))] +
+                [(128, 283), (128,), (1, 256), (1,), (256, 256), (256,), (4, 128), (4,)])
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor], dtype=torch.float32, name='tensor'):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L.VipNerfHipError(f'{name} must live on the GPU (got {t.device})')
+    if t.dtype != dtype:
+        raise L.VipNerfHipError(f'{name} must be {dtype} (got {t.dtype})')
+    if not t.is_contiguous():
+        raise L.VipNerfHipError(f'{name} must be contiguous')
+    return t.data_ptr()
+
+
+def f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+def make_config(ndc, n_coarse, n_fine, n_sec, train, noise_std=0.0, lindisp=False, white_bkgd=False,
+                save_acts=False) -> L.Config:
+    c = L.Config()
+    c.ndc, c.n_coarse, c.n_fine, c.n_sec = int(bool(ndc)), int(n_coarse), int(n_fine), int(n_sec)
+    c.train, c.lindisp, c.white_bkgd, c.save_acts = int(bool(train)), int(bool(lindisp)), int(bool(white_bkgd)), int(bool(save_acts))
+    c.noise_std = float(noise_std)
+    return c
+
+
+def packed_bytes() -> int:
+    return L.load().vipnerf_packed_weights_bytes()
+
+
+def pack_weights(params: List[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """params: the 24 tensors of one MLP in PARAM_ORDER."""
+    lib = L.load()
+    if len(params) != L.VIPNERF_N_PARAMS:
+        raise L.VipNerfHipError(f'expected {L.VIPNERF_N_PARAMS} parameter tensors, got {len(params)}')
+    mp = L.MlpParams()
+    keep = []
+    for i, (t, shp) in enumerate(zip(params, PARAM_SHAPES)):
+        if tuple(t.shape) != shp:
+            raise L.VipNerfHipError(f'parameter {PARAM_ORDER[i]} has shape {tuple(t.shape)}, the HIP path supports only '
+                                    f'the 8x256 topology ({shp})')
+        tc = f32c(t)
+        keep.append(tc)
+        mp.p[i] = _p(tc, name=PARAM_ORDER[i])
+    if out is None:
+        out = torch.empty(packed_bytes() // 4, dtype=torch.float32, device=params[0].device)
+    L.check(lib.vipnerf_pack_weights(C.byref(mp), _p(out), _stream()), 'vipnerf_pack_weights')
+    return out
+
+
+def query_workspace(cfg: L.Config, n_rays: int):
+    a, b = C.c_size_t(0), C.c_size_t(0)
+    L.check(L.load().vipnerf_query_workspace(C.byref(cfg), n_rays, C.byref(a), C.byref(b)), 'vipnerf_query_workspace')
+    return a.value, b.value
+
+
+def _rays_struct(cfg: L.Config, b: Dict[str, torch.Tensor], keep: list) -> L.Rays:
+    r = L.Rays()
+    n = b['rays_o'].shape[0]
+    r.n_rays = n
+
+    def put(field, t, name):
+        tc = f32c(t)
+        keep.append(tc)
+        setattr(r, field, _p(tc, name=name))
+
+    put('rays_o', b['rays_o'], 'rays_o')
+    put('rays_d', b['rays_d'], 'rays_d')
+    if cfg.ndc:
+        put('rays_o_s', b['rays_o_ndc'], 'rays_o_ndc'); put('rays_d_s', b['rays_d_ndc'], 'rays_d_ndc')
+        put('near', b['near_ndc'].reshape(n), 'near_ndc'); put('far', b['far_ndc'].reshape(n), 'far_ndc')
+    else:
+        put('rays_o_s', b['rays_o'], 'rays_o'); put('rays_d_s', b['rays_d'], 'rays_d')
+        put('near', b['near'].reshape(n), 'near'); put('far', b['far'].reshape(n), 'far')
+    put('view_dirs', b['view_dirs'], 'view_dirs')
+    if cfg.n_sec > 0:
+        o2 = b['rays_o2']
+        if tuple(o2.shape) != (n, cfg.n_sec, 3):
+            raise L.VipNerfHipError(f'rays_o2 has shape {tuple(o2.shape)}, expected {(n, cfg.n_sec, 3)}')
+        put('rays_o2', o2, 'rays_o2')
+    return r
+
+
+def alloc_level(n, S, V, ndc, dev) -> Dict[str, torch.Tensor]:
+    e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    d = {'z_vals': e(n, S), 'raw_sigma': e(n, S), 'raw_rgb': e(n, S, 3), 'raw_vis': e(n, S), 'alpha': e(n, S),
+         'visibility': e(n, S), 'weights': e(n, S), 'rgb': e(n, 3), 'acc': e(n), 'depth': e(n), 'depth_var': e(n)}
+    if V > 0:
+        d['raw_vis2'] = e(n, S, V)
+        d['vis2'] = e(n, V)
+    if ndc:
+        d['depth_ndc'] = e(n)
+        d['depth_var_ndc'] = e(n)
+    return d
+
+
+def _level_struct(d: Dict[str, torch.Tensor]) -> L.LevelOut:
+    lo = L.LevelOut()
+    for k in L.LEVEL_OUT_FIELDS:
+        setattr(lo, k, _p(d.get(k), name=k))
+    return lo
+
+
+def render_forward(cfg: L.Config, batch: Dict[str, torch.Tensor], rng: Optional[dict], packed_coarse, packed_fine,
+                   acts: Optional[torch.Tensor] = None, z_fine: Optional[torch.Tensor] = None):
+    """-> (coarse dict, fine dict or None, extras dict).  `rng`: {'t_rand','u','noise_coarse','noise_fine'} tensors
+    (any may be missing -> device Philox) and optional 'seed'/'offset' ints."""
+    lib = L.load()
+    keep = []
+    rays = _rays_struct(cfg, batch, keep)
+    n = rays.n_rays
+    dev = batch['rays_o'].device
+    coarse = alloc_level(n, cfg.n_coarse, cfg.n_sec, cfg.ndc, dev)
+    fine = alloc_level(n, cfg.n_coarse + cfg.n_fine, cfg.n_sec, cfg.ndc, dev) if cfg.n_fine > 0 else None
+    out = L.Outputs()
+    out.coarse = _level_struct(coarse)
+    extras = {}
+    cfg.given_z_fine = int(z_fine is not None)
+    if fine is not None:
+        if z_fine is not None:          # teacher forcing (parity tests)
+            fine['z_vals'].copy_(z_fine)
+        out.fine = _level_struct(fine)
+        extras['sample_inds'] = torch.empty(n, cfg.n_fine, dtype=torch.int32, device=dev)
+        extras['z_samples'] = torch.empty(n, cfg.n_fine, dtype=torch.float32, device=dev)
+        out.sample_inds = _p(extras['sample_inds'], torch.int32)
+        out.z_samples = _p(extras['z_samples'])
+    rs = None
+    if rng is not None:
+        rs = L.Rng()
+        for k in ('t_rand', 'u', 'noise_coarse', 'noise_fine'):
+            if rng.get(k) is not None:
+                tc = f32c(rng[k])
+                keep.append(tc)
+                setattr(rs, k, _p(tc, name=k))
+        rs.seed = int(rng.get('seed', 0))
+        rs.offset = int(rng.get('offset', 0))
+    L.check(lib.vipnerf_render_forward(C.byref(cfg), C.byref(rays), C.byref(rs) if rs is not None else None,
+                                       _p(packed_coarse), _p(packed_fine) if packed_fine is not None else None,
+                                       C.byref(out), _p(acts) if acts is not None else None, _stream()),
+            'vipnerf_render_forward')
+    extras['_keep'] = keep
+    return coarse, fine, extras
+
+
+def render_backward(cfg: L.Config, batch, packed_coarse, packed_fine, coarse, fine, grads_coarse: dict,
+                    grads_fine: Optional[dict], acts, bwd_ws, gparams_coarse: List[torch.Tensor],
+                    gparams_fine: Optional[List[torch.Tensor]]):
+    lib = L.load()
+    keep = []
+    rays = _rays_struct(cfg, batch, keep)
+    out = L.Outputs()
+    out.coarse = _level_struct(coarse)
+    if fine is not None:
+        out.fine = _level_struct(fine)
+    og = L.OutGrads()
+
+    def fill(lg, d):
+        for k in L.LEVEL_GRAD_FIELDS:
+            t = d.get(k) if d else None
+            if t is not None:
+                tc = f32c(t)
+                keep.append(tc)
+                setattr(lg, k, _p(tc, name='grad_' + k))
+    fill(og.coarse, grads_coarse)
+    fill(og.fine, grads_fine)
+    gc, gf = L.MlpGrads(), L.MlpGrads()
+    for i, t in enumerate(gparams_coarse):
+        gc.g[i] = _p(t, name=f'grad param {i}')
+    if gparams_fine is not None:
+        for i, t in enumerate(gparams_fine):
+            gf.g[i] = _p(t, name=f'grad param {i}')
+    L.check(lib.vipnerf_render_backward(C.byref(cfg), C.byref(rays), _p(packed_coarse),
+                                        _p(packed_fine) if packed_fine is not None else None, C.byref(out),
+                                        C.byref(og), _p(acts), _p(bwd_ws), C.byref(gc),
+                                        C.byref(gf) if gparams_fine is not None else None, _stream()),
+            'vipnerf_render_backward')
+    return keep
+
+
+# ------------------------------------------------------------------------------------------------ stage-wise ops
+def coarse_depths(near, far, n_samples, t_rand=None, lindisp=False):
+    n = near.shape[0]
+    near, far = f32c(near.reshape(n)), f32c(far.reshape(n))
+    tr = f32c(t_rand) if t_rand is not None else None
+    z = torch.empty(n, n_samples, dtype=torch.float32, device=near.device)
+    L.check(L.load().vipnerf_coarse_depths(n, n_samples, int(lindisp), _p(near), _p(far), _p(tr), _p(z), _stream()),
+            'vipnerf_coarse_depths')
+    return z
+
+
+def sample_fine(z_coarse, w_coarse, n_fine, u=None):
+    n, sc = z_coarse.shape
+    zc, wc = f32c(z_coarse), f32c(w_coarse)
+    uu = f32c(u) if u is not None else None
+    dev = zc.device
+    zf = torch.empty(n, sc + n_fine, dtype=torch.float32, device=dev)
+    inds = torch.empty(n, n_fine, dtype=torch.int32, device=dev)
+    zs = torch.empty(n, n_fine, dtype=torch.float32, device=dev)
+    L.check(L.load().vipnerf_sample_fine(n, sc, n_fine, _p(zc), _p(wc), _p(uu), _p(zf), _p(inds, torch.int32), _p(zs),
+                                         _stream()), 'vipnerf_sample_fine')
+    return zf, inds, zs
+
+
+def mlp_forward(packed, pts, view_dirs, view_dirs2=None, noise=None, noise_std=1.0):
+    P = pts.shape[0]
+    V = 0 if view_dirs2 is None else view_dirs2.shape[1]
+    dev = pts.device
+    pts, vd = f32c(pts), f32c(view_dirs)
+    vd2 = f32c(view_dirs2) if view_dirs2 is not None else None
+    nz = f32c(noise) if noise is not None else None
+    e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    sigma, rgb, vis = e(P), e(P, 3), e(P)
+    vis2 = e(P, V) if V > 0 else None
+    L.check(L.load().vipnerf_mlp_forward(P, V, _p(pts), _p(vd), _p(vd2), _p(nz), float(noise_std), _p(packed),
+                                         _p(sigma), _p(rgb), _p(vis), _p(vis2), _stream()), 'vipnerf_mlp_forward')
+    return {'sigma': sigma, 'rgb': rgb, 'visibility': vis, 'visibility2': vis2}
+
+
+def composite(cfg: L.Config, batch, z, sigma, rgb, vis2=None):
+    """volume_rendering on explicit network outputs; returns the level dict."""
+    keep = []
+    rays = _rays_struct(cfg, batch, keep)
+    n, S = z.shape
+    lvl = alloc_level(n, S, cfg.n_sec, cfg.ndc, z.device)
+    lvl['z_vals'] = f32c(z); lvl['raw_sigma'] = f32c(sigma); lvl['raw_rgb'] = f32c(rgb)
+    if cfg.n_sec > 0:
+        lvl['raw_vis2'] = f32c(vis2)
+    lo = _level_struct(lvl)
+    L.check(L.load().vipnerf_composite(C.byref(cfg), C.byref(rays), S, C.byref(lo), _stream()), 'vipnerf_composite')
+    return lvl
+
+
+def losses_forward(cfg: L.Config, n_rays, target_rgb, mask_nerf, prior, mask_sparse, sparse_depth, coarse, fine):
+    """-> (loss_values (8,), seeds_coarse dict, seeds_fine dict)."""
+    dev = target_rgb.device
+    keep = []
+    li = L.LossIn()
+    t = f32c(target_rgb); keep.append(t); li.target_rgb = _p(t)
+    if mask_nerf is not None:
+        m = mask_nerf.to(torch.uint8).contiguous(); keep.append(m); li.mask_nerf = _p(m, torch.uint8)
+    if prior is not None:
+        pr = f32c(prior); keep.append(pr); li.prior = _p(pr)
+    if mask_sparse is not None:
+        m2 = mask_sparse.to(torch.uint8).contiguous(); keep.append(m2); li.mask_sparse = _p(m2, torch.uint8)
+        sd = f32c(sparse_depth.reshape(n_rays)); keep.append(sd); li.sparse_depth = _p(sd)
+    out = L.Outputs()
+    out.coarse = _level_struct(coarse)
+    if fine is not None:
+        out.fine = _level_struct(fine)
+    lo = L.LossOut()
+    vals = torch.empty(8, dtype=torch.float32, device=dev)
+    scratch = torch.empty(8 * n_rays + 8, dtype=torch.float32, device=dev)
+    lo.loss_values, lo.scratch = _p(vals), _p(scratch)
+    seeds = []
+    for lvl, S, st in ((coarse, cfg.n_coarse, lo.coarse), (fine, cfg.n_coarse + cfg.n_fine, lo.fine)):
+        if lvl is None:
+            seeds.append(None)
+            continue
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        d = {'rgb': e(n_rays, 3), 'visibility': e(n_rays, S), 'raw_vis': e(n_rays, S)}
+        if cfg.n_sec > 0:
+            d['vis2'] = e(n_rays, cfg.n_sec)
+        last = (lvl is fine) or (fine is None)
+        if last:
+            d['depth'] = torch.zeros(n_rays, dtype=torch.float32, device=dev)
+        for k, v in d.items():
+            setattr(st, k, _p(v))
+        seeds.append(d)
+    L.check(L.load().vipnerf_losses_forward(C.byref(cfg), n_rays, C.byref(li), C.byref(out), C.byref(lo), _stream()),
+            'vipnerf_losses_forward')
+    return vals, seeds[0], seeds[1]

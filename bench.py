@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""Benchmark of the ViP-NeRF per-ray hot path on MI355X (BASELINE.json: train rays/sec + full-frame render ms,
+LLFF-fern 2-view geometry, synthetic data).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one training iteration over one 4096-ray batch per GPU (BASELINE config 2: 64 + 128 samples, coarse + fine
+8x256 MLP, fp32): forward -> fused losses (MSE 1, Visibility 0.1, VisibilityPrior 0.001 @ iter 40000) -> backward ->
+[RCCL all-reduce of the flat gradient bucket] -> Adam.  Batches are generated and resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'vip-nerf_amd'))
+sys.path.insert(0, os.path.join(ROOT, 'vip-nerf_amd', 'src'))
+
+MAC_PER_POINT = 630272          # trunk+sigma+feature 556,800 + 2 x 36,736 view-branch evaluations (V = 1)
+POINTS_PER_RAY = 64 + 192
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+
+
+def model_configs(n_views=2):
+    mlp = lambda ns: {'num_samples': ns, 'netdepth': 8, 'netwidth': 256, 'points_positional_encoding_degree': 10,
+                      'views_positional_encoding_degree': 4, 'use_view_dirs': True, 'view_dependent_rgb': True,
+                      'predict_visibility': True}
+    return {'data_loader': {'ndc': True},
+            'model': {'name': 'VipNeRFHip01', 'coarse_mlp': mlp(64), 'fine_mlp': mlp(128), 'chunk': 4096,
+                      'netchunk': 16384, 'lindisp': False, 'perturb': True, 'raw_noise_std': 1.0, 'white_bkgd': False},
+            'losses': [{'name': 'MSEHip01', 'weight': 1}, {'name': 'VisibilityLossHip01', 'weight': 0.1},
+                       {'name': 'VisibilityPriorLossHip01', 'iter_weights': {'0': 0, '30000': 0.001}}],
+            'device': [0]}
+
+
+def make_batch(vo, n_rays, seed, dev, iter_num=40000):
+    b = vo.synthetic_batch(n_rays, seed, scene='fern', nf=2)
+    rb = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items() if k not in ('poses', 'ndc')}
+    rb['common_data'] = {'poses': b['poses'][None].clone().to(dev)}
+    rb['iter_num'] = iter_num
+    return rb
+
+
+def cpu_baseline(vo, n_rays, steps):
+    """The CPU oracle (a PyTorch-eager restatement pinned to the reference, kind='port') doing the same training
+    step on the host cores, on a bounded ray sample."""
+    torch.manual_seed(0)
+    params = vo.params_to_torch(vo.init_params(0), requires_grad=True)
+    opt = torch.optim.Adam(list(params.values()), lr=5e-4, betas=(0.9, 0.999))
+    lcfg = [{'name': 'MSE01', 'weight': 1}, {'name': 'VisibilityLoss01', 'weight': 0.1},
+            {'name': 'VisibilityPriorLoss01', 'iter_weights': {'0': 0, '30000': 0.001}}]
+    cfg = {'ndc': True, 'n_coarse': 64, 'n_fine': 128, 'noise_std': 1.0}
+    times = []
+    for it in range(steps + 1):
+        b = vo.synthetic_batch(n_rays, 1000 + it, scene='fern', nf=2)
+        rng = vo.synthetic_rng(n_rays, 64, 128, 2000 + it)
+        t0 = time.time()
+        opt.zero_grad(set_to_none=True)
+        out = vo.render_rays(params, b, cfg, rng, train=True, sec_views=True, chunk=4096)
+        vo.total_loss(b, out, lcfg, 40000)['TotalLoss'].backward()
+        opt.step()
+        times.append(time.time() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]          # median after one warm-up
+    return n_rays / t
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--rays', type=int, default=4096, help='rays per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-rays', type=int, default=1024)
+    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--no-render', action='store_true')
+    args = ap.parse_args()
+
+    from vipnerf_hip import dist as vdist
+    from vipnerf_hip import ops
+    rank, world, local = vdist.init_from_env()
+    if args.gpus != world and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    dev = torch.device(f'cuda:{local}')
+    torch.cuda.set_device(dev)
+
+    from oracle import vipnerf_oracle as vo       # synthetic-data generator + cpu_baseline leg only
+    from models.ModelFactory import get_model
+    from loss_functions.LossComputerHip01 import LossComputerHip
+
+    cfg = model_configs()
+    torch.manual_seed(0)
+    model = get_model(cfg, None).to(dev)
+    vdist.broadcast_parameters(model)
+    model.train()
+    lossc = LossComputerHip(cfg)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.999))
+    bucket = vdist.FlatGradBucket(model.parameters())
+
+    n_batches = args.steps + args.warmup
+    batches = [make_batch(vo, args.rays, 1000 + rank * 100003 + i, dev) for i in range(n_batches)]
+    torch.cuda.synchronize()
+
+    def step(i):
+        b = dict(batches[i])
+        b['common_data'] = {'poses': batches[i]['common_data']['poses']}
+        bucket.zero()
+        out = model(b)
+        losses = lossc.compute_losses(b, out)
+        losses['TotalLoss'].backward()
+        bucket.all_reduce_mean()
+        opt.step()
+
+    for i in range(args.warmup):
+        step(i)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    ops.profile_enable(True)
+    ops.profile_read()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ops.profile_read()
+    ops.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        return
+    rays_total = args.rays * world * args.steps
+    value = rays_total / elapsed
+
+    # roofline of the dominant stage: algorithmic FLOP (reference-equivalent work, 3x convention: forward, data
+    # gradient and weight gradient each count 630,272 MAC/point) / device time from HIP events on the launch stream
+    groups = {
+        'mlp_fwd': ('mlp_fwd_coarse', 'mlp_fwd_fine'),
+        'mlp_dgrad': ('mlp_dgrad_coarse', 'mlp_dgrad_fine'),
+        'wgrad': ('wgrad_256x256', 'wgrad_small'),
+    }
+    stage_ms = {g: sum(prof.get(k, (0, 0.0))[1] for k in ks) / args.steps for g, ks in groups.items()}
+    other_ms = sum(v[1] for k, v in prof.items() if not any(k in ks for ks in groups.values())) / args.steps
+    dom = max(stage_ms, key=stage_ms.get)
+    flop_per_launch = MAC_PER_POINT * 2.0 * POINTS_PER_RAY * args.rays
+    achieved = flop_per_launch / (stage_ms[dom] * 1e-3) / 1e12 if stage_ms[dom] > 0 else 0.0
+    roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                'stage_ms_per_step': {k: round(v, 3) for k, v in stage_ms.items()},
+                'other_kernels_ms_per_step': round(other_ms, 3),
+                'step_flop_frac': round(3 * flop_per_launch / (elapsed / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+
+    result = {
+        'metric': 'train_rays_per_sec', 'value': round(value, 1), 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'LLFF-fern 2-view geometry, %d rays/iter/GPU x (64+128) samples, coarse+fine 8x256 MLP, '
+                               'V=1 secondary view, losses MSE+Visibility+VisibilityPrior, Adam' % args.rays,
+                   'rays_per_gpu': args.rays, 'parallelism': f'ray-sharded dp{world}'},
+        'roofline': roofline,
+    }
+
+    if world == 1 and not args.no_render:
+        # full-frame eval render: 756 x 1008 rays, no secondary views, per-ray outputs on device
+        model.eval()
+        n = 756 * 1008
+        fb = make_batch(vo, n, 4242, dev)
+        with torch.no_grad():
+            for _ in range(2):
+                b = dict(fb); b['common_data'] = {'poses': fb['common_data']['poses']}
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                model(b)
+                torch.cuda.synchronize(); rt = time.perf_counter() - t0
+        result['render_ms_per_frame'] = round(rt * 1e3, 1)
+        result['render_rays_per_sec'] = round(n / rt, 1)
+        model.train()
+
+    if world == 1 and not args.no_cpu_baseline:
+        cores = torch.get_num_threads()
+        v = cpu_baseline(vo, args.cpu_rays, args.cpu_steps)
+        result['cpu_baseline'] = {'value': round(v, 1), 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
+                                  'sample': '%d training steps of %d rays (same synthetic workload, CPU oracle, fp32, '
+                                            'os.cpu_count=%d)' % (args.cpu_steps, args.cpu_rays, os.cpu_count())}
+    print(json.dumps(result), flush=True)
+
+
+if __name__ == '__main__':
+    main()

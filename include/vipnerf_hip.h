@@ -50,14 +50,15 @@ typedef struct vipnerf_config {
     int32_t n_coarse;     /* coarse_mlp.num_samples (64); multiple of 32, <= 256 */
     int32_t n_fine;       /* fine_mlp.num_samples (128); 0 = coarse pass only; n_coarse+n_fine mult. of 32, <= 256 */
     int32_t n_sec;        /* V: secondary views whose visibility is predicted this call (0 if !sec_views_vis) */
-    int32_t train;        /* model.training: stratified jitter (perturb) + sigma noise */
+    int32_t train;        /* model.training: sigma noise (if noise_std > 0) */
     int32_t lindisp;      /* configs['model']['lindisp'] */
     int32_t white_bkgd;   /* configs['model']['white_bkgd'] */
     int32_t save_acts;    /* keep layer activations in the `acts` workspace for vipnerf_render_backward */
     float   noise_std;    /* configs['model']['raw_noise_std'] (used when train) */
     int32_t given_z_fine; /* parity tests (teacher forcing): out->fine.z_vals already holds the fine depths on
                              entry; importance sampling is skipped.  0 in production. */
-    int32_t reserved[6];
+    int32_t perturb;      /* configs['model']['perturb'] && training: stratified jitter + random inverse-CDF draws */
+    int32_t reserved[5];
 } vipnerf_config;
 
 /* One ray batch (render_rays' input_dict, src/models/VipNeRF01.py:74-98).  N = n_rays. */
@@ -233,6 +234,18 @@ int32_t vipnerf_mlp_forward(int64_t n_points, int32_t n_sec, const float *pts, c
  * held in lvl->raw_* and lvl->z_vals; fills the remaining fields of *lvl. */
 int32_t vipnerf_composite(const vipnerf_config *cfg, const vipnerf_rays *rays, int32_t n_samples,
                           const vipnerf_level_out *lvl, vipnerf_stream_t stream);
+
+/* ---- measurement --------------------------------------------------------------------------------------- */
+/* Per-stage device time from HIP events recorded on the launch stream around each kernel (group) the calls
+ * above queue.  Off by default.  profile_read waits for the recorded events, aggregates them by stage name
+ * ("mlp_fwd_fine", "mlp_dgrad_fine", "wgrad_256x256", ...), returns up to max_entries and clears the log. */
+typedef struct vipnerf_profile_entry {
+    char    name[32];
+    int32_t count;
+    float   total_ms;
+} vipnerf_profile_entry;
+int32_t vipnerf_profile_enable(int32_t on);
+int32_t vipnerf_profile_read(vipnerf_profile_entry *entries, int32_t max_entries, int32_t *n_out);
 
 #ifdef __cplusplus
 }

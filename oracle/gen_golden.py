@@ -256,14 +256,14 @@ def gen_f4():
     n = 48
     b = vo.synthetic_batch(n, 400, scene='fern', nf=2)
     cfg = ref_configs(True, netchunk=2048, chunk=32)            # exercise both host loops
-    params = vo.init_params(11, scale=1.6)
+    params = vo.init_params(11, scale=1.6, sigma_bias=0.6)
     model = ref_model(cfg, params).eval()
     with torch.no_grad():
         out_plain = model(ref_batch(b, 0))                                   # retraw False, no secondary
         out_raw = model(ref_batch(b, 0), retraw=True, sec_views_vis=True)    # validation of a train frame
     keys_plain = sorted(out_plain.keys())
     d = pack_outputs(out_raw, ('coarse', 'fine'))
-    npz('f4_eval_fern', seed_params=11, scale_params=1.6, seed_batch=400, n=n,
+    npz('f4_eval_fern', seed_params=11, scale_params=1.6, sigma_bias=0.6, seed_batch=400, n=n,
         keys_plain=np.array(keys_plain), **{'plain_' + k: v for k, v in out_plain.items()}, **d)
 
 

@@ -71,7 +71,7 @@ def mlp_param_shapes(depth: int = 8, width: int = 256, l_pts: int = 10, l_view: 
 
 
 def init_params(seed: int, depth: int = 8, width: int = 256, l_pts: int = 10, l_view: int = 4,
-                levels=('coarse', 'fine'), scale: float = 1.0) -> Dict[str, np.ndarray]:
+                levels=('coarse', 'fine'), scale: float = 1.0, sigma_bias: float = 0.0) -> Dict[str, np.ndarray]:
     """Deterministic, platform-independent parameter set (numpy PCG64), U(-1/sqrt(in), 1/sqrt(in)) like
     nn.Linear's default.  Keys follow the reference's state_dict: `coarse_model.pts_linears.0.weight`, ..."""
     rng = np.random.default_rng(seed)
@@ -82,6 +82,7 @@ def init_params(seed: int, depth: int = 8, width: int = 256, l_pts: int = 10, l_
                 name.replace('bias', 'weight')][1]
             bound = scale / math.sqrt(fan_in)
             out[f'{level}_model.{name}'] = rng.uniform(-bound, bound, size=shape).astype(np.float32)
+        out[f'{level}_model.pts_output_linear.bias'] += np.float32(sigma_bias)   # lets eval-mode tests see non-zero density
     return out
 
 

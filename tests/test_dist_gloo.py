@@ -1,0 +1,85 @@
+"""The N>1 path on CPU: two gloo processes, ray-sharded, one all-reduce of the flat gradient bucket.  The model
+here is the CPU oracle (the HIP module cannot run without a GPU); what is under test is vipnerf_hip.dist -- bucket
+views, the single collective, shard arithmetic -- and the claim of SURVEY.md §8e that with equal shards the averaged
+per-rank gradients equal the single-process gradients of the whole batch."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'vip-nerf_amd'))
+
+N_RAYS = 16
+CFG = {'ndc': True, 'n_coarse': 64, 'n_fine': 128, 'noise_std': 1.0}
+LOSSES = [{'name': 'MSE01', 'weight': 1}, {'name': 'VisibilityLoss01', 'weight': 0.1},
+          {'name': 'VisibilityPriorLoss01', 'iter_weights': {'0': 0, '30000': 0.001}}]
+
+
+class OracleModule(torch.nn.Module):
+    def __init__(self, params):
+        super().__init__()
+        self.names = list(params.keys())
+        self.ps = torch.nn.ParameterList([torch.nn.Parameter(torch.from_numpy(v.copy())) for v in params.values()])
+
+    def pdict(self):
+        return dict(zip(self.names, self.ps))
+
+
+def step_grads(model, batch, rng, sl):
+    from oracle import vipnerf_oracle as vo
+    n = batch['rays_o'].shape[0]
+    sub = {k: (v[sl] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == n else v) for k, v in batch.items()}
+    out = vo.render_rays(model.pdict(), sub, CFG, {k: v[sl] for k, v in rng.items()}, train=True, sec_views=True)
+    vo.total_loss(sub, out, LOSSES, 40000)['TotalLoss'].backward()
+
+
+def worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from oracle import vipnerf_oracle as vo
+    from vipnerf_hip import dist as vdist
+    r, w, _ = vdist.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world)
+    params = vo.init_params(5 + rank, scale=1.6)            # deliberately different: broadcast must fix it
+    model = OracleModule(params)
+    vdist.broadcast_parameters(model, src=0)
+    bucket = vdist.FlatGradBucket(model.parameters())
+    batch = vo.synthetic_batch(N_RAYS, 3, scene='fern', nf=2)
+    rng = vo.synthetic_rng(N_RAYS, 64, 128, 4)
+    bucket.zero()
+    step_grads(model, batch, rng, vdist.shard_rows(N_RAYS, rank, world))
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views)), 'grads left the bucket'
+    bucket.all_reduce_mean()
+    ret[rank] = bucket.flat.clone().numpy()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_step_matches_single_process():
+    from oracle import vipnerf_oracle as vo
+    from vipnerf_hip import dist as vdist
+    world, port = 2, 29500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(worker, args=(world, port, ret), nprocs=world, join=True)
+    assert np.array_equal(ret[0], ret[1]), 'ranks disagree after the all-reduce'
+    model = OracleModule(vo.init_params(5, scale=1.6))
+    bucket = vdist.FlatGradBucket(model.parameters())
+    bucket.zero()
+    step_grads(model, vo.synthetic_batch(N_RAYS, 3, scene='fern', nf=2), vo.synthetic_rng(N_RAYS, 64, 128, 4), slice(0, N_RAYS))
+    ref = bucket.flat.numpy()
+    assert ref.size == 1191946
+    err = np.linalg.norm(ret[0] - ref) / np.linalg.norm(ref)
+    assert err < 1e-5, err
+
+
+def test_shard_rows_partition():
+    from vipnerf_hip import dist as vdist
+    for world in (1, 2, 4, 8):
+        rows = np.concatenate([np.arange(4096)[vdist.shard_rows(4096, r, world)] for r in range(world)])
+        assert np.array_equal(rows, np.arange(4096))

@@ -88,7 +88,8 @@ def _check_outputs(out, g, levels, rtol, atol):
 def test_f4_eval_render():
     g = load('f4_eval_fern')
     b = vo.synthetic_batch(int(g['n']), int(g['seed_batch']), scene='fern', nf=2)
-    p = vo.params_to_torch(vo.init_params(int(g['seed_params']), scale=float(g['scale_params'])))
+    p = vo.params_to_torch(vo.init_params(int(g['seed_params']), scale=float(g['scale_params']),
+                                          sigma_bias=float(g['sigma_bias'])))
     with torch.no_grad():
         out = vo.render_rays(p, b, _cfg(True), None, train=False, sec_views=True)
         plain = vo.render_rays(p, b, _cfg(True), None, train=False, sec_views=False)

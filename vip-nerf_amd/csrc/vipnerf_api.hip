@@ -4,7 +4,12 @@
 #include <cstdio>
 #include <cstring>
 
+#include <mutex>
+#include <string>
+#include <vector>
+
 #include "vipnerf_mlp.h"
+#include "vipnerf_prof.h"
 #include "vipnerf_ray.h"
 #include "vipnerf_wgrad.h"
 
@@ -17,6 +22,35 @@ void set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ---- per-kernel event timing -----------------------------------------------------------------------------
+struct ProfRec { const char *name; hipEvent_t e0, e1; };
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+
+static hipEvent_t prof_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+ProfScope::ProfScope(const char *name, hipStream_t s) : idx(-1), st(s) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r{name, prof_event(), prof_event()};
+    if (!r.e0 || !r.e1) return;
+    hipEventRecord(r.e0, st);
+    g_recs.push_back(r);
+    idx = (int)g_recs.size() - 1;
+}
+ProfScope::~ProfScope() {
+    if (idx < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (idx < (int)g_recs.size()) hipEventRecord(g_recs[idx].e1, st);
 }
 
 static int check_cfg(const vipnerf_config *cfg) {
@@ -121,6 +155,7 @@ int32_t vipnerf_sample_fine(int64_t n_rays, int32_t n_coarse, int32_t n_fine, co
 int32_t vipnerf_mlp_forward(int64_t n_points, int32_t n_sec, const float *pts, const float *view_dirs,
                             const float *view_dirs2, const float *noise, float noise_std, const void *packed,
                             float *sigma, float *rgb, float *vis, float *vis2, vipnerf_stream_t stream) {
+    if (n_points == 0) return VIPNERF_OK;
     if (!pts || !view_dirs || !packed || !sigma || !rgb || !vis || (n_sec > 0 && (!view_dirs2 || !vis2))) {
         set_error("mlp_forward: NULL argument"); return VIPNERF_E_ARG; }
     if (n_sec < 0 || n_sec > VIPNERF_MAX_SEC) { set_error("mlp_forward: n_sec=%d unsupported", n_sec); return VIPNERF_E_UNSUPPORTED; }
@@ -161,13 +196,16 @@ int32_t vipnerf_render_forward(const vipnerf_config *cfg, const vipnerf_rays *ra
     const int64_t N = rays->n_rays;
     if (N == 0) return VIPNERF_OK;
     const int Sc = cfg->n_coarse, Sf = cfg->n_fine, V = cfg->n_sec;
-    const bool train = cfg->train != 0;
+    const bool train = cfg->train != 0, perturb = cfg->perturb != 0;
     const uint64_t seed = rng ? rng->seed : 0, offset = rng ? rng->offset : 0;
 
     // 1. coarse depths
-    const float *t_rand = (train && rng) ? rng->t_rand : nullptr;
-    rc = launch_coarse_z(N, Sc, cfg->lindisp, rays->near, rays->far, t_rand, train && !t_rand, seed, offset,
-                         out->coarse.z_vals, st);
+    const float *t_rand = (perturb && rng) ? rng->t_rand : nullptr;
+    {
+        ProfScope ps("coarse_z", st);
+        rc = launch_coarse_z(N, Sc, cfg->lindisp, rays->near, rays->far, t_rand, perturb && !t_rand, seed, offset,
+                             out->coarse.z_vals, st);
+    }
     if (rc) return rc;
 
     for (int lv = 0; lv < (Sf > 0 ? 2 : 1); ++lv) {
@@ -178,9 +216,10 @@ int32_t vipnerf_render_forward(const vipnerf_config *cfg, const vipnerf_rays *ra
             SampleArgs sa;
             memset(&sa, 0, sizeof(sa));
             sa.N = N; sa.Sc = Sc; sa.Sf = Sf; sa.z_coarse = out->coarse.z_vals; sa.w_coarse = out->coarse.weights;
-            sa.u = (train && rng) ? rng->u : nullptr;
-            sa.device_rng = train && !sa.u; sa.seed = seed; sa.offset = offset;
+            sa.u = (perturb && rng) ? rng->u : nullptr;
+            sa.device_rng = perturb && !sa.u; sa.seed = seed; sa.offset = offset;
             sa.z_fine = L.z_vals; sa.inds = out->sample_inds; sa.z_samples = out->z_samples;
+            ProfScope ps("sample_fine", st);
             if ((rc = launch_sample_fine(sa, st))) return rc;
         }
         // 2./5. MLP
@@ -201,12 +240,16 @@ int32_t vipnerf_render_forward(const vipnerf_config *cfg, const vipnerf_rays *ra
             ma.al = act_layout((size_t)N * S, V);
             ma.acts = (float *)acts + (lv ? act_layout(Pc, V).total : 0);
         }
-        if ((rc = launch_mlp_fwd(ma, st))) return rc;
+        {
+            ProfScope ps(lv ? "mlp_fwd_fine" : "mlp_fwd_coarse", st);
+            if ((rc = launch_mlp_fwd(ma, st))) return rc;
+        }
         // 3./6. compositing
         CompositeArgs ca;
         memset(&ca, 0, sizeof(ca));
         ca.N = N; ca.S = S; ca.V = V; ca.ndc = cfg->ndc; ca.white_bkgd = cfg->white_bkgd;
         ca.rays_o = rays->rays_o; ca.rays_d = rays->rays_d; ca.rays_d_s = rays->rays_d_s; ca.lvl = L;
+        ProfScope ps("composite", st);
         if ((rc = launch_composite(ca, st))) return rc;
     }
     return VIPNERF_OK;
@@ -245,7 +288,10 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
         cb.rays_o = rays->rays_o; cb.rays_d = rays->rays_d; cb.rays_d_s = rays->rays_d_s; cb.lvl = L;
         cb.g = lv ? gout->fine : gout->coarse;
         cb.dsig = bw + bl.dsig; cb.drgb = bw + bl.drgb; cb.dvis = bw + bl.dvis; cb.dvis2 = bw + bl.dvis2;
-        if ((rc = launch_composite_bwd(cb, st))) return rc;
+        {
+            ProfScope ps("composite_bwd", st);
+            if ((rc = launch_composite_bwd(cb, st))) return rc;
+        }
         // 2. MLP data gradients (register-chained, transposed weights)
         MlpBwdArgs mb;
         memset(&mb, 0, sizeof(mb));
@@ -255,7 +301,10 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
         mb.al = act_layout(P, V);
         mb.acts = (const float *)acts + (lv ? act_layout((size_t)N * Sc, V).total : 0);
         mb.bwd = bw; mb.bl = bl;
-        if ((rc = launch_mlp_bwd(mb, st))) return rc;
+        {
+            ProfScope ps(lv ? "mlp_dgrad_fine" : "mlp_dgrad_coarse", st);
+            if ((rc = launch_mlp_bwd(mb, st))) return rc;
+        }
         // 3. weight gradients: dW = dY^T H as MFMA GEMMs over the point axis
         if ((rc = launch_wgrad(P, V, mb.acts, mb.al, bw, bl, G, st))) return rc;
     }
@@ -282,7 +331,33 @@ int32_t vipnerf_losses_forward(const vipnerf_config *cfg, int64_t n_rays, const 
             set_error("losses_forward: a seed pointer is NULL"); return VIPNERF_E_ARG; }
     }
     a.partial = lout->scratch; a.counts = lout->scratch + 7 * (size_t)n_rays; a.loss_values = lout->loss_values;
+    ProfScope ps("losses", (hipStream_t)stream);
     return launch_losses(a, (hipStream_t)stream);
+}
+
+int32_t vipnerf_profile_enable(int32_t on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return VIPNERF_OK;
+}
+
+int32_t vipnerf_profile_read(vipnerf_profile_entry *entries, int32_t max_entries, int32_t *n_out) {
+    if (!entries || !n_out || max_entries <= 0) { set_error("profile_read: bad argument"); return VIPNERF_E_ARG; }
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int n = 0;
+    for (auto &r : g_recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            int k = 0;
+            for (; k < n; ++k) if (!strcmp(entries[k].name, r.name)) break;
+            if (k == n && n < max_entries) { memset(&entries[n], 0, sizeof(entries[n])); strncpy(entries[n].name, r.name, sizeof(entries[n].name) - 1); ++n; }
+            if (k < n) { entries[k].count += 1; entries[k].total_ms += ms; }
+        }
+        g_pool.push_back(r.e0); g_pool.push_back(r.e1);
+    }
+    g_recs.clear();
+    *n_out = n;
+    return VIPNERF_OK;
 }
 
 }  // extern "C"

@@ -1,5 +1,278 @@
+// Weight gradients of one level: every nn.Linear's dW = dY^T H (and db = column sums of dY) as fp32-MFMA
+// GEMMs that contract over the POINT axis (autograd of reference src/models/VipNeRF01.py:537-596 w.r.t. the
+// parameters).
+//
+// A = dY [P][M] and B = H [P][K] are the row-major arrays the forward / dgrad kernels left in HBM.  With points
+// along MFMA's k the fragments are rows of those arrays: lane l supplies A[p = 2s + (l>>5)][o = 32*ot + (l&31)]
+// and B[p][k = 32*kt + (l&31)] -- 128 contiguous bytes per half-wave, conflict-free from a row-major LDS tile.
+// A workgroup owns one (GEMM, point-chunk) pair, keeps the whole M x K product in accumulators (up to 16
+// 32x32 tiles = 256 registers per wave), streams 32-point tiles of A and B through double-buffered LDS, and
+// writes its partial product; an ordered second pass sums the chunks (deterministic; no atomics) straight into
+// the nn.Linear-layout gradient tensors.
 #include "vipnerf_wgrad.h"
+#include "vipnerf_prof.h"
+
 namespace vn {
-int launch_wgrad(size_t, int, const float *, const ActLayout &, float *, const BwdLayout &, const vipnerf_mlp_grads *, hipStream_t) {
-    set_error("wgrad not built yet"); return VIPNERF_E_UNSUPPORTED; }
+
+struct WgDesc {
+    const float *A; int lda; int m_load;      // A[p][0..m_load) is read (m_load multiple of 4), zero beyond
+    const float *B; int ldb; int k_load;
+    size_t part_off;                          // float offset of this GEMM's partials (chunk 0)
+    size_t part_stride;                       // floats per chunk: Mp*Kp + Mp
+};
+constexpr int WG_MAX_DESC = 12;
+struct WgArgs {
+    WgDesc d[WG_MAX_DESC];
+    int64_t P;
+    int chunk_pts;
+    float *partial;
+};
+
+// output groups for the ordered reduction
+struct WgGroup {
+    size_t part_off, part_stride;             // of the group's first GEMM
+    int n_desc;                               // GEMMs summed into this output (consecutive, same shape)
+    size_t desc_stride;                       // float distance between consecutive GEMMs' partial blocks
+    int Mp, Kp, m_valid, k_valid;
+    float *dW; int ldw; int col_off;
+    float *dbias;                             // NULL = no bias output
+};
+constexpr int WG_MAX_GROUP = 24;
+struct WgReduceArgs {
+    WgGroup g[WG_MAX_GROUP];
+    int n_chunks;
+    const float *partial;
+};
+
+__device__ __forceinline__ floatx16 mfma32(float a, float b, floatx16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+
+// MTW x KTW tiles per wave; WAVES_M waves split the M tiles (the other 4/WAVES_M split K).
+template <int MTW, int KTW, int WAVES_M>
+__global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
+    constexpr int WAVES_K = 4 / WAVES_M;
+    constexpr int MT = MTW * WAVES_M, KT = KTW * WAVES_K;
+    constexpr int Mp = 32 * MT, Kp = 32 * KT;
+    constexpr int TILE_F = 32 * (Mp + Kp);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const WgDesc &d = a.d[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int wm = wave % WAVES_M, wk = wave / WAVES_M;
+    const int64_t p0 = (int64_t)blockIdx.x * a.chunk_pts;
+    const int64_t p1 = p0 + a.chunk_pts < a.P ? p0 + a.chunk_pts : a.P;
+    const int nblk = (int)((p1 - p0 + 31) / 32);
+
+    floatx16 acc[MTW][KTW];
+    float bsum[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        bsum[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KTW; ++j) acc[i][j] = (floatx16)(0.f);
+    }
+
+    float4 ra[MT], rb[KT];
+    auto gload = [&](int blk) {
+        const int64_t pb = p0 + (int64_t)blk * 32;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int idx = tid + 256 * i, row = idx / (8 * MT), col = 4 * (idx % (8 * MT));
+            const bool ok = (pb + row < p1) && (col < d.m_load);
+            ra[i] = ok ? *(const float4 *)(d.A + (size_t)(pb + row) * d.lda + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < KT; ++i) {
+            const int idx = tid + 256 * i, row = idx / (8 * KT), col = 4 * (idx % (8 * KT));
+            const bool ok = (pb + row < p1) && (col < d.k_load);
+            rb[i] = ok ? *(const float4 *)(d.B + (size_t)(pb + row) * d.ldb + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&](int buf) {
+        float4 *la = (float4 *)(lds + buf * TILE_F), *lb = (float4 *)(lds + buf * TILE_F + 32 * Mp);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) la[tid + 256 * i] = ra[i];
+#pragma unroll
+        for (int i = 0; i < KT; ++i) lb[tid + 256 * i] = rb[i];
+    };
+
+    if (nblk > 0) { gload(0); lstore(0); }
+    __syncthreads();
+    int cur = 0;
+    for (int blk = 0; blk < nblk; ++blk) {
+        if (blk + 1 < nblk) gload(blk + 1);
+        const float *la = lds + cur * TILE_F, *lb = la + 32 * Mp;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            float af[MTW], bf[KTW];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) af[i] = la[(2 * s + h) * Mp + 32 * (wm * MTW + i) + l31];
+#pragma unroll
+            for (int j = 0; j < KTW; ++j) bf[j] = lb[(2 * s + h) * Kp + 32 * (wk * KTW + j) + l31];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+                bsum[i] += af[i];
+#pragma unroll
+                for (int j = 0; j < KTW; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+            }
+        }
+        if (blk + 1 < nblk) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // partial product of this chunk: [Mp][Kp] row-major, then the bias column sums [Mp]
+    float *part = a.partial + d.part_off + (size_t)blockIdx.x * d.part_stride;
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int ot = wm * MTW + i;
+#pragma unroll
+        for (int j = 0; j < KTW; ++j) {
+            const int kt = wk * KTW + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * h;
+                part[(size_t)o * Kp + 32 * kt + l31] = acc[i][j][r];
+            }
+        }
+        if (wk == 0) {
+            const float b = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+            if (h == 0) part[(size_t)Mp * Kp + 32 * ot + l31] = b;
+        }
+    }
+}
+
+__global__ void k_wgrad_reduce(WgReduceArgs a) {
+    const WgGroup &g = a.g[blockIdx.y];
+    const int n_w = g.m_valid * g.k_valid;
+    const int n_all = n_w + (g.dbias ? g.m_valid : 0);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_all; e += gridDim.x * blockDim.x) {
+        size_t off;
+        float *dst;
+        if (e < n_w) {
+            const int m = e / g.k_valid, k = e % g.k_valid;
+            off = (size_t)m * g.Kp + k;
+            dst = g.dW + (size_t)m * g.ldw + g.col_off + k;
+        } else {
+            const int m = e - n_w;
+            off = (size_t)g.Mp * g.Kp + m;
+            dst = g.dbias + m;
+        }
+        float s = 0.f;
+        for (int dd = 0; dd < g.n_desc; ++dd) {
+            const float *pp = a.partial + g.part_off + (size_t)dd * g.desc_stride + off;
+            for (int c = 0; c < a.n_chunks; ++c) s += pp[(size_t)c * g.part_stride];
+        }
+        *dst = s;
+    }
+}
+
+template <int MTW, int KTW, int WAVES_M>
+static int launch_class(const WgArgs &args, int n_desc, int n_chunks, hipStream_t st) {
+    if (n_desc == 0) return VIPNERF_OK;
+    constexpr int MT = MTW * WAVES_M, KT = KTW * (4 / WAVES_M);
+    const size_t lds = (size_t)2 * 32 * (32 * MT + 32 * KT) * sizeof(float);
+    VN_HIP(hipFuncSetAttribute((const void *)k_wgrad<MTW, KTW, WAVES_M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_wgrad<MTW, KTW, WAVES_M>), dim3(n_chunks, n_desc), dim3(256), lds, st, args);
+    VN_HIP(hipGetLastError());
+    return VIPNERF_OK;
+}
+
+int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float *bwd, const BwdLayout &bl,
+                 const vipnerf_mlp_grads *G, hipStream_t st) {
+    if (P == 0) return VIPNERF_OK;
+    const int n_chunks = wgrad_chunks(P);
+    const int chunk_pts = (int)(((P + n_chunks - 1) / n_chunks + 31) / 32 * 32);
+    float *partial = bwd + bl.partial;
+
+    WgArgs c88, c82, c48, c41, c18, c14;       // classes by (M tiles, K tiles)
+    WgReduceArgs red;
+    int n88 = 0, n82 = 0, n48 = 0, n41 = 0, n18 = 0, n14 = 0, ng = 0;
+    size_t off = 0;
+    auto init = [&](WgArgs &w) { w.P = (int64_t)P; w.chunk_pts = chunk_pts; w.partial = partial; };
+    init(c88); init(c82); init(c48); init(c41); init(c18); init(c14);
+    red.n_chunks = n_chunks;
+    red.partial = partial;
+
+    // adds one GEMM; returns its partial offset
+    auto add = [&](WgArgs &w, int &n, int Mp, int Kp, const float *A, int lda, int m_load, const float *B, int ldb, int k_load) {
+        WgDesc &d = w.d[n++];
+        d.A = A; d.lda = lda; d.m_load = m_load; d.B = B; d.ldb = ldb; d.k_load = k_load;
+        d.part_off = off; d.part_stride = (size_t)Mp * Kp + Mp;
+        const size_t o = off;
+        off += (size_t)n_chunks * d.part_stride;
+        return o;
+    };
+    auto group = [&](size_t part_off, int n_desc, int Mp, int Kp, int m_valid, int k_valid, float *dW, int ldw, int col_off, float *dbias) {
+        WgGroup &g = red.g[ng++];
+        g.part_off = part_off; g.part_stride = (size_t)Mp * Kp + Mp; g.n_desc = n_desc;
+        g.desc_stride = (size_t)n_chunks * g.part_stride;
+        g.Mp = Mp; g.Kp = Kp; g.m_valid = m_valid; g.k_valid = k_valid; g.dW = dW; g.ldw = ldw; g.col_off = col_off; g.dbias = dbias;
+    };
+    const float *pex = acts + al.pex;
+    // trunk
+    for (int i = 0; i < D; ++i) {
+        const float *dy = bwd + bl.dy[i];
+        float *dW = G->g[2 * i], *db = G->g[2 * i + 1];
+        if (i == 0) {
+            const size_t o = add(c82, n82, 256, 64, dy, W, W, pex, DPE_PAD, DPE_PAD);
+            group(o, 1, 256, 64, W, DPE, dW, DPE, 0, db);
+        } else if (i == SKIP_LAYER) {
+            const size_t o1 = add(c82, n82, 256, 64, dy, W, W, pex, DPE_PAD, DPE_PAD);
+            group(o1, 1, 256, 64, W, DPE, dW, W + DPE, 0, nullptr);
+            const size_t o2 = add(c88, n88, 256, 256, dy, W, W, acts + al.h[i - 1], W, W);
+            group(o2, 1, 256, 256, W, W, dW, W + DPE, DPE, db);
+        } else {
+            const size_t o = add(c88, n88, 256, 256, dy, W, W, acts + al.h[i - 1], W, W);
+            group(o, 1, 256, 256, W, W, dW, W, 0, db);
+        }
+    }
+    {   // feature_linear
+        const size_t o = add(c88, n88, 256, 256, bwd + bl.dyf, W, W, acts + al.h[D - 1], W, W);
+        group(o, 1, 256, 256, W, W, G->g[P_FW], W, 0, G->g[P_FB]);
+    }
+    {   // sigma head: A = column 4 of DQ[0]
+        const size_t o = add(c18, n18, 32, 256, bwd + bl.dq[0] + 4, 8, 4, acts + al.h[D - 1], W, W);
+        group(o, 1, 32, 256, 1, W, G->g[P_SW], W, 0, G->g[P_SB]);
+    }
+    {   // view layer, feature columns: A = sum over directions
+        const size_t o = add(c48, n48, 128, 256, bwd + bl.dyvsum, WV, WV, acts + al.feat, W, W);
+        group(o, 1, 128, 256, WV, W, G->g[P_VW], W + DVE, 0, G->g[P_VB]);
+    }
+    {   // view layer, direction columns: one GEMM per direction, summed in order
+        size_t first = 0;
+        for (int k = 0; k <= V; ++k) {
+            const size_t o = add(c41, n41, 128, 32, bwd + bl.dyv[k], WV, WV, acts + al.ped[k], DVE_PAD, DVE_PAD);
+            if (k == 0) first = o;
+        }
+        group(first, 1 + V, 128, 32, WV, DVE, G->g[P_VW], W + DVE, W, nullptr);
+    }
+    {   // output head: A = DQ[k][:, 0:4], B = view hidden of direction k
+        size_t first = 0;
+        for (int k = 0; k <= V; ++k) {
+            const size_t o = add(c14, n14, 32, 128, bwd + bl.dq[k], 8, 4, acts + al.g[k], WV, WV);
+            if (k == 0) first = o;
+        }
+        group(first, 1 + V, 32, 128, 4, WV, G->g[P_OW], WV, 0, G->g[P_OB]);
+    }
+    if (off > (size_t)n_chunks * wgrad_partial_per_chunk(V)) { set_error("wgrad: partial buffer plan mismatch"); return VIPNERF_E_ARG; }
+
+    int rc;
+    {
+        ProfScope ps("wgrad_256x256", st);
+        if ((rc = launch_class<2, 8, 4>(c88, n88, n_chunks, st))) return rc;
+    }
+    ProfScope ps("wgrad_small", st);
+    if ((rc = launch_class<1, 8, 4>(c48, n48, n_chunks, st))) return rc;
+    if ((rc = launch_class<2, 2, 4>(c82, n82, n_chunks, st))) return rc;
+    if ((rc = launch_class<1, 1, 4>(c41, n41, n_chunks, st))) return rc;
+    if ((rc = launch_class<1, 2, 1>(c18, n18, n_chunks, st))) return rc;
+    if ((rc = launch_class<1, 1, 1>(c14, n14, n_chunks, st))) return rc;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(64, ng), dim3(256), 0, st, red);
+    VN_HIP(hipGetLastError());
+    return VIPNERF_OK;
+}
+
+}  // namespace vn

@@ -1,0 +1,50 @@
+"""Shared evaluation of the four ray losses on the GPU.  The first drop-in loss class asked for its value in an
+iteration runs ONE fused kernel (vipnerf_losses_forward) over the model's output dict and caches the eight
+loss scalars on that dict; the other classes read them.  Autograd sees a single node whose backward scales the
+kernel's precomputed gradient seeds by each loss's weight."""
+import os
+import sys
+from pathlib import Path
+
+import torch
+
+try:
+    import vipnerf_hip  # noqa: F401
+except ImportError:
+    for cand in (os.environ.get('VIPNERF_HIP_ROOT'), str(Path(__file__).resolve().parents[2])):
+        if cand and cand not in sys.path:
+            sys.path.insert(0, cand)
+from vipnerf_hip import ops
+from vipnerf_hip.autograd import FusedLossFunction
+
+CACHE_KEY = '_vipnerf_hip_fused_losses'
+
+
+def fused_loss_values(configs: dict, input_dict: dict, output_dict: dict) -> torch.Tensor:
+    """-> tensor (8,): [mse_c, mse_f, vis_c, vis_f, prior_c, prior_f, sparse_depth, 0] (unweighted)."""
+    if CACHE_KEY in output_dict:
+        return output_dict[CACHE_KEY]
+    m = configs['model']
+    fine = 'fine_mlp' in m
+    n = output_dict['rgb_coarse'].shape[0]
+    V = output_dict['visibility2_coarse'].shape[1] if 'visibility2_coarse' in output_dict else 0
+    cfg = ops.make_config(configs['data_loader']['ndc'], m['coarse_mlp']['num_samples'],
+                          m['fine_mlp']['num_samples'] if fine else 0, V, train=False)
+    prior = None
+    if V > 0:
+        if 'visibility_prior_masks' in input_dict:
+            prior = input_dict['visibility_prior_masks']
+        elif 'visibility_prior_weights' in input_dict:
+            prior = input_dict['visibility_prior_weights']
+    mask_sd = input_dict.get('indices_mask_sparse_depth')
+    sd = input_dict['sparse_depth_values'][:, 0] if mask_sd is not None else None
+
+    def level(lv):
+        if f'rgb_{lv}' not in output_dict:
+            return (None,) * 5
+        return (output_dict[f'rgb_{lv}'], output_dict[f'visibility_{lv}'], output_dict[f'raw_visibility_{lv}'][..., 0],
+                output_dict.get(f'visibility2_{lv}'), output_dict[f'depth_{lv}'])
+    vals = FusedLossFunction.apply(cfg, n, input_dict['target_rgb'], input_dict['indices_mask_nerf'], prior, mask_sd, sd,
+                                   *level('coarse'), *(level('fine') if fine else (None,) * 5))
+    output_dict[CACHE_KEY] = vals
+    return vals

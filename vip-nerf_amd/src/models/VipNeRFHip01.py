@@ -1,0 +1,158 @@
+"""Drop-in model for the reference's name-based factory: set configs['model']['name'] = 'VipNeRFHip01' and
+`models.ModelFactory.get_model` (reference src/models/ModelFactory.py:10-22) instantiates `VipNeRFHip` with the
+same `(configs, model_configs)` constructor, `forward(input_batch, retraw, sec_views_vis) -> dict` and
+`render_rays(input_dict, retraw, sec_views_vis) -> dict` contract as `VipNeRF`
+(reference src/models/VipNeRF01.py:11-171).  Parameters are ordinary nn.Linear modules with the reference's names and
+shapes (`coarse_model.pts_linears.0.weight`, ...), created in the reference's construction order
+(VipNeRF01.py:472-491), so optimizers, checkpoints (incl. the `module.` DataParallel prefix) and seeded
+initialisation carry over.
+
+All arithmetic of the path runs in libvipnerf_hip.so (MI355X / gfx950).  There is no CPU fallback: on a box
+without the library or without a GPU tensor this module raises.
+"""
+import os
+import sys
+from pathlib import Path
+
+import torch
+
+try:
+    import vipnerf_hip  # noqa: F401
+except ImportError:
+    for cand in (os.environ.get('VIPNERF_HIP_ROOT'), str(Path(__file__).resolve().parents[2])):
+        if cand and cand not in sys.path:
+            sys.path.insert(0, cand)
+    import vipnerf_hip  # noqa: F401
+from vipnerf_hip import _lib as L
+from vipnerf_hip import ops
+from vipnerf_hip.autograd import RenderFunction, RenderState
+
+_SUPPORTED = {'netdepth': 8, 'netwidth': 256, 'points_positional_encoding_degree': 10,
+              'views_positional_encoding_degree': 4, 'use_view_dirs': True, 'view_dependent_rgb': True,
+              'predict_visibility': True}
+
+
+class MLPParams(torch.nn.Module):
+    """Parameter container with MLP's layout (reference VipNeRF01.py:451-492).  No forward of its own: the
+    network is evaluated inside the fused kernels."""
+
+    def __init__(self, configs, mlp_configs):
+        super().__init__()
+        for k, v in _SUPPORTED.items():
+            if mlp_configs.get(k) != v:
+                raise L.VipNerfHipError(f"VipNeRFHip supports only {k}={v} (got {mlp_configs.get(k)!r}): the HIP kernels are "
+                                        f"specialised on the one topology every shipped reference config uses")
+        self.configs, self.mlp_configs = configs, mlp_configs
+        W, d_pts, d_view = 256, 63, 27
+        self.pts_linears = torch.nn.ModuleList(
+            [torch.nn.Linear(d_pts, W)] +
+            [torch.nn.Linear(W, W) if i != 4 else torch.nn.Linear(W + d_pts, W) for i in range(7)])
+        self.views_linears = torch.nn.ModuleList([torch.nn.Linear(d_view + W, W // 2)])
+        self.pts_output_linear = torch.nn.Linear(W, 1)
+        self.feature_linear = torch.nn.Linear(W, W)
+        self.views_output_linear = torch.nn.Linear(W // 2, 4)
+        self.predict_visibility = True
+
+    def ordered_params(self):
+        sd = dict(self.named_parameters())
+        return [sd[n] for n in ops.PARAM_ORDER]
+
+
+class VipNeRFHip(torch.nn.Module):
+    def __init__(self, configs: dict, model_configs: dict = None):
+        super().__init__()
+        self.configs, self.model_configs = configs, model_configs
+        self.ndc = configs['data_loader']['ndc']
+        m = configs['model']
+        if 'coarse_mlp' not in m:
+            raise L.VipNerfHipError('VipNeRFHip needs a coarse_mlp')
+        self.coarse_mlp_needed = True
+        self.fine_mlp_needed = 'fine_mlp' in m
+        self.predict_visibility = True
+        self.coarse_model = MLPParams(configs, m['coarse_mlp'])
+        self.fine_model = MLPParams(configs, m['fine_mlp']) if self.fine_mlp_needed else None
+        self._calls = 0
+        # parity hooks (tests): injected random numbers / teacher-forced fine depths for the next forward
+        self.injected_rng = None
+        self.injected_z_fine = None
+
+    # ---- reference contract ------------------------------------------------------------------------------
+    def forward(self, input_batch: dict, retraw: bool = False, sec_views_vis: bool = False):
+        if 'common_data' in input_batch.keys():
+            for key in input_batch['common_data'].keys():           # same in-place unpacking as the reference
+                if isinstance(input_batch['common_data'][key], torch.Tensor):
+                    input_batch['common_data'][key] = input_batch['common_data'][key][0]
+        return self.render_rays(input_batch, retraw or self.training, sec_views_vis or self.training)
+
+    def render(self, input_dict: dict, retraw: bool, sec_views_vis: bool):
+        return self.render_rays(input_dict, retraw, sec_views_vis)
+
+    def render_rays(self, input_dict: dict, retraw: bool, sec_views_vis: bool):
+        """One fused launch sequence for any number of rays (the reference's chunk / netchunk host loops,
+        VipNeRF01.py:47-72,295-329, are not needed)."""
+        m = self.configs['model']
+        rays_o = input_dict['rays_o']
+        if not rays_o.is_cuda:
+            raise L.VipNerfHipError('VipNeRFHip runs on the GPU only (rays_o is on %s); there is no CPU fallback' % rays_o.device)
+        n = rays_o.shape[0]
+        batch = {k: input_dict[k] for k in ('rays_o', 'rays_d', 'view_dirs') if k in input_dict}
+        if self.ndc:
+            for k in ('rays_o_ndc', 'rays_d_ndc', 'near_ndc', 'far_ndc'):
+                batch[k] = input_dict[k]
+        else:
+            batch['near'], batch['far'] = input_dict['near'], input_dict['far']
+        V = 0
+        if sec_views_vis:
+            if 'rays_o2' in input_dict:
+                o2 = input_dict['rays_o2']
+            else:                                               # VipNeRF01.py:88-98 (index glue)
+                poses = input_dict['common_data']['poses']
+                image_id = input_dict['pixel_id'][:, 0].long()
+                nf = int(input_dict['num_frames'])
+                cols = []
+                for i in range(nf - 1):
+                    other = i + (i >= image_id).long()
+                    cols.append(poses[other][:, :3, 3])
+                o2 = torch.stack(cols, dim=1)
+            V = o2.shape[1]
+            batch['rays_o2'] = o2
+        n_fine = m['fine_mlp']['num_samples'] if self.fine_mlp_needed else 0
+        train = bool(self.training)
+        perturb = bool(m.get('perturb', False)) and train
+        noise_std = float(m.get('raw_noise_std', 0.0)) if train else 0.0
+        cfg = ops.make_config(self.ndc, m['coarse_mlp']['num_samples'], n_fine, V, train=train, noise_std=noise_std,
+                              lindisp=m.get('lindisp', False), white_bkgd=m.get('white_bkgd', False), perturb=perturb)
+        rng = None
+        if train:
+            rng = dict(self.injected_rng) if self.injected_rng is not None else {}
+            rng.setdefault('seed', torch.initial_seed() & 0xFFFFFFFFFFFFFFFF)
+            rng.setdefault('offset', self._calls)
+        self._calls += 1
+        state = RenderState(cfg, batch, rng, self.injected_z_fine)
+        params = self.coarse_model.ordered_params() + (self.fine_model.ordered_params() if self.fine_mlp_needed else [])
+        outs = RenderFunction.apply(state, *params)
+        d = dict(zip(state.keys, outs))
+        ret = {}
+        for lv in ('coarse', 'fine') if self.fine_mlp_needed else ('coarse',):
+            S = d[f'z_vals_{lv}'].shape[1]
+            ret[f'z_vals_{lv}'] = d[f'z_vals_{lv}']
+            for k in ('rgb', 'acc', 'alpha', 'visibility', 'weights', 'depth', 'depth_var'):
+                ret[f'{k}_{lv}'] = d[f'{k}_{lv}']
+            if self.ndc:
+                ret[f'depth_ndc_{lv}'] = d[f'depth_ndc_{lv}']
+                ret[f'depth_var_ndc_{lv}'] = d[f'depth_var_ndc_{lv}']
+            if V > 0:
+                ret[f'visibility2_{lv}'] = d[f'vis2_{lv}']
+            if retraw:
+                ret[f'raw_sigma_{lv}'] = d[f'raw_sigma_{lv}'].unsqueeze(-1)
+                ret[f'raw_rgb_view_dependent_{lv}'] = d[f'raw_rgb_{lv}']
+                ret[f'raw_visibility_{lv}'] = d[f'raw_vis_{lv}'].unsqueeze(-1)
+                if V > 0:
+                    ret[f'raw_visibility2_{lv}'] = d[f'raw_vis2_{lv}'].unsqueeze(-1)
+                ret[f'raw_rgb_{lv}'] = d[f'raw_rgb_{lv}']
+        if not retraw:                                           # VipNeRF01.py:168-170
+            for lv in ('coarse', 'fine'):
+                for k in ('z_vals', 'visibility', 'weights'):
+                    ret.pop(f'{k}_{lv}', None)
+        self.last_extras = state.extras
+        return ret

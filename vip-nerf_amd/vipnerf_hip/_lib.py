@@ -23,7 +23,7 @@ class VipNerfHipError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [('ndc', C.c_int32), ('n_coarse', C.c_int32), ('n_fine', C.c_int32), ('n_sec', C.c_int32),
                 ('train', C.c_int32), ('lindisp', C.c_int32), ('white_bkgd', C.c_int32), ('save_acts', C.c_int32),
-                ('noise_std', C.c_float), ('given_z_fine', C.c_int32), ('reserved', C.c_int32 * 6)]
+                ('noise_std', C.c_float), ('given_z_fine', C.c_int32), ('perturb', C.c_int32), ('reserved', C.c_int32 * 5)]
 
 
 class Rays(C.Structure):
@@ -80,6 +80,10 @@ class LossOut(C.Structure):
     _fields_ = [('loss_values', c_f), ('coarse', LossLevelSeeds), ('fine', LossLevelSeeds), ('scratch', c_f)]
 
 
+class ProfileEntry(C.Structure):
+    _fields_ = [('name', C.c_char * 32), ('count', C.c_int32), ('total_ms', C.c_float)]
+
+
 # every symbol include/vipnerf_hip.h declares: name -> (restype, argtypes)
 P = C.POINTER
 SYMBOLS = {
@@ -97,6 +101,8 @@ SYMBOLS = {
     'vipnerf_mlp_forward': (C.c_int32, [C.c_int64, C.c_int32, c_f, c_f, c_f, c_f, C.c_float, c_f, c_f, c_f, c_f,
                                         c_f, c_f]),
     'vipnerf_composite': (C.c_int32, [P(Config), P(Rays), C.c_int32, P(LevelOut), c_f]),
+    'vipnerf_profile_enable': (C.c_int32, [C.c_int32]),
+    'vipnerf_profile_read': (C.c_int32, [P(ProfileEntry), C.c_int32, P(C.c_int32)]),
 }
 
 _lib = None

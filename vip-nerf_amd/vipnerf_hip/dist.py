@@ -1,0 +1,74 @@
+"""Ray-sharded data parallelism: one process per GPU, identical weights, each rank renders its own shard of the
+ray batch, and ONE all-reduce (RCCL over xGMI; `nccl` backend on ROCm) of a single flat fp32 gradient bucket per
+step replaces the reference's torch.nn.DataParallel replicate/scatter/gather (reference src/Trainer01.py:517,
+SURVEY.md §2.1, §8e).  No activation ever crosses GPUs.
+
+Every loss of the path is a mean over its own row subset, so with equal per-rank row counts the mean of the rank
+means is the global mean and averaging the gradients is exact.
+"""
+import os
+from typing import Iterable, List
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str = None):
+    """torchrun-style initialisation.  Returns (rank, world_size, local_rank)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class FlatGradBucket:
+    """Makes every parameter's .grad a view into one contiguous fp32 buffer so that the whole model's gradient
+    (1,191,946 floats = 4.77 MB for coarse + fine) is reduced with a single collective."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.views = []
+        o = 0
+        for p in self.params:
+            v = self.flat[o:o + p.numel()].view_as(p)
+            self.views.append(v)
+            o += p.numel()
+        self.attach()
+
+    def attach(self):
+        """(re)point .grad at the bucket; call after optimizer.zero_grad(set_to_none=True)."""
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def zero(self):
+        self.flat.zero_()
+        self.attach()
+
+    def all_reduce_mean(self):
+        """sum over ranks, then 1/world.  No-op in a single process."""
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.mul_(1.0 / dist.get_world_size())
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0):
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        for p in module.parameters():
+            dist.broadcast(p.data, src=src)
+
+
+def shard_rows(n_rows: int, rank: int, world: int):
+    """Equal contiguous shards (the caller keeps n_rows divisible by world so that loss means stay exact)."""
+    per = n_rows // world
+    return slice(rank * per, (rank + 1) * per)

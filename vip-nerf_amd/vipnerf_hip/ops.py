@@ -36,8 +36,9 @@ def f32c(t: torch.Tensor) -> torch.Tensor:
 
 
 def make_config(ndc, n_coarse, n_fine, n_sec, train, noise_std=0.0, lindisp=False, white_bkgd=False,
-                save_acts=False) -> L.Config:
+                save_acts=False, perturb=None) -> L.Config:
     c = L.Config()
+    c.perturb = int(bool(train if perturb is None else perturb))
     c.ndc, c.n_coarse, c.n_fine, c.n_sec = int(bool(ndc)), int(n_coarse), int(n_fine), int(n_sec)
     c.train, c.lindisp, c.white_bkgd, c.save_acts = int(bool(train)), int(bool(lindisp)), int(bool(white_bkgd)), int(bool(save_acts))
     c.noise_std = float(noise_std)
@@ -231,6 +232,8 @@ def mlp_forward(packed, pts, view_dirs, view_dirs2=None, noise=None, noise_std=1
     e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
     sigma, rgb, vis = e(P), e(P, 3), e(P)
     vis2 = e(P, V) if V > 0 else None
+    if P == 0:
+        return {'sigma': sigma, 'rgb': rgb, 'visibility': vis, 'visibility2': vis2}
     L.check(L.load().vipnerf_mlp_forward(P, V, _p(pts), _p(vd), _p(vd2), _p(nz), float(noise_std), _p(packed),
                                          _p(sigma), _p(rgb), _p(vis), _p(vis2), _stream()), 'vipnerf_mlp_forward')
     return {'sigma': sigma, 'rgb': rgb, 'visibility': vis, 'visibility2': vis2}
@@ -289,3 +292,16 @@ def losses_forward(cfg: L.Config, n_rays, target_rgb, mask_nerf, prior, mask_spa
     L.check(L.load().vipnerf_losses_forward(C.byref(cfg), n_rays, C.byref(li), C.byref(out), C.byref(lo), _stream()),
             'vipnerf_losses_forward')
     return vals, seeds[0], seeds[1]
+
+
+# ------------------------------------------------------------------------------------------------ measurement
+def profile_enable(on: bool):
+    L.check(L.load().vipnerf_profile_enable(int(on)), 'vipnerf_profile_enable')
+
+
+def profile_read() -> Dict[str, tuple]:
+    """-> {stage name: (launch count, total ms)} since the last read (waits for the recorded events)."""
+    arr = (L.ProfileEntry * 32)()
+    n = C.c_int32(0)
+    L.check(L.load().vipnerf_profile_read(arr, 32, C.byref(n)), 'vipnerf_profile_read')
+    return {arr[i].name.decode(): (arr[i].count, arr[i].total_ms) for i in range(n.value)}

@@ -45,25 +45,34 @@ __host__ __device__ inline int feat_of(int r, int h) {
 // ----------------------------------------------------------------------------------------------- packed image
 // One chunk = the A operands of 4 consecutive k-steps for one 32-row tile: 64 lanes x float4 = 1 KiB.
 constexpr int CHUNK_F = 256;                    // floats per chunk
-constexpr int STAGE_CHUNKS = 32;
-constexpr int STAGE_F = CHUNK_F * STAGE_CHUNKS; // 8192 floats = 32 KiB
+#ifndef VN_STAGE_CHUNKS
+#define VN_STAGE_CHUNKS 64
+#endif
+constexpr int STAGE_CHUNKS = VN_STAGE_CHUNKS;   // 64 KiB stages: half the workgroup barriers of 32 KiB ones
+constexpr int STAGE_F = CHUNK_F * STAGE_CHUNKS;
+constexpr int KGS8 = STAGE_CHUNKS / 8;          // kgroups per stage when a stage spans 8 row tiles
+constexpr int KGS4 = STAGE_CHUNKS / 4;          // ... 4 row tiles (view layer forward)
+constexpr int ST_256 = 32 / KGS8;               // stages of a 256-wide contraction over 8 tiles
+constexpr int ST_PE = 8 / KGS8;                 // gamma(x): K = 64 -> 8 kgroups
+constexpr int ST_VIEW_F = 32 / KGS4;            // view layer forward: 4 tiles x 32 kgroups
+constexpr int ST_VIEW_B = 16 / KGS8;            // view layer dgrad: 8 tiles x 16 kgroups
 
 // forward stream, in consumption order (stage indices)
-constexpr int FS_L0PE = 0;          // 2 stages: 8 tiles x 8 kgroups (K = 64: gamma(x))
-constexpr int FS_L1 = 2;            // 8 stages each for L1..L4
-constexpr int FS_L5PE = 34;         // 2 stages
-constexpr int FS_L5 = 36;           // 8 stages
-constexpr int FS_L6 = 44;
-constexpr int FS_L7 = 52;
-constexpr int FS_FEAT = 60;         // feature_linear
-constexpr int FS_VIEW = 68;         // views_linears[0][:, 0:256]: 4 tiles x 32 kgroups = 4 stages
-constexpr int F_STAGES = 72;
+constexpr int FS_L0PE = 0;                      // 8 tiles x 8 kgroups (K = 64: gamma(x))
+constexpr int FS_L1 = FS_L0PE + ST_PE;          // L1..L4
+constexpr int FS_L5PE = FS_L1 + 4 * ST_256;
+constexpr int FS_L5 = FS_L5PE + ST_PE;
+constexpr int FS_L6 = FS_L5 + ST_256;
+constexpr int FS_L7 = FS_L6 + ST_256;
+constexpr int FS_FEAT = FS_L7 + ST_256;         // feature_linear
+constexpr int FS_VIEW = FS_FEAT + ST_256;       // views_linears[0][:, 0:256]
+constexpr int F_STAGES = FS_VIEW + ST_VIEW_F;
 
 // backward (dgrad) stream: A = W^T
-constexpr int BS_VIEW = 0;          // 4 stages: 8 tiles(k) x 16 kgroups(o in 128)
-constexpr int BS_FEAT = 4;          // 8 stages
-constexpr int BS_L7 = 12;           // then L6, L5 (h part), L4, L3, L2, L1: 8 stages each
-constexpr int B_STAGES = 68;
+constexpr int BS_VIEW = 0;                      // 8 tiles(k) x 16 kgroups(o in 128)
+constexpr int BS_FEAT = BS_VIEW + ST_VIEW_B;
+constexpr int BS_L7 = BS_FEAT + ST_256;         // then L6, L5 (h part), L4, L3, L2, L1
+constexpr int B_STAGES = BS_L7 + 7 * ST_256;
 
 // LDS-resident block (floats)
 constexpr int R_DIRW = 0;                       // 4 kgroups x 4 tiles chunks: views_linears[0][:, 256:283]
@@ -91,6 +100,7 @@ __host__ __device__ inline int layer_in_dim(int i) { return i == 0 ? DPE : (i ==
 // Activation store of one level (floats).  P = points of the level.
 struct ActLayout {
     size_t h[D];      // [P][256] output of pts_linears[i] (post ReLU)
+    size_t hm[D];     // [P][2][4] uint32: ReLU masks of the same, one bit per feature in C/D-fragment order
     size_t feat;      // [P][256]
     size_t g[1 + VIPNERF_MAX_SEC];    // [P][128] view-branch hidden (post ReLU), per direction
     size_t pex;       // [P][64]  gamma(x), zero padded
@@ -100,6 +110,7 @@ struct ActLayout {
 __host__ __device__ inline ActLayout act_layout(size_t P, int V) {
     ActLayout a; size_t o = 0;
     for (int i = 0; i < D; ++i) { a.h[i] = o; o += P * W; }
+    for (int i = 0; i < D; ++i) { a.hm[i] = o; o += P * 8; }
     a.feat = o; o += P * W;
     for (int k = 0; k <= VIPNERF_MAX_SEC; ++k) { a.g[k] = o; if (k <= V) o += P * WV; }
     a.pex = o; o += P * DPE_PAD;

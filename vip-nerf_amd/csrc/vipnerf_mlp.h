@@ -67,10 +67,11 @@ struct WStream {
     int lane, wave;
 
     __device__ __forceinline__ void fetch(int b) {
-        const float *src = g + (wave * 8) * CHUNK_F + lane * 4;
-        float *dst = buf + b * STAGE_F + (wave * 8) * CHUNK_F;
+        constexpr int PER_WAVE = STAGE_CHUNKS / 4;
+        const float *src = g + (wave * PER_WAVE) * CHUNK_F + lane * 4;
+        float *dst = buf + b * STAGE_F + (wave * PER_WAVE) * CHUNK_F;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < PER_WAVE; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * CHUNK_F),
                                              (__attribute__((address_space(3))) void *)(dst + i * CHUNK_F), 16, 0, 0);
         g += STAGE_F;
@@ -82,7 +83,13 @@ struct WStream {
     }
     // returns the LDS address of the stage to consume now
     __device__ __forceinline__ const float *next() {
+#if defined(VN_EXP) && VN_EXP == 3
+        if (n_left & 1) __syncthreads();          // timing experiment only (races): half the barriers
+#elif defined(VN_EXP) && VN_EXP == 4
+        if (n_left == 1000) __syncthreads();      // timing experiment only (races): no barriers
+#else
         __syncthreads();
+#endif
         const float *ret = buf + cur * STAGE_F;
         cur ^= 1;
         if (n_left > 0) fetch(cur);
@@ -200,6 +207,40 @@ __device__ __forceinline__ void store_frag(float *base, int64_t p, int ld, int h
         for (int q = 0; q < 4; ++q)
             *(float4 *)(row + 32 * t + 8 * q) = make_float4(v[t][4 * q], v[t][4 * q + 1], v[t][4 * q + 2], v[t][4 * q + 3]);
 }
+// one 32-feature tile of a fragment (4 x 16 B per lane)
+__device__ __forceinline__ void store_tile(float *base, int64_t p, int ld, int h, int t, const floatx16 &v, bool valid) {
+    if (!valid) return;
+#if defined(VN_EXP) && VN_EXP == 1
+    return;                                   // experiment: no activation stores at all
+#endif
+    float *row = base + (size_t)p * ld + 4 * h + 32 * t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#if defined(VN_EXP) && VN_EXP == 2
+        *(float4 *)(row + 8 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+#else
+        // non-temporal: the activation / dY store is written once and next read by wgrad ~10 ms (11 GB) later,
+        // so it should not displace the L2-resident weight stream (measured: -0.4 ms per step vs plain stores)
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 val = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        __builtin_nontemporal_store(val, (f4 *)(row + 8 * q));
+#endif
+    }
+}
+// ReLU mask of a fragment: bit (16*(t&1) + r) of word t>>1 <=> v[t][r] > 0
+__device__ __forceinline__ uint4 frag_mask(const floatx16 (&v)[8]) {
+    unsigned m[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m[t >> 1] |= (v[t][r] > 0.f ? 1u : 0u) << (16 * (t & 1) + r);
+    return make_uint4(m[0], m[1], m[2], m[3]);
+}
+__device__ __forceinline__ bool mask_bit(const uint4 &m, int t, int r) {
+    const unsigned w = (t >> 1) == 0 ? m.x : ((t >> 1) == 1 ? m.y : ((t >> 1) == 2 ? m.z : m.w));
+    return (w >> (16 * (t & 1) + r)) & 1u;
+}
+
 template <int NT>
 __device__ __forceinline__ void load_frag(const float *base, int64_t p, int ld, int h, floatx16 (&v)[NT]) {
     const float *row = base + (size_t)p * ld + 4 * h;

@@ -95,23 +95,30 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_bwd(MlpBwdArgs a) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = (floatx16)(0.f);
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
+    for (int jj = 0; jj < ST_VIEW_B; ++jj) {
         const float *st = ws.next();
-        VN_GEMM_STAGE(st, 8, 4, 4 * jj, acc, vsum[r_ >> 4][r_ & 15])
+        VN_GEMM_STAGE(st, 8, KGS8, KGS8 * jj, acc, vsum[r_ >> 4][r_ & 15])
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) in[t] = acc[t];
-    store_frag<8>(a.bwd + a.bl.dyf, p, W, h, in, valid);
 
     // ---------------------------------------------------------------- feature layer, then layers 7..1
 #pragma unroll 1
     for (int it = 0; it < 8; ++it) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc[t] = (floatx16)(0.f);
+        // ReLU mask of the layer this GEMM lands on: 16 B per lane, fetched under the GEMM
+        const int layer = 7 - it;
+        const uint4 mk = *(const uint4 *)(a.acts + a.al.hm[layer] + ((size_t)p * 2 + h) * 4);
+        float *dy_dst = a.bwd + (it == 0 ? a.bl.dyf : a.bl.dy[8 - it]);
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
+        for (int jj = 0; jj < ST_256; ++jj) {
             const float *st = ws.next();
-            VN_GEMM_STAGE(st, 8, 4, 4 * jj, acc, in[r_ >> 4][r_ & 15])
+            // this GEMM's B operand (a dY) is also what wgrad needs: stored one tile per stage, ahead of the MFMAs
+#pragma unroll
+            for (int tt = 0; tt < 8 / ST_256; ++tt) store_tile(dy_dst, p, W, h, jj * (8 / ST_256) + tt, in[jj * (8 / ST_256) + tt], valid);
+            __builtin_amdgcn_sched_barrier(0);
+            VN_GEMM_STAGE(st, 8, KGS8, KGS8 * jj, acc, in[r_ >> 4][r_ & 15])
         }
         if (it == 0) {                                   // h_8 also feeds the sigma head
             const float *wsg = res + R_WSIG + h * 128;
@@ -127,20 +134,12 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_bwd(MlpBwdArgs a) {
                 }
         }
         // acc = dLoss/d(output of layer 7-it); through its ReLU -> dY of that layer
-        const int layer = 7 - it;
-        const float *hrow = a.acts + a.al.h[layer] + (size_t)p * W + 4 * h;
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 hv = *(const float4 *)(hrow + 32 * t + 8 * q);
-                in[t][4 * q] = hv.x > 0.f ? acc[t][4 * q] : 0.f;
-                in[t][4 * q + 1] = hv.y > 0.f ? acc[t][4 * q + 1] : 0.f;
-                in[t][4 * q + 2] = hv.z > 0.f ? acc[t][4 * q + 2] : 0.f;
-                in[t][4 * q + 3] = hv.w > 0.f ? acc[t][4 * q + 3] : 0.f;
-            }
-        store_frag<8>(a.bwd + a.bl.dy[layer], p, W, h, in, valid);
+            for (int r = 0; r < 16; ++r) in[t][r] = mask_bit(mk, t, r) ? acc[t][r] : 0.f;
     }
+    store_frag<8>(a.bwd + a.bl.dy[0], p, W, h, in, valid);     // dY of layer 0 has no further GEMM to hide under
 }
 
 int launch_mlp_bwd(const MlpBwdArgs &a, hipStream_t st) {

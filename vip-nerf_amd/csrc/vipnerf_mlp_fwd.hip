@@ -58,16 +58,25 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_fwd(MlpFwdArgs a) {
 
         if (layer == 0 || layer == SKIP_LAYER) {
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
+            for (int jj = 0; jj < ST_PE; ++jj) {
                 const float *st = ws.next();
-                VN_GEMM_STAGE(st, 8, 4, 4 * jj, acc, pe[r_])
+                VN_GEMM_STAGE(st, 8, KGS8, KGS8 * jj, acc, pe[r_])
             }
         }
         if (layer != 0) {
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
+            for (int jj = 0; jj < ST_256; ++jj) {
                 const float *st = ws.next();
-                VN_GEMM_STAGE(st, 8, 4, 4 * jj, acc, in[r_ >> 4][r_ & 15])
+                if (SAVE) {
+                    // the previous layer's output (this layer's B operand) goes to the activation store one tile per
+                    // stage, issued BEFORE the stage's MFMAs: the stores then have a whole stage (>= 8192 cycles) to
+                    // retire before the next barrier's vmcnt(0), instead of a 32 KB burst draining in front of it
+#pragma unroll
+                    for (int tt = 0; tt < 8 / ST_256; ++tt)
+                        store_tile(a.acts + a.al.h[layer - 1], p, W, h, jj * (8 / ST_256) + tt, in[jj * (8 / ST_256) + tt], valid);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                VN_GEMM_STAGE(st, 8, KGS8, KGS8 * jj, acc, in[r_ >> 4][r_ & 15])
             }
         }
         if (layer < 8) {
@@ -75,7 +84,7 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_fwd(MlpFwdArgs a) {
             for (int t = 0; t < 8; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) in[t][r] = fmaxf(acc[t][r], 0.f);
-            if (SAVE) store_frag<8>(a.acts + a.al.h[layer], p, W, h, in, valid);
+            if (SAVE && valid) *(uint4 *)(a.acts + a.al.hm[layer] + ((size_t)p * 2 + h) * 4) = frag_mask(in);
             if (layer == 7) {   // sigma head on h_8: per-lane partial dot over its 128 features, then fold halves
                 const float *wsg = res + R_WSIG + h * 128;
                 float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -96,7 +105,6 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_fwd(MlpFwdArgs a) {
         } else {
 #pragma unroll
             for (int t = 0; t < 8; ++t) in[t] = acc[t];      // feature: no activation
-            if (SAVE) store_frag<8>(a.acts + a.al.feat, p, W, h, in, valid);
         }
     }
 
@@ -114,9 +122,15 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_fwd(MlpFwdArgs a) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) vb[t] = *(const floatx16 *)(res + R_BVIEW + t * 32 + h * 16);
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
+    for (int jj = 0; jj < ST_VIEW_F; ++jj) {
         const float *st = ws.next();
-        VN_GEMM_STAGE(st, 4, 8, 8 * jj, vb, in[r_ >> 4][r_ & 15])
+        if (SAVE) {
+#pragma unroll
+            for (int tt = 0; tt < 8 / ST_VIEW_F; ++tt)
+                store_tile(a.acts + a.al.feat, p, W, h, jj * (8 / ST_VIEW_F) + tt, in[jj * (8 / ST_VIEW_F) + tt], valid);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        VN_GEMM_STAGE(st, 4, KGS4, KGS4 * jj, vb, in[r_ >> 4][r_ & 15])
     }
 
     for (int dsel = 0; dsel <= a.src.V; ++dsel) {

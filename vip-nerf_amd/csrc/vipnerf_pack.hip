@@ -27,14 +27,14 @@ __global__ void k_pack(PackArgs a) {
                 const int layer = s < FS_L1 ? 0 : SKIP_LAYER;
                 const int j = s < FS_L1 ? s - FS_L0PE : s - FS_L5PE;
                 const int gl = c >> 3, t = c & 7;
-                const int k = 2 * (4 * (4 * j + gl) + q) + h;
+                const int k = 2 * (4 * (KGS8 * j + gl) + q) + h;
                 const int o = 32 * t + l31;
                 v = k < DPE ? layer_w(a.p, layer)[(size_t)o * layer_in_dim(layer) + k] : 0.f;
             } else if (s < FS_VIEW) {                                           // 256-wide register-sourced layers
                 int layer, j;
                 const float *wp;
                 int ld, koff = 0;
-                if (s < FS_L5PE) { layer = 1 + (s - FS_L1) / 8; j = (s - FS_L1) % 8; }
+                if (s < FS_L5PE) { layer = 1 + (s - FS_L1) / ST_256; j = (s - FS_L1) % ST_256; }
                 else if (s < FS_L6) { layer = 5; j = s - FS_L5; koff = DPE; }
                 else if (s < FS_L7) { layer = 6; j = s - FS_L6; }
                 else if (s < FS_FEAT) { layer = 7; j = s - FS_L7; }
@@ -42,27 +42,27 @@ __global__ void k_pack(PackArgs a) {
                 if (layer < 8) { wp = layer_w(a.p, layer); ld = layer_in_dim(layer); }
                 else { wp = a.p.p[P_FW]; ld = W; }
                 const int gl = c >> 3, t = c & 7;
-                const int r = 4 * (4 * j + gl) + q;
+                const int r = 4 * (KGS8 * j + gl) + q;
                 v = wp[(size_t)(32 * t + l31) * ld + koff + feat_of(r, h)];
             } else {                                                            // view layer, feature columns
                 const int j = s - FS_VIEW;
                 const int gl = c >> 2, t = c & 3;
-                const int r = 4 * (8 * j + gl) + q;
+                const int r = 4 * (KGS4 * j + gl) + q;
                 v = a.p.p[P_VW][(size_t)(32 * t + l31) * (W + DVE) + feat_of(r, h)];
             }
         } else {
             const int gl = c >> 3, t = c & 7;
             const int k = 32 * t + l31;                                         // dgrad output row = input feature
             if (s < BS_FEAT) {
-                const int r = 4 * (4 * s + gl) + q;                             // r < 64 -> o < 128
+                const int r = 4 * (KGS8 * s + gl) + q;                          // r < 64 -> o < 128
                 v = a.p.p[P_VW][(size_t)feat_of(r, h) * (W + DVE) + k];
             } else if (s < BS_L7) {
-                const int r = 4 * (4 * (s - BS_FEAT) + gl) + q;
+                const int r = 4 * (KGS8 * (s - BS_FEAT) + gl) + q;
                 v = a.p.p[P_FW][(size_t)feat_of(r, h) * W + k];
             } else {
-                const int layer = 7 - (s - BS_L7) / 8;
-                const int j = (s - BS_L7) % 8;
-                const int r = 4 * (4 * j + gl) + q;
+                const int layer = 7 - (s - BS_L7) / ST_256;
+                const int j = (s - BS_L7) % ST_256;
+                const int r = 4 * (KGS8 * j + gl) + q;
                 const int koff = layer == SKIP_LAYER ? DPE : 0;
                 v = layer_w(a.p, layer)[(size_t)feat_of(r, h) * layer_in_dim(layer) + koff + k];
             }

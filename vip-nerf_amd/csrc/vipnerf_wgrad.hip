@@ -75,8 +75,20 @@ __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
     }
 
     float4 ra[MT], rb[KT];
+    // whole-tile-contiguous operands (row stride == padded width, all columns valid) are a linear 16 B/lane copy
+    const bool linA = d.lda == Mp && d.m_load == Mp, linB = d.ldb == Kp && d.k_load == Kp;
     auto gload = [&](int blk) {
         const int64_t pb = p0 + (int64_t)blk * 32;
+        const bool inrange = pb + 32 <= p1;
+        if (inrange && linA && linB) {
+            const float4 *ta = (const float4 *)(d.A + (size_t)pb * Mp) + tid;
+            const float4 *tb = (const float4 *)(d.B + (size_t)pb * Kp) + tid;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) ra[i] = ta[256 * i];
+#pragma unroll
+            for (int i = 0; i < KT; ++i) rb[i] = tb[256 * i];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int idx = tid + 256 * i, row = idx / (8 * MT), col = 4 * (idx % (8 * MT));

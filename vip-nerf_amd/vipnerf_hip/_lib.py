@@ -11,7 +11,7 @@ VIPNERF_N_PARAMS = 24
 ABI_VERSION = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libvipnerf_hip.so')
+LIB_PATH = os.environ.get('VIPNERF_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libvipnerf_hip.so')
 
 c_f = C.c_void_p   # device pointers travel as plain addresses
 

@@ -138,16 +138,28 @@ __host__ __device__ inline int wgrad_chunks(size_t P) {
     size_t c = (P + WGRAD_CHUNK_PTS - 1) / WGRAD_CHUNK_PTS;
     return (int)(c < 1 ? 1 : (c > WGRAD_MAX_CHUNKS ? WGRAD_MAX_CHUNKS : c));
 }
-// floats of partial output per chunk: sum over GEMMs of Mp*Kp (+ Mp for the bias column sums)
-__host__ __device__ inline size_t wgrad_partial_per_chunk(int V) {
-    size_t f = 0;
-    f += 2 * (size_t)(256 * 64 + 256);          // layer 0, layer 5 gamma(x) part
-    f += 8 * (size_t)(256 * 256 + 256);         // layers 1-4, 5(h part), 6, 7, feature
-    f += (size_t)(32 * 256 + 32);               // sigma head
-    f += (size_t)(128 * 256 + 128);             // view layer, feature columns
-    f += (size_t)(1 + V) * (128 * 32 + 128);    // view layer, direction columns (per direction)
-    f += (size_t)(1 + V) * (32 * 128 + 32);     // output head (per direction)
-    return f;
+// The eight 256x256 GEMMs use 4096-point chunks; the small GEMMs (few MFMAs per point) use chunks 4x shorter so
+// that their single-GEMM launches still fill the chip.
+constexpr int WGRAD_SMALL_SPLIT = 4;
+__host__ __device__ inline int wgrad_chunk_pts(size_t P) {            // multiple of 32 * WGRAD_SMALL_SPLIT
+    const int n = wgrad_chunks(P);
+    const size_t c = (P + n - 1) / n, q = 32 * WGRAD_SMALL_SPLIT;
+    return (int)((c + q - 1) / q * q);
+}
+__host__ __device__ inline int wgrad_chunks_small(size_t P) {
+    const size_t c = wgrad_chunk_pts(P) / WGRAD_SMALL_SPLIT;
+    return (int)((P + c - 1) / c);
+}
+// floats of partial output: sum over GEMMs of chunks * (Mp*Kp + Mp)   (Mp for the bias column sums)
+__host__ __device__ inline size_t wgrad_partial_total(size_t P, int V) {
+    size_t big = 8 * (size_t)(256 * 256 + 256);     // layers 1-4, 5(h part), 6, 7, feature
+    size_t sm = 0;
+    sm += 2 * (size_t)(256 * 64 + 256);             // layer 0, layer 5 gamma(x) part
+    sm += (size_t)(32 * 256 + 32);                  // sigma head
+    sm += (size_t)(128 * 256 + 128);                // view layer, feature columns
+    sm += (size_t)(1 + V) * (128 * 32 + 128);       // view layer, direction columns (per direction)
+    sm += (size_t)(1 + V) * (32 * 128 + 32);        // output head (per direction)
+    return (size_t)wgrad_chunks(P) * big + (size_t)wgrad_chunks_small(P) * sm;
 }
 __host__ __device__ inline BwdLayout bwd_layout(size_t P, int V) {
     BwdLayout b; size_t o = 0;
@@ -161,7 +173,7 @@ __host__ __device__ inline BwdLayout bwd_layout(size_t P, int V) {
     b.dvis = o; o += P;
     b.dvis2 = o; o += P * (V > 0 ? V : 1);
     o = (o + 63) & ~(size_t)63;
-    b.partial = o; o += (size_t)wgrad_chunks(P) * wgrad_partial_per_chunk(V);
+    b.partial = o; o += wgrad_partial_total(P, V);
     b.total = o;
     return b;
 }

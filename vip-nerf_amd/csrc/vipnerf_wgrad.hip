@@ -18,6 +18,7 @@ struct WgDesc {
     const float *A; int lda; int m_load;      // A[p][0..m_load) is read (m_load multiple of 4), zero beyond
     const float *B; int ldb; int k_load;
     size_t part_off;                          // float offset of this GEMM's partials (chunk 0)
+    int n_chunks;                             // chunks of this GEMM (workgroups beyond it exit)
     size_t part_stride;                       // floats per chunk: Mp*Kp + Mp
 };
 constexpr int WG_MAX_DESC = 12;
@@ -33,14 +34,13 @@ struct WgGroup {
     size_t part_off, part_stride;             // of the group's first GEMM
     int n_desc;                               // GEMMs summed into this output (consecutive, same shape)
     size_t desc_stride;                       // float distance between consecutive GEMMs' partial blocks
-    int Mp, Kp, m_valid, k_valid;
+    int Mp, Kp, m_valid, k_valid, n_chunks;
     float *dW; int ldw; int col_off;
     float *dbias;                             // NULL = no bias output
 };
 constexpr int WG_MAX_GROUP = 24;
 struct WgReduceArgs {
     WgGroup g[WG_MAX_GROUP];
-    int n_chunks;
     const float *partial;
 };
 
@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const WgDesc &d = a.d[blockIdx.y];
+    if ((int)blockIdx.x >= d.n_chunks) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l31 = lane & 31;
     const int wm = wave % WAVES_M, wk = wave / WAVES_M;
@@ -175,7 +176,7 @@ __global__ void k_wgrad_reduce(WgReduceArgs a) {
         float s = 0.f;
         for (int dd = 0; dd < g.n_desc; ++dd) {
             const float *pp = a.partial + g.part_off + (size_t)dd * g.desc_stride + off;
-            for (int c = 0; c < a.n_chunks; ++c) s += pp[(size_t)c * g.part_stride];
+            for (int c = 0; c < g.n_chunks; ++c) s += pp[(size_t)c * g.part_stride];
         }
         *dst = s;
     }
@@ -195,17 +196,16 @@ static int launch_class(const WgArgs &args, int n_desc, int n_chunks, hipStream_
 int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float *bwd, const BwdLayout &bl,
                  const vipnerf_mlp_grads *G, hipStream_t st) {
     if (P == 0) return VIPNERF_OK;
-    const int n_chunks = wgrad_chunks(P);
-    const int chunk_pts = (int)(((P + n_chunks - 1) / n_chunks + 31) / 32 * 32);
+    const int n_chunks = wgrad_chunks(P), n_small = wgrad_chunks_small(P);
+    const int chunk_pts = wgrad_chunk_pts(P), chunk_small = chunk_pts / WGRAD_SMALL_SPLIT;
     float *partial = bwd + bl.partial;
 
     WgArgs c88, c82, c48, c41, c18, c14;       // classes by (M tiles, K tiles)
     WgReduceArgs red;
     int n88 = 0, n82 = 0, n48 = 0, n41 = 0, n18 = 0, n14 = 0, ng = 0;
     size_t off = 0;
-    auto init = [&](WgArgs &w) { w.P = (int64_t)P; w.chunk_pts = chunk_pts; w.partial = partial; };
-    init(c88); init(c82); init(c48); init(c41); init(c18); init(c14);
-    red.n_chunks = n_chunks;
+    auto init = [&](WgArgs &w, int cp) { w.P = (int64_t)P; w.chunk_pts = cp; w.partial = partial; };
+    init(c88, chunk_pts); init(c82, chunk_small); init(c48, chunk_small); init(c41, chunk_small); init(c18, chunk_small); init(c14, chunk_small);
     red.partial = partial;
 
     // adds one GEMM; returns its partial offset
@@ -213,14 +213,16 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
         WgDesc &d = w.d[n++];
         d.A = A; d.lda = lda; d.m_load = m_load; d.B = B; d.ldb = ldb; d.k_load = k_load;
         d.part_off = off; d.part_stride = (size_t)Mp * Kp + Mp;
+        d.n_chunks = (&w == &c88) ? n_chunks : n_small;
         const size_t o = off;
-        off += (size_t)n_chunks * d.part_stride;
+        off += (size_t)d.n_chunks * d.part_stride;
         return o;
     };
-    auto group = [&](size_t part_off, int n_desc, int Mp, int Kp, int m_valid, int k_valid, float *dW, int ldw, int col_off, float *dbias) {
+    auto group = [&](bool big, size_t part_off, int n_desc, int Mp, int Kp, int m_valid, int k_valid, float *dW, int ldw, int col_off, float *dbias) {
         WgGroup &g = red.g[ng++];
         g.part_off = part_off; g.part_stride = (size_t)Mp * Kp + Mp; g.n_desc = n_desc;
-        g.desc_stride = (size_t)n_chunks * g.part_stride;
+        g.n_chunks = big ? n_chunks : n_small;
+        g.desc_stride = (size_t)g.n_chunks * g.part_stride;
         g.Mp = Mp; g.Kp = Kp; g.m_valid = m_valid; g.k_valid = k_valid; g.dW = dW; g.ldw = ldw; g.col_off = col_off; g.dbias = dbias;
     };
     const float *pex = acts + al.pex;
@@ -230,28 +232,28 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
         float *dW = G->g[2 * i], *db = G->g[2 * i + 1];
         if (i == 0) {
             const size_t o = add(c82, n82, 256, 64, dy, W, W, pex, DPE_PAD, DPE_PAD);
-            group(o, 1, 256, 64, W, DPE, dW, DPE, 0, db);
+            group(false, o, 1, 256, 64, W, DPE, dW, DPE, 0, db);
         } else if (i == SKIP_LAYER) {
             const size_t o1 = add(c82, n82, 256, 64, dy, W, W, pex, DPE_PAD, DPE_PAD);
-            group(o1, 1, 256, 64, W, DPE, dW, W + DPE, 0, nullptr);
+            group(false, o1, 1, 256, 64, W, DPE, dW, W + DPE, 0, nullptr);
             const size_t o2 = add(c88, n88, 256, 256, dy, W, W, acts + al.h[i - 1], W, W);
-            group(o2, 1, 256, 256, W, W, dW, W + DPE, DPE, db);
+            group(true, o2, 1, 256, 256, W, W, dW, W + DPE, DPE, db);
         } else {
             const size_t o = add(c88, n88, 256, 256, dy, W, W, acts + al.h[i - 1], W, W);
-            group(o, 1, 256, 256, W, W, dW, W, 0, db);
+            group(true, o, 1, 256, 256, W, W, dW, W, 0, db);
         }
     }
     {   // feature_linear
         const size_t o = add(c88, n88, 256, 256, bwd + bl.dyf, W, W, acts + al.h[D - 1], W, W);
-        group(o, 1, 256, 256, W, W, G->g[P_FW], W, 0, G->g[P_FB]);
+        group(true, o, 1, 256, 256, W, W, G->g[P_FW], W, 0, G->g[P_FB]);
     }
     {   // sigma head: A = column 4 of DQ[0]
         const size_t o = add(c18, n18, 32, 256, bwd + bl.dq[0] + 4, 8, 4, acts + al.h[D - 1], W, W);
-        group(o, 1, 32, 256, 1, W, G->g[P_SW], W, 0, G->g[P_SB]);
+        group(false, o, 1, 32, 256, 1, W, G->g[P_SW], W, 0, G->g[P_SB]);
     }
     {   // view layer, feature columns: A = sum over directions
         const size_t o = add(c48, n48, 128, 256, bwd + bl.dyvsum, WV, WV, acts + al.feat, W, W);
-        group(o, 1, 128, 256, WV, W, G->g[P_VW], W + DVE, 0, G->g[P_VB]);
+        group(false, o, 1, 128, 256, WV, W, G->g[P_VW], W + DVE, 0, G->g[P_VB]);
     }
     {   // view layer, direction columns: one GEMM per direction, summed in order
         size_t first = 0;
@@ -259,7 +261,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
             const size_t o = add(c41, n41, 128, 32, bwd + bl.dyv[k], WV, WV, acts + al.ped[k], DVE_PAD, DVE_PAD);
             if (k == 0) first = o;
         }
-        group(first, 1 + V, 128, 32, WV, DVE, G->g[P_VW], W + DVE, W, nullptr);
+        group(false, first, 1 + V, 128, 32, WV, DVE, G->g[P_VW], W + DVE, W, nullptr);
     }
     {   // output head: A = DQ[k][:, 0:4], B = view hidden of direction k
         size_t first = 0;
@@ -267,9 +269,9 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
             const size_t o = add(c14, n14, 32, 128, bwd + bl.dq[k], 8, 4, acts + al.g[k], WV, WV);
             if (k == 0) first = o;
         }
-        group(first, 1 + V, 32, 128, 4, WV, G->g[P_OW], WV, 0, G->g[P_OB]);
+        group(false, first, 1 + V, 32, 128, 4, WV, G->g[P_OW], WV, 0, G->g[P_OB]);
     }
-    if (off > (size_t)n_chunks * wgrad_partial_per_chunk(V)) { set_error("wgrad: partial buffer plan mismatch"); return VIPNERF_E_ARG; }
+    if (off != wgrad_partial_total(P, V)) { set_error("wgrad: partial buffer plan mismatch"); return VIPNERF_E_ARG; }
 
     int rc;
     {
@@ -277,12 +279,12 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
         if ((rc = launch_class<2, 8, 4>(c88, n88, n_chunks, st))) return rc;
     }
     ProfScope ps("wgrad_small", st);
-    if ((rc = launch_class<1, 8, 4>(c48, n48, n_chunks, st))) return rc;
-    if ((rc = launch_class<2, 2, 4>(c82, n82, n_chunks, st))) return rc;
-    if ((rc = launch_class<1, 1, 4>(c41, n41, n_chunks, st))) return rc;
-    if ((rc = launch_class<1, 2, 1>(c18, n18, n_chunks, st))) return rc;
-    if ((rc = launch_class<1, 1, 1>(c14, n14, n_chunks, st))) return rc;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(64, ng), dim3(256), 0, st, red);
+    if ((rc = launch_class<1, 8, 4>(c48, n48, n_small, st))) return rc;
+    if ((rc = launch_class<2, 2, 4>(c82, n82, n_small, st))) return rc;
+    if ((rc = launch_class<1, 1, 4>(c41, n41, n_small, st))) return rc;
+    if ((rc = launch_class<1, 2, 1>(c18, n18, n_small, st))) return rc;
+    if ((rc = launch_class<1, 1, 1>(c14, n14, n_small, st))) return rc;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(256, ng), dim3(256), 0, st, red);
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;
 }

@@ -235,6 +235,53 @@ int32_t vipnerf_mlp_forward(int64_t n_points, int32_t n_sec, const float *pts, c
 int32_t vipnerf_composite(const vipnerf_config *cfg, const vipnerf_rays *rays, int32_t n_samples,
                           const vipnerf_level_out *lvl, vipnerf_stream_t stream);
 
+/* ---- callers' sides of the path (f-1 ray generation + batch gather, f-2 frame post-processing) - */
+/* One camera.  kinv = inverse of the float32 intrinsic matrix; pose = camera-to-world [3][4]; ndc_cx/cy are the
+ * float32 values of the reference's `-1. / (w / (2. * fx))`, `-1. / (h / (2. * fy))`
+ * (src/data_preprocessors/DataPreprocessor01.py:364-370). */
+typedef struct vipnerf_camera {
+    float kinv[9];
+    float pose[12];
+    float ndc_cx, ndc_cy;
+    float pad[2];
+} vipnerf_camera;
+
+typedef struct vipnerf_raygen {
+    int32_t height, width, n_frames, ndc;
+    float near, far, near_ndc, far_ndc;
+    const vipnerf_camera *cameras;   /* device array [n_frames] */
+    const int64_t *indices;          /* (N) flat ray ids  frame*H*W + y*W + x  (the reference's shuffled `indices`,
+                                        DataPreprocessor01.py:538); NULL = first_index .. first_index+N-1 */
+    int64_t first_index;
+    const float *images;             /* (n_frames,H,W,3) float32 in [0,1] or NULL: source of target_rgb */
+    const float *prior;              /* (n_frames,n_frames-1,H,W) float32 or NULL: visibility prior masks / weights */
+} vipnerf_raygen;
+
+/* The ray batch the model consumes (load_nerf_cached_batch, DataPreprocessor01.py:566-615).  Any pointer except
+ * rays_o / rays_d may be NULL. */
+typedef struct vipnerf_ray_batch {
+    float *rays_o, *rays_d, *view_dirs;        /* (N,3) */
+    float *rays_o_ndc, *rays_d_ndc;            /* (N,3) if ndc */
+    float *near, *far, *near_ndc, *far_ndc;    /* (N) */
+    int32_t *pixel_id;                         /* (N,3): frame, x, y */
+    float *target_rgb;                         /* (N,3) */
+    float *prior;                              /* (N,n_frames-1) */
+    float *rays_o2;                            /* (N,n_frames-1,3) secondary camera centres (VipNeRF01.py:88-98) */
+} vipnerf_ray_batch;
+
+/* DataPreprocessor.get_rays / get_ndc_rays / get_view_dirs (DataPreprocessor01.py:335-378) for the selected
+ * pixels + the batch gather of load_nerf_cached_batch (:566-615) and load_visibility_prior_cached_batch (:702-724),
+ * recomputed from the cameras instead of gathered from a per-scene ray cache. */
+int32_t vipnerf_generate_rays(const vipnerf_raygen *gen, int64_t n_rays, const vipnerf_ray_batch *out,
+                              vipnerf_stream_t stream);
+
+/* DataPreprocessor.retrieve_inference_outputs (DataPreprocessor01.py:866-894, :1074-1084): uint8 image
+ * (clip to [0,1], x255, round half to even) and non-negative depth maps.  Any in/out pair may be NULL. */
+int32_t vipnerf_postprocess_frame(int64_t n_pixels, const float *rgb, const float *depth, const float *depth_var,
+                                  const float *depth_ndc, const float *depth_var_ndc, uint8_t *image,
+                                  float *o_depth, float *o_depth_var, float *o_depth_ndc, float *o_depth_var_ndc,
+                                  vipnerf_stream_t stream);
+
 /* ---- measurement --------------------------------------------------------------------------------------- */
 /* Per-stage device time from HIP events recorded on the launch stream around each kernel (group) the calls
  * above queue.  Off by default.  profile_read waits for the recorded events, aggregates them by stage name

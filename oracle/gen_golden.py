@@ -304,6 +304,45 @@ def gen_f5(tag, scene, nf, n, n_sparse, seed, depth=8, width=256, n_fine=128, ps
         **{'rng_' + k: v for k, v in rng.items()}, **d)
 
 
+# ------------------------------------------------------------------------------------------------ F6
+def gen_f6():
+    """Ray generation (get_rays / get_ndc_rays / get_view_dirs) and inference post-processing of the reference's
+    DataPreprocessor, on a 2-camera 24x32 scene with generic (non-axis-aligned) poses."""
+    import types
+    from types import SimpleNamespace
+    for m in ('skimage', 'skimage.transform', 'skimage.io'):
+        sys.modules.setdefault(m, types.ModuleType(m))           # absent here; only used for optional down-scaling
+    from data_preprocessors.DataPreprocessor01 import DataPreprocessor
+    g = np.random.default_rng(61)
+    res = (24, 32)
+    K = np.array([[40.3, 0, 16.2], [0, 39.7, 11.9], [0, 0, 1.]]).astype('float32')
+    poses = []
+    for i in range(3):
+        q, _ = np.linalg.qr(g.standard_normal((3, 3)))
+        if np.linalg.det(q) < 0:
+            q[:, 0] *= -1
+        q = 0.15 * q + 0.85 * np.eye(3)                             # mostly forward-facing so that d_z stays away from 0
+        u, _, vt = np.linalg.svd(q)
+        p = np.eye(4)
+        p[:3, :3] = u @ vt
+        p[:3, 3] = g.uniform(-0.3, 0.3, 3)
+        poses.append(p.astype('float32'))
+    poses = np.stack(poses)
+    out = {'resolution': np.array(res), 'intrinsic': K, 'poses': poses, 'near': 1.0}
+    stub = SimpleNamespace(mip_nerf_used=False)
+    for i in range(3):
+        o, d = DataPreprocessor.get_rays(stub, res, K, poses[i])
+        vd = DataPreprocessor.get_view_dirs(d)
+        on, dn = DataPreprocessor.get_ndc_rays(o, d, res, K, 1.0)
+        out.update({f'rays_o_{i}': o, f'rays_d_{i}': d, f'view_dirs_{i}': vd, f'rays_o_ndc_{i}': on, f'rays_d_ndc_{i}': dn})
+    rgb = g.uniform(-0.2, 1.2, size=(res[0] * res[1], 3)).astype('float32')
+    rgb[:16] = (np.arange(48).reshape(16, 3).astype('float32') + 0.5) / 255          # exact .5 ties: round half to even
+    depth = g.uniform(-1, 5, size=(res[0] * res[1],)).astype('float32')
+    out.update(pp_rgb=rgb, pp_depth=depth, pp_image=DataPreprocessor.post_process_image(rgb.reshape(res[0], res[1], 3)),
+               pp_depth_out=DataPreprocessor.post_process_depth(depth.reshape(res)))
+    npz('f6_raygen', **out)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     gen_f1()
@@ -314,3 +353,4 @@ if __name__ == '__main__':
     gen_f5('realestate', 'realestate', 3, 16, 16, 510)
     gen_f5('dtu', 'dtu', 3, 24, 0, 520)
     gen_f5('toy', 'toy', 2, 64, 0, 530, depth=4, width=64, n_fine=0, pscale=1.0)
+    gen_f6()

@@ -1,0 +1,109 @@
+"""SURVEY.md §8f rows f-1 / f-2 on the GPU: ray generation + batch gather and frame post-processing through the C
+ABI, against the golden vectors of the reference's DataPreprocessor (bit-exact) and the CPU oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+sys.path.insert(0, os.path.join(ROOT, 'vip-nerf_amd', 'src'))
+
+from oracle import raygen_oracle as ro  # noqa: E402
+from oracle import vipnerf_oracle as vo  # noqa: E402
+
+
+def load(name):
+    return {k: v for k, v in np.load(os.path.join(GOLD, name + '.npz')).items()}
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def make_gen(g, dev, images=None, prior=None, ndc=True):
+    from data_preprocessors.RayGeneratorHip01 import RayGeneratorHip
+    res = tuple(int(v) for v in g['resolution'])
+    return RayGeneratorHip(res, g['intrinsic'][None], g['poses'], float(g['near']), 6.0, ndc, dev, images=images, visibility_prior=prior), res
+
+
+def test_ray_generation_bit_exact(dev):
+    g = load('f6_raygen')
+    gen, res = make_gen(g, dev)
+    for i in range(3):
+        b = gen.create_test_data(i, secondary=True)
+        for hk, gk in (('rays_o', 'rays_o'), ('rays_d', 'rays_d'), ('view_dirs', 'view_dirs'), ('rays_o_ndc', 'rays_o_ndc'), ('rays_d_ndc', 'rays_d_ndc')):
+            ref = g[f'{gk}_{i}'].reshape(-1, 3)
+            assert np.array_equal(b[hk].cpu().numpy(), ref), f'{hk} frame {i}'
+        img_id = np.full(res[0] * res[1], i)
+        assert np.array_equal(b['rays_o2'].cpu().numpy(), ro.secondary_origins(g['poses'], img_id))
+        pid = b['pixel_id'].cpu().numpy()
+        assert (pid[:, 0] == i).all() and pid[:, 1].max() == res[1] - 1 and pid[:, 2].max() == res[0] - 1
+        assert float(b['near'].min()) == 1.0 and float(b['far_ndc'].max()) == 1.0
+
+
+def test_batch_gather_matches_cached_gather(dev):
+    """shuffled indices: the on-device recomputation equals gathering rows of the full per-scene ray cache"""
+    g = load('f6_raygen')
+    res = tuple(int(v) for v in g['resolution'])
+    rs = np.random.default_rng(8)
+    n, hw = 3, res[0] * res[1]
+    images = rs.random((n, res[0], res[1], 3), dtype=np.float32)
+    prior = (rs.random((n, n - 1, res[0], res[1])) < 0.5).astype(np.float32)
+    gen, _ = make_gen(g, dev, torch.from_numpy(images), torch.from_numpy(prior))
+    idx = rs.permutation(n * hw)[:1000]
+    b = gen.get_next_batch(7, torch.from_numpy(idx))
+    cache = {k: np.concatenate([g[f'{k}_{i}'].reshape(-1, 3) for i in range(n)]) for k in ('rays_o', 'rays_d', 'view_dirs', 'rays_o_ndc', 'rays_d_ndc')}
+    for k in cache:
+        assert np.array_equal(b[k].cpu().numpy(), cache[k][idx]), k
+    assert np.array_equal(b['target_rgb'].cpu().numpy(), images.reshape(-1, 3)[idx])
+    masks = np.transpose(prior, [0, 2, 3, 1]).reshape(-1, n - 1)            # DataPreprocessor01.py:475-476
+    assert np.array_equal(b['visibility_prior_masks'].cpu().numpy(), masks[idx])
+    assert b['iter_num'] == 7 and b['num_frames'] == 3 and b['common_data']['poses'].shape == (1, 3, 4, 4)
+    e = gen.get_next_batch(0, torch.zeros(0, dtype=torch.int64))            # empty batch
+    assert e['rays_o'].shape == (0, 3)
+
+
+def test_postprocess_bit_exact(dev):
+    g = load('f6_raygen')
+    gen, res = make_gen(g, dev, ndc=False)
+    out = {'rgb_fine': torch.from_numpy(g['pp_rgb']).to(dev), 'depth_fine': torch.from_numpy(g['pp_depth']).to(dev),
+           'depth_var_fine': torch.from_numpy(g['pp_depth']).to(dev)}
+    r = gen.retrieve_inference_outputs(out)
+    assert r['image'].dtype == torch.uint8 and np.array_equal(r['image'].cpu().numpy(), g['pp_image'])
+    assert np.array_equal(r['depth'].cpu().numpy(), g['pp_depth_out'])
+
+
+def test_predict_frame_against_oracle(dev):
+    """camera -> image entirely on the GPU vs the oracle render of the same rays (uint8 image within one level)."""
+    from data_preprocessors.RayGeneratorHip01 import predict_frame
+    from models.ModelFactory import get_model
+    g = load('f6_raygen')
+    gen, res = make_gen(g, dev)
+    mlp = lambda ns: {'num_samples': ns, 'netdepth': 8, 'netwidth': 256, 'points_positional_encoding_degree': 10,
+                      'views_positional_encoding_degree': 4, 'use_view_dirs': True, 'view_dependent_rgb': True, 'predict_visibility': True}
+    cfg = {'data_loader': {'ndc': True}, 'model': {'name': 'VipNeRFHip01', 'coarse_mlp': mlp(64), 'fine_mlp': mlp(128), 'lindisp': False,
+                                                    'perturb': True, 'raw_noise_std': 1.0, 'white_bkgd': False}}
+    params = vo.init_params(31, scale=1.6, sigma_bias=0.6)
+    model = get_model(cfg, None)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    model = model.to(dev).eval()
+    r = predict_frame(model, gen, frame=1)
+    o, d = ro.get_rays(res, g['intrinsic'], g['poses'][1])
+    on, dn = ro.get_ndc_rays(o, d, res, g['intrinsic'], 1.0)
+    hw = res[0] * res[1]
+    b = {'rays_o': torch.from_numpy(o.reshape(-1, 3).copy()), 'rays_d': torch.from_numpy(d.reshape(-1, 3).copy()),
+         'view_dirs': torch.from_numpy(ro.get_view_dirs(d).reshape(-1, 3)), 'rays_o_ndc': torch.from_numpy(on.reshape(-1, 3)),
+         'rays_d_ndc': torch.from_numpy(dn.reshape(-1, 3)), 'near_ndc': torch.zeros(hw, 1), 'far_ndc': torch.ones(hw, 1)}
+    with torch.no_grad():
+        ref = vo.render_rays(vo.params_to_torch(params), b, {'ndc': True, 'n_coarse': 64, 'n_fine': 128}, None, train=False, sec_views=False)
+    img = ro.post_process_image(ref['rgb_fine'].numpy().reshape(res[0], res[1], 3)).astype(np.int32)
+    diff = np.abs(r['image'].cpu().numpy().astype(np.int32) - img)
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.02, (diff.max(), (diff > 0).mean())
+    dep = ro.post_process_depth(ref['depth_fine'].numpy().reshape(res))
+    assert np.abs(r['depth'].cpu().numpy() - dep).max() <= 2e-3 * dep.max()

@@ -134,3 +134,18 @@ def test_f5_train_step(tag):
         # not reproducible, so compare with an absolute tolerance of one step
         np.testing.assert_allclose(digest(t)[2:], g['adig_' + k][2:], rtol=0, atol=1.1e-3)
         np.testing.assert_allclose(digest(t)[1], g['adig_' + k][1], rtol=1e-4)
+
+
+def test_f6_raygen_and_postprocess():
+    """oracle/raygen_oracle.py against the reference's DataPreprocessor: bit-exact."""
+    from oracle import raygen_oracle as ro
+    g = load('f6_raygen')
+    res = tuple(int(v) for v in g['resolution'])
+    for i in range(3):
+        o, d = ro.get_rays(res, g['intrinsic'], g['poses'][i])
+        assert np.array_equal(o, g[f'rays_o_{i}']) and np.array_equal(d, g[f'rays_d_{i}'])
+        assert np.array_equal(ro.get_view_dirs(d), g[f'view_dirs_{i}'])
+        on, dn = ro.get_ndc_rays(o, d, res, g['intrinsic'], float(g['near']))
+        assert np.array_equal(on, g[f'rays_o_ndc_{i}']) and np.array_equal(dn, g[f'rays_d_ndc_{i}'])
+    assert np.array_equal(ro.post_process_image(g['pp_rgb'].reshape(res[0], res[1], 3)), g['pp_image'])
+    assert np.array_equal(ro.post_process_depth(g['pp_depth'].reshape(res)), g['pp_depth_out'])

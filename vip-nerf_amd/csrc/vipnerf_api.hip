@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include "vipnerf_camera.h"
 #include "vipnerf_mlp.h"
 #include "vipnerf_prof.h"
 #include "vipnerf_ray.h"
@@ -333,6 +334,27 @@ int32_t vipnerf_losses_forward(const vipnerf_config *cfg, int64_t n_rays, const 
     a.partial = lout->scratch; a.counts = lout->scratch + 7 * (size_t)n_rays; a.loss_values = lout->loss_values;
     ProfScope ps("losses", (hipStream_t)stream);
     return launch_losses(a, (hipStream_t)stream);
+}
+
+int32_t vipnerf_generate_rays(const vipnerf_raygen *gen, int64_t n_rays, const vipnerf_ray_batch *out,
+                              vipnerf_stream_t stream) {
+    if (!gen || !out || !gen->cameras || !out->rays_o || !out->rays_d) { set_error("generate_rays: NULL argument"); return VIPNERF_E_ARG; }
+    if (gen->height <= 0 || gen->width <= 0 || gen->n_frames <= 0 || n_rays < 0) { set_error("generate_rays: bad sizes"); return VIPNERF_E_ARG; }
+    if (gen->ndc && (!out->rays_o_ndc || !out->rays_d_ndc)) { set_error("generate_rays: ndc set but NDC outputs are NULL"); return VIPNERF_E_ARG; }
+    RayGenArgs a;
+    a.g = *gen; a.out = *out; a.N = n_rays;
+    ProfScope ps("gen_rays", (hipStream_t)stream);
+    return launch_gen_rays(a, (hipStream_t)stream);
+}
+
+int32_t vipnerf_postprocess_frame(int64_t n_pixels, const float *rgb, const float *depth, const float *depth_var,
+                                  const float *depth_ndc, const float *depth_var_ndc, uint8_t *image,
+                                  float *o_depth, float *o_depth_var, float *o_depth_ndc, float *o_depth_var_ndc,
+                                  vipnerf_stream_t stream) {
+    if (n_pixels < 0) { set_error("postprocess_frame: n_pixels < 0"); return VIPNERF_E_ARG; }
+    ProfScope ps("postprocess", (hipStream_t)stream);
+    return launch_postprocess(n_pixels, rgb, depth, depth_var, depth_ndc, depth_var_ndc, image, o_depth, o_depth_var,
+                              o_depth_ndc, o_depth_var_ndc, (hipStream_t)stream);
 }
 
 int32_t vipnerf_profile_enable(int32_t on) {

@@ -188,7 +188,7 @@ __device__ __forceinline__ void secondary_dir(const PointSrc &s, const PointCtx 
         w[i] = __fsub_rn(pt, s.rays_o2[(c.n * s.V + v) * 3 + i]);
         n2 = __fadd_rn(n2, __fmul_rn(w[i], w[i]));
     }
-    const float nrm = __fsqrt_rn(n2);
+    const float nrm = sqrtf(n2);
 #pragma unroll
     for (int i = 0; i < 3; ++i) out[i] = __fdiv_rn(w[i], nrm);
 }

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(RAY_WG) void k_composite(CompositeArgs a) {
     const int k0 = lane * IPL;
     const float *zr = a.lvl.z_vals + n * S, *sg = a.lvl.raw_sigma + n * S;
     const float *dn = a.rays_d_s + 3 * n;
-    const float dnorm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dn[0], dn[0]), __fmul_rn(dn[1], dn[1])), __fmul_rn(dn[2], dn[2])));
+    const float dnorm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dn[0], dn[0]), __fmul_rn(dn[1], dn[1])), __fmul_rn(dn[2], dn[2])));
     const float oz = a.rays_o[3 * n + 2], dz = a.rays_d[3 * n + 2];
 
     float z[IPL + 1], al[IPL], T[IPL], w[IPL];
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(RAY_WG) void k_composite_bwd(CompositeBwdArgs a) {
     const int k0 = lane * IPL;
     const vipnerf_level_grads &g = a.g;
     const float *dn = a.rays_d_s + 3 * n;
-    const float dnorm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dn[0], dn[0]), __fmul_rn(dn[1], dn[1])), __fmul_rn(dn[2], dn[2])));
+    const float dnorm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dn[0], dn[0]), __fmul_rn(dn[1], dn[1])), __fmul_rn(dn[2], dn[2])));
     const float oz = a.rays_o[3 * n + 2], dz = a.rays_d[3 * n + 2];
     const float A = a.lvl.acc[n], den = __fadd_rn(A, 1e-6f);
     float g_rgb[3] = {0.f, 0.f, 0.f}, g_v2[VIPNERF_MAX_SEC] = {0.f, 0.f, 0.f}, V2[VIPNERF_MAX_SEC] = {0.f, 0.f, 0.f};

@@ -80,6 +80,25 @@ class LossOut(C.Structure):
     _fields_ = [('loss_values', c_f), ('coarse', LossLevelSeeds), ('fine', LossLevelSeeds), ('scratch', c_f)]
 
 
+class Camera(C.Structure):
+    _fields_ = [('kinv', C.c_float * 9), ('pose', C.c_float * 12), ('ndc_cx', C.c_float), ('ndc_cy', C.c_float),
+                ('pad', C.c_float * 2)]
+
+
+class RayGen(C.Structure):
+    _fields_ = [('height', C.c_int32), ('width', C.c_int32), ('n_frames', C.c_int32), ('ndc', C.c_int32),
+                ('near', C.c_float), ('far', C.c_float), ('near_ndc', C.c_float), ('far_ndc', C.c_float),
+                ('cameras', c_f), ('indices', c_f), ('first_index', C.c_int64), ('images', c_f), ('prior', c_f)]
+
+
+RAY_BATCH_FIELDS = ['rays_o', 'rays_d', 'view_dirs', 'rays_o_ndc', 'rays_d_ndc', 'near', 'far', 'near_ndc', 'far_ndc',
+                    'pixel_id', 'target_rgb', 'prior', 'rays_o2']
+
+
+class RayBatch(C.Structure):
+    _fields_ = [(k, c_f) for k in RAY_BATCH_FIELDS]
+
+
 class ProfileEntry(C.Structure):
     _fields_ = [('name', C.c_char * 32), ('count', C.c_int32), ('total_ms', C.c_float)]
 
@@ -101,6 +120,8 @@ SYMBOLS = {
     'vipnerf_mlp_forward': (C.c_int32, [C.c_int64, C.c_int32, c_f, c_f, c_f, c_f, C.c_float, c_f, c_f, c_f, c_f,
                                         c_f, c_f]),
     'vipnerf_composite': (C.c_int32, [P(Config), P(Rays), C.c_int32, P(LevelOut), c_f]),
+    'vipnerf_generate_rays': (C.c_int32, [P(RayGen), C.c_int64, P(RayBatch), c_f]),
+    'vipnerf_postprocess_frame': (C.c_int32, [C.c_int64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     'vipnerf_profile_enable': (C.c_int32, [C.c_int32]),
     'vipnerf_profile_read': (C.c_int32, [P(ProfileEntry), C.c_int32, P(C.c_int32)]),
 }

@@ -282,6 +282,23 @@ int32_t vipnerf_postprocess_frame(int64_t n_pixels, const float *rgb, const floa
                                   float *o_depth, float *o_depth_var, float *o_depth_ndc, float *o_depth_var_ndc,
                                   vipnerf_stream_t stream);
 
+/* Visibility-prior generator: plane-sweep-volume visibility weights of frame 1 w.r.t. frame 2,
+ * VisibilityWeightsComputer.compute_weights (src/prior_generators/visibility/VisibilityMask02_NeRF_LLFF.py:27-162).
+ * All geometry in float64 like the reference.  k1_inv = inv(intrinsic1); transform = extrinsic2 @ inv(extrinsic1)
+ * (rows 0..2); planes = 1 / linspace(1/min_depth, 1/max_depth, n_planes) -- computed by the host binding with
+ * numpy exactly as the reference does (:38-41, :56, :65).  weights64 / weights32 / mask (h*w each) may be NULL;
+ * mask = weights > 0.5 (:275-279). */
+typedef struct vipnerf_psv {
+    int32_t height, width, n_planes, pad;
+    double k1_inv[9], transform[12], k2[9];
+    double temperature;
+    const double *planes;       /* device, (n_planes) */
+    const uint8_t *frame1;      /* device, (h,w,3) */
+    const uint8_t *frame2;      /* device, (h,w,3) */
+} vipnerf_psv;
+int32_t vipnerf_visibility_prior(const vipnerf_psv *psv, double *weights64, float *weights32, uint8_t *mask,
+                                 vipnerf_stream_t stream);
+
 /* ---- measurement --------------------------------------------------------------------------------------- */
 /* Per-stage device time from HIP events recorded on the launch stream around each kernel (group) the calls
  * above queue.  Off by default.  profile_read waits for the recorded events, aggregates them by stage name

@@ -343,6 +343,36 @@ def gen_f6():
     npz('f6_raygen', **out)
 
 
+# ------------------------------------------------------------------------------------------------ F7
+def gen_f7():
+    """Visibility-prior generator of the reference (plane-sweep volume) on a 40x56 two-camera toy scene."""
+    import types
+    for m in ('skimage', 'skimage.transform', 'skimage.io', 'simplejson'):
+        sys.modules.setdefault(m, types.ModuleType(m))           # absent here; used only for file IO
+    sys.path.insert(0, '/root/reference/src/prior_generators/visibility')
+    from VisibilityMask02_NeRF_LLFF import VisibilityWeightsComputer
+    g = np.random.default_rng(71)
+    h, w = 40, 56
+    base = g.integers(0, 256, size=(h // 4 + 2, w // 4 + 2, 3)).astype(np.float64)
+    yy, xx = np.meshgrid(np.linspace(0, h // 4, h), np.linspace(0, w // 4, w), indexing='ij')
+    y0, x0 = yy.astype(int), xx.astype(int)
+    ty, tx = (yy - y0)[..., None], (xx - x0)[..., None]
+    img = (1 - ty) * ((1 - tx) * base[y0, x0] + tx * base[y0, x0 + 1]) + ty * ((1 - tx) * base[y0 + 1, x0] + tx * base[y0 + 1, x0 + 1])
+    frame1 = np.clip(np.round(img), 0, 255).astype(np.uint8)
+    frame2 = np.clip(np.round(np.roll(img, 3, axis=1) + g.normal(0, 6, img.shape)), 0, 255).astype(np.uint8)
+    K = np.array([[60., 0, 28.], [0, 60., 20.], [0, 0, 1.]])
+    E1 = np.eye(4)
+    E2 = np.eye(4)
+    ang = 0.04
+    E2[:3, :3] = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    E2[:3, 3] = [0.25, -0.03, 0.02]
+    comp = VisibilityWeightsComputer({'num_depth_planes': 64, 'temperature': 10})
+    w12 = comp.compute_weights(frame1, frame2, E1, E2, K, K, 1.5, 9.0)
+    w21 = comp.compute_weights(frame2, frame1, E2, E1, K, K, 1.5, 9.0)
+    npz('f7_visibility_prior', frame1=frame1, frame2=frame2, K=K, E1=E1, E2=E2, min_depth=1.5, max_depth=9.0,
+        n_planes=64, temperature=10.0, weights12=w12, weights21=w21)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     gen_f1()
@@ -354,3 +384,4 @@ if __name__ == '__main__':
     gen_f5('dtu', 'dtu', 3, 24, 0, 520)
     gen_f5('toy', 'toy', 2, 64, 0, 530, depth=4, width=64, n_fine=0, pscale=1.0)
     gen_f6()
+    gen_f7()

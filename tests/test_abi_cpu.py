@@ -92,3 +92,32 @@ def test_oracle_is_not_imported_by_the_product():
             if re.search(r'^\s*(from|import)\s+oracle', line):
                 offenders.append(f)
     assert not offenders, offenders
+
+
+def test_checkpoint_roundtrip_with_reference_key_layout(tmp_path):
+    """f-4: state-dict keys / shapes / order equal the reference's DataParallel-wrapped VipNeRF (manifest captured
+    from the real reference by importing it), and the save/load shim round-trips through the reference's file format."""
+    import json
+    import CheckpointHip01 as ck
+    from models.ModelFactory import get_model
+    man = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'f8_reference_state_dict_manifest.json')))
+    mlp = {'num_samples': 64, 'netdepth': 8, 'netwidth': 256, 'points_positional_encoding_degree': 10,
+           'views_positional_encoding_degree': 4, 'use_view_dirs': True, 'view_dependent_rgb': True, 'predict_visibility': True}
+    cfg = {'data_loader': {'ndc': True}, 'model': {'name': 'VipNeRFHip01', 'coarse_mlp': dict(mlp), 'fine_mlp': dict(mlp, num_samples=128)}}
+    torch.manual_seed(3)
+    m = get_model(cfg, None)
+    sd = ck.add_prefix(m.state_dict())
+    assert list(sd.keys()) == man['keys']
+    assert all(list(v.shape) == man['shapes'][k] for k, v in sd.items())
+    opt = torch.optim.Adam(m.parameters(), lr=5e-4)
+    path = ck.save_model(m, opt, 50000, tmp_path)
+    assert path.name == 'Model_Iter050000.tar' and (tmp_path / 'saved_models' / 'Model_Latest.tar').is_symlink()
+    raw = torch.load(str(path), weights_only=False)
+    assert set(raw.keys()) == {'iteration_num', 'model_state_dict', 'optimizer_state_dict'}
+    assert all(k.startswith('module.') for k in raw['model_state_dict'])
+    torch.manual_seed(4)
+    m2 = get_model(cfg, None)
+    it = ck.load_model(torch.nn.DataParallel(m2), tmp_path / 'saved_models' / 'Model_Latest.tar')
+    assert it == 50000
+    for (k1, p1), (k2, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        assert k1 == k2 and torch.equal(p1, p2)

@@ -107,3 +107,35 @@ def test_predict_frame_against_oracle(dev):
     assert diff.max() <= 1 and (diff > 0).mean() < 0.02, (diff.max(), (diff > 0).mean())
     dep = ro.post_process_depth(ref['depth_fine'].numpy().reshape(res))
     assert np.abs(r['depth'].cpu().numpy() - dep).max() <= 2e-3 * dep.max()
+
+
+def test_visibility_prior_generator_golden(dev):
+    """f-3: plane-sweep visibility weights on the GPU vs the reference's VisibilityWeightsComputer (float64 geometry:
+    1e-9 relative on the weights, identical masks)."""
+    from prior_generators.VisibilityMaskHip02 import VisibilityWeightsComputerHip
+    g = load('f7_visibility_prior')
+    comp = VisibilityWeightsComputerHip({'num_depth_planes': int(g['n_planes']), 'temperature': float(g['temperature'])}, dev)
+    for a, b, ea, eb, key in (('frame1', 'frame2', 'E1', 'E2', 'weights12'), ('frame2', 'frame1', 'E2', 'E1', 'weights21')):
+        w, m = comp.compute_masks(g[a], g[b], g[ea], g[eb], g['K'], g['K'], float(g['min_depth']), float(g['max_depth']))
+        np.testing.assert_allclose(w, g[key], rtol=1e-9, atol=1e-12)
+        assert np.array_equal(m, g[key] > 0.5)
+        assert w.dtype == np.float64 and w.shape == g[key].shape
+
+
+def test_visibility_prior_full_frame_properties(dev):
+    """LLFF-sized frame (756x1008, 64 planes): identical frames and cameras are fully visible (w = 1); a camera
+    displaced far to the side sees nothing (all taps outside -> warped = 0 -> error = mean intensity)."""
+    from prior_generators.VisibilityMaskHip02 import VisibilityWeightsComputerHip
+    rs = np.random.default_rng(2)
+    h, w = 756, 1008
+    img = rs.integers(1, 256, size=(h, w, 3)).astype(np.uint8)
+    K = np.array([[815.13, 0, 504.], [0, 815.13, 378.], [0, 0, 1.]])
+    comp = VisibilityWeightsComputerHip({'num_depth_planes': 64, 'temperature': 10}, dev)
+    wts = comp.compute_weights(img, img, np.eye(4), np.eye(4), K, K, 1.0, 5.0)
+    assert wts.shape == (h, w) and np.abs(wts - 1.0).max() < 1e-9
+    E2 = np.eye(4)
+    E2[0, 3] = 1e5                                                       # projects every plane far outside frame 2
+    wts = comp.compute_weights(img, img, np.eye(4), E2, K, K, 1.0, 5.0)
+    ref = np.exp(-img.astype(np.float64).mean(-1) / 10)
+    inside = (slice(2, h - 2), slice(2, w - 2))
+    assert np.abs(wts[inside] - ref[inside]).max() < 1e-9

@@ -149,3 +149,13 @@ def test_f6_raygen_and_postprocess():
         assert np.array_equal(on, g[f'rays_o_ndc_{i}']) and np.array_equal(dn, g[f'rays_d_ndc_{i}'])
     assert np.array_equal(ro.post_process_image(g['pp_rgb'].reshape(res[0], res[1], 3)), g['pp_image'])
     assert np.array_equal(ro.post_process_depth(g['pp_depth'].reshape(res)), g['pp_depth_out'])
+
+
+def test_f7_visibility_prior_generator():
+    from oracle import psv_oracle as po
+    g = load('f7_visibility_prior')
+    for a, b, ea, eb, key in (('frame1', 'frame2', 'E1', 'E2', 'weights12'), ('frame2', 'frame1', 'E2', 'E1', 'weights21')):
+        w = po.compute_weights(g[a], g[b], g[ea], g[eb], g['K'], g['K'], float(g['min_depth']), float(g['max_depth']),
+                               int(g['n_planes']), float(g['temperature']))
+        np.testing.assert_allclose(w, g[key], rtol=1e-11, atol=1e-13)
+        assert np.array_equal(w > 0.5, g[key] > 0.5)

@@ -357,6 +357,14 @@ int32_t vipnerf_postprocess_frame(int64_t n_pixels, const float *rgb, const floa
                               o_depth_ndc, o_depth_var_ndc, (hipStream_t)stream);
 }
 
+int32_t vipnerf_visibility_prior(const vipnerf_psv *psv, double *weights64, float *weights32, uint8_t *mask,
+                                 vipnerf_stream_t stream) {
+    if (!psv || !psv->planes || !psv->frame1 || !psv->frame2) { set_error("visibility_prior: NULL argument"); return VIPNERF_E_ARG; }
+    if (psv->height <= 0 || psv->width <= 0 || psv->n_planes <= 0 || !(psv->temperature > 0)) { set_error("visibility_prior: bad sizes"); return VIPNERF_E_ARG; }
+    ProfScope ps("visibility_prior", (hipStream_t)stream);
+    return launch_psv(psv, weights64, weights32, mask, (hipStream_t)stream);
+}
+
 int32_t vipnerf_profile_enable(int32_t on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = on != 0;

@@ -12,4 +12,5 @@ int launch_gen_rays(const RayGenArgs &a, hipStream_t st);
 int launch_postprocess(int64_t n, const float *rgb, const float *depth, const float *depth_var, const float *depth_ndc,
                        const float *depth_var_ndc, uint8_t *image, float *o_depth, float *o_depth_var, float *o_depth_ndc,
                        float *o_depth_var_ndc, hipStream_t st);
+int launch_psv(const vipnerf_psv *p, double *weights64, float *weights32, uint8_t *mask, hipStream_t st);
 }  // namespace vn

@@ -99,6 +99,12 @@ class RayBatch(C.Structure):
     _fields_ = [(k, c_f) for k in RAY_BATCH_FIELDS]
 
 
+class Psv(C.Structure):
+    _fields_ = [('height', C.c_int32), ('width', C.c_int32), ('n_planes', C.c_int32), ('pad', C.c_int32),
+                ('k1_inv', C.c_double * 9), ('transform', C.c_double * 12), ('k2', C.c_double * 9),
+                ('temperature', C.c_double), ('planes', c_f), ('frame1', c_f), ('frame2', c_f)]
+
+
 class ProfileEntry(C.Structure):
     _fields_ = [('name', C.c_char * 32), ('count', C.c_int32), ('total_ms', C.c_float)]
 
@@ -122,6 +128,7 @@ SYMBOLS = {
     'vipnerf_composite': (C.c_int32, [P(Config), P(Rays), C.c_int32, P(LevelOut), c_f]),
     'vipnerf_generate_rays': (C.c_int32, [P(RayGen), C.c_int64, P(RayBatch), c_f]),
     'vipnerf_postprocess_frame': (C.c_int32, [C.c_int64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    'vipnerf_visibility_prior': (C.c_int32, [P(Psv), c_f, c_f, c_f, c_f]),
     'vipnerf_profile_enable': (C.c_int32, [C.c_int32]),
     'vipnerf_profile_read': (C.c_int32, [P(ProfileEntry), C.c_int32, P(C.c_int32)]),
 }

@@ -176,18 +176,26 @@ def main():
     }
 
     if world == 1 and not args.no_render:
-        # full-frame eval render: 756 x 1008 rays, no secondary views, per-ray outputs on device
+        # full-frame eval render, camera -> uint8 image on the GPU (756 x 1008 rays, no secondary views):
+        # on-device ray generation -> coarse+fine eval pass -> post-processing (Tester01.predict_frame's job)
+        from data_preprocessors.RayGeneratorHip01 import RayGeneratorHip, predict_frame
+        import numpy as np
         model.eval()
+        K = np.array([[815.1316, 0, 504.], [0, 815.1316, 378.], [0, 0, 1.]], dtype=np.float32)
+        poses = np.tile(np.eye(4, dtype=np.float32), (2, 1, 1))
+        poses[:, 0, 3] = [-0.1, 0.1]
+        gen = RayGeneratorHip((756, 1008), K[None], poses, 1.0, 5.1731, True, dev)
+        ops.profile_enable(True); ops.profile_read()
+        for _ in range(2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            frame = predict_frame(model, gen, frame=0)
+            torch.cuda.synchronize(); rt = time.perf_counter() - t0
+        rp = ops.profile_read(); ops.profile_enable(False)
+        assert frame['image'].shape == (756, 1008, 3) and frame['image'].dtype == torch.uint8
         n = 756 * 1008
-        fb = make_batch(vo, n, 4242, dev)
-        with torch.no_grad():
-            for _ in range(2):
-                b = dict(fb); b['common_data'] = {'poses': fb['common_data']['poses']}
-                torch.cuda.synchronize(); t0 = time.perf_counter()
-                model(b)
-                torch.cuda.synchronize(); rt = time.perf_counter() - t0
         result['render_ms_per_frame'] = round(rt * 1e3, 1)
         result['render_rays_per_sec'] = round(n / rt, 1)
+        result['render_stage_ms'] = {k: round(v[1] / 2, 3) for k, v in sorted(rp.items())}
         model.train()
 
     if world == 1 and not args.no_cpu_baseline:

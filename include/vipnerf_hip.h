@@ -38,6 +38,13 @@ extern "C" {
 #define VIPNERF_E_UNSUPPORTED (-2)   /* configuration outside the supported topology / sizes */
 #define VIPNERF_E_HIP         (-3)   /* a HIP runtime call failed (text in vipnerf_last_error) */
 
+/* MLP GEMM arithmetic.  FP32: v_mfma_f32_32x32x2_f32, bit-equivalent to an fmaf chain (the parity default).
+ * BF16X3 / BF16X6: operands split into 2 / 3 bf16 parts, 3 / 6 cross terms on v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation -- ~1e-5 / fp32-grade relative error per product at 5.3x / 2.7x the fp32 MFMA rate. */
+#define VIPNERF_PREC_FP32   0
+#define VIPNERF_PREC_BF16X3 1
+#define VIPNERF_PREC_BF16X6 2
+
 #define VIPNERF_MAX_SEC 3            /* secondary views V = nf-1 <= 3 (reference configs use nf in {2,3,4}) */
 #define VIPNERF_N_PARAMS 24          /* tensors of one MLP */
 
@@ -58,7 +65,8 @@ typedef struct vipnerf_config {
     int32_t given_z_fine; /* parity tests (teacher forcing): out->fine.z_vals already holds the fine depths on
                              entry; importance sampling is skipped.  0 in production. */
     int32_t perturb;      /* configs['model']['perturb'] && training: stratified jitter + random inverse-CDF draws */
-    int32_t reserved[5];
+    int32_t precision;    /* VIPNERF_PREC_*: arithmetic of the MLP GEMMs (forward; backward GEMMs are fp32) */
+    int32_t reserved[4];
 } vipnerf_config;
 
 /* One ray batch (render_rays' input_dict, src/models/VipNeRF01.py:74-98).  N = n_rays. */
@@ -186,6 +194,9 @@ size_t  vipnerf_packed_weights_bytes(void);
  * image for dgrad, LDS-resident heads/biases).  Replaces nothing in the reference; it is what lets
  * MLP.forward (VipNeRF01.py:509-596) run as one kernel.  Call after every optimizer step. */
 int32_t vipnerf_pack_weights(const vipnerf_mlp_params *params, void *packed, vipnerf_stream_t stream);
+/* Same for a given precision: the buffer holds the fp32 image followed by the split-bf16 image (if precision != FP32). */
+size_t  vipnerf_packed_weights_bytes_p(int32_t precision);
+int32_t vipnerf_pack_weights_p(const vipnerf_mlp_params *params, int32_t precision, void *packed, vipnerf_stream_t stream);
 
 /* ---- workspace ------------------------------------------------------------------------------------------ */
 /* acts_bytes: per-call activation store written by render_forward when cfg.save_acts (0 otherwise), read by
@@ -230,6 +241,11 @@ int32_t vipnerf_sample_fine(int64_t n_rays, int32_t n_coarse, int32_t n_fine, co
 int32_t vipnerf_mlp_forward(int64_t n_points, int32_t n_sec, const float *pts, const float *view_dirs,
                             const float *view_dirs2, const float *noise, float noise_std, const void *packed,
                             float *sigma, float *rgb, float *vis, float *vis2, vipnerf_stream_t stream);
+/* vipnerf_mlp_forward with the GEMM arithmetic of `precision` (packed from vipnerf_pack_weights_p). */
+int32_t vipnerf_mlp_forward_p(int64_t n_points, int32_t n_sec, const float *pts, const float *view_dirs,
+                              const float *view_dirs2, const float *noise, float noise_std, int32_t precision,
+                              const void *packed, float *sigma, float *rgb, float *vis, float *vis2,
+                              vipnerf_stream_t stream);
 /* VipNeRF.volume_rendering (+ convert_depth_from_ndc) (VipNeRF01.py:331-403) on explicit network outputs
  * held in lvl->raw_* and lvl->z_vals; fills the remaining fields of *lvl. */
 int32_t vipnerf_composite(const vipnerf_config *cfg, const vipnerf_rays *rays, int32_t n_samples,

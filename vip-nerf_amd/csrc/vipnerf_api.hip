@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include "vipnerf_bf16.h"
 #include "vipnerf_camera.h"
 #include "vipnerf_mlp.h"
 #include "vipnerf_prof.h"
@@ -62,7 +63,17 @@ static int check_cfg(const vipnerf_config *cfg) {
         set_error("n_fine=%d unsupported (n_coarse+n_fine multiple of 32, <= 256)", cfg->n_fine); return VIPNERF_E_UNSUPPORTED; }
     if (cfg->n_sec < 0 || cfg->n_sec > VIPNERF_MAX_SEC) {
         set_error("n_sec=%d unsupported (0..%d)", cfg->n_sec, VIPNERF_MAX_SEC); return VIPNERF_E_UNSUPPORTED; }
+    if (cfg->precision < 0 || cfg->precision > VIPNERF_PREC_BF16X6) {
+        set_error("precision=%d unsupported", cfg->precision); return VIPNERF_E_UNSUPPORTED; }
     return VIPNERF_OK;
+}
+
+int launch_mlp_fwd_bf16(const MlpFwdArgs &a, int precision, hipStream_t st);
+
+static int launch_mlp_fwd_any(MlpFwdArgs &a, int precision, hipStream_t st) {
+    if (precision == VIPNERF_PREC_FP32) return launch_mlp_fwd(a, st);
+    a.packed += PK_TOTAL_F;                       // the split-bf16 image follows the fp32 image
+    return launch_mlp_fwd_bf16(a, precision, st);
 }
 
 static int check_rays(const vipnerf_config *cfg, const vipnerf_rays *r) {
@@ -119,6 +130,15 @@ int32_t vipnerf_pack_weights(const vipnerf_mlp_params *params, void *packed, vip
     return launch_pack(params, packed, (hipStream_t)stream);
 }
 
+size_t vipnerf_packed_weights_bytes_p(int32_t precision) { return packed_total_floats(precision) * sizeof(float); }
+
+int32_t vipnerf_pack_weights_p(const vipnerf_mlp_params *params, int32_t precision, void *packed, vipnerf_stream_t stream) {
+    if (precision < 0 || precision > VIPNERF_PREC_BF16X6) { set_error("pack_weights: precision=%d unsupported", precision); return VIPNERF_E_UNSUPPORTED; }
+    int rc = vipnerf_pack_weights(params, packed, stream);
+    if (rc || precision == VIPNERF_PREC_FP32) return rc;
+    return launch_pack_bf16(params, precision, (float *)packed + PK_TOTAL_F, (hipStream_t)stream);
+}
+
 int32_t vipnerf_query_workspace(const vipnerf_config *cfg, int64_t n_rays, size_t *acts_bytes, size_t *bwd_bytes) {
     int rc = check_cfg(cfg);
     if (rc) return rc;
@@ -156,6 +176,15 @@ int32_t vipnerf_sample_fine(int64_t n_rays, int32_t n_coarse, int32_t n_fine, co
 int32_t vipnerf_mlp_forward(int64_t n_points, int32_t n_sec, const float *pts, const float *view_dirs,
                             const float *view_dirs2, const float *noise, float noise_std, const void *packed,
                             float *sigma, float *rgb, float *vis, float *vis2, vipnerf_stream_t stream) {
+    return vipnerf_mlp_forward_p(n_points, n_sec, pts, view_dirs, view_dirs2, noise, noise_std, VIPNERF_PREC_FP32, packed,
+                                 sigma, rgb, vis, vis2, stream);
+}
+
+int32_t vipnerf_mlp_forward_p(int64_t n_points, int32_t n_sec, const float *pts, const float *view_dirs,
+                              const float *view_dirs2, const float *noise, float noise_std, int32_t precision,
+                              const void *packed, float *sigma, float *rgb, float *vis, float *vis2,
+                              vipnerf_stream_t stream) {
+    if (precision < 0 || precision > VIPNERF_PREC_BF16X6) { set_error("mlp_forward: precision=%d unsupported", precision); return VIPNERF_E_UNSUPPORTED; }
     if (n_points == 0) return VIPNERF_OK;
     if (!pts || !view_dirs || !packed || !sigma || !rgb || !vis || (n_sec > 0 && (!view_dirs2 || !vis2))) {
         set_error("mlp_forward: NULL argument"); return VIPNERF_E_ARG; }
@@ -167,7 +196,7 @@ int32_t vipnerf_mlp_forward(int64_t n_points, int32_t n_sec, const float *pts, c
     a.ns.noise = noise; a.ns.std = noise_std;
     a.packed = (const float *)packed;
     a.sigma = sigma; a.rgb = rgb; a.vis = vis; a.vis2 = vis2;
-    return launch_mlp_fwd(a, (hipStream_t)stream);
+    return launch_mlp_fwd_any(a, precision, (hipStream_t)stream);
 }
 
 int32_t vipnerf_composite(const vipnerf_config *cfg, const vipnerf_rays *rays, int32_t n_samples,
@@ -243,7 +272,7 @@ int32_t vipnerf_render_forward(const vipnerf_config *cfg, const vipnerf_rays *ra
         }
         {
             ProfScope ps(lv ? "mlp_fwd_fine" : "mlp_fwd_coarse", st);
-            if ((rc = launch_mlp_fwd(ma, st))) return rc;
+            if ((rc = launch_mlp_fwd_any(ma, cfg->precision, st))) return rc;
         }
         // 3./6. compositing
         CompositeArgs ca;

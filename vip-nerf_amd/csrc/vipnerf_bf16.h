@@ -1,0 +1,146 @@
+// Split-precision bf16 MFMA path ("bf16xN"): every fp32 operand x is written as a short sum of bf16 numbers,
+// x ~= x0 + x1 (+ x2), x0 = bf16(x), x1 = bf16(x - x0), ..., and a product a*b is accumulated in fp32 from the
+// significant cross terms on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate):
+//   NS = 2 ("bf16x3"): a0b0 + a0b1 + a1b0              3 MFMAs, per-product error <= ~3 * 2^-18  (~1e-5)
+//   NS = 3 ("bf16x6"): a0b0 + a0b1 + a1b0 + a0b2 + a2b0 + a1b1   6 MFMAs, error ~2^-26 (fp32 grade)
+// Everything else -- transposed register-chained layers, weights streamed through LDS in fragment order -- is the
+// fp32 design (vipnerf_common.h) with a different fragment: lane l supplies A[i = l&31][k = 8*(l>>5) + e] and
+// B[k = 8*(l>>5) + e][j = l&31], e = 0..7, 16 k-values per MFMA; C/D layout is identical.  A C/D tile of the
+// previous layer (16 registers per lane) therefore feeds two k-steps: registers 8u..8u+7 of tile T are the 8
+// k-values of k-step s = 2T + u for this lane's half, i.e. the contraction index is feat(16T + 8u + e, h).
+#pragma once
+#include "vipnerf_common.h"
+
+namespace vn {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int NS>
+struct BfPlan {
+    static constexpr int KSB = NS == 2 ? 4 : 2;              // k-steps (of 16) per stage for an 8-tile layer
+    static constexpr int CH = KSB * 8 * NS;                  // chunks (1 KiB) per stage: 64 (NS=2) / 48 (NS=3)
+    static constexpr int STAGE_F = CH * CHUNK_F;             // in float units
+    static constexpr int ST_256 = 16 / KSB;                  // stages of a 256-deep contraction over 8 tiles
+    static constexpr int ST_PE = 4 / KSB;                    // gamma(x): K = 64 -> 4 k-steps
+    static constexpr int KSV = 2 * KSB;                      // k-steps per stage when a stage spans 4 tiles
+    static constexpr int ST_VIEW_F = 16 / KSV;               // view layer forward: 4 tiles x 16 k-steps
+    static constexpr int ST_VIEW_B = 8 / KSB;                // view layer dgrad: 8 tiles x 8 k-steps (K = 128)
+    static constexpr int FS_L0PE = 0;
+    static constexpr int FS_L1 = FS_L0PE + ST_PE;
+    static constexpr int FS_L5PE = FS_L1 + 4 * ST_256;
+    static constexpr int FS_L5 = FS_L5PE + ST_PE;
+    static constexpr int FS_L6 = FS_L5 + ST_256;
+    static constexpr int FS_L7 = FS_L6 + ST_256;
+    static constexpr int FS_FEAT = FS_L7 + ST_256;
+    static constexpr int FS_VIEW = FS_FEAT + ST_256;
+    static constexpr int F_STAGES = FS_VIEW + ST_VIEW_F;
+    static constexpr int BS_VIEW = 0;
+    static constexpr int BS_FEAT = BS_VIEW + ST_VIEW_B;
+    static constexpr int BS_L7 = BS_FEAT + ST_256;
+    static constexpr int B_STAGES = BS_L7 + 7 * ST_256;
+    // LDS-resident block: direction columns of the view layer as bf16 fragments (2 k-steps x 4 tiles x NS chunks),
+    // then the fp32 biases / heads exactly as in the fp32 image (R_BIAS .. R_TOTAL)
+    static constexpr int R_DIRW = 0;
+    static constexpr int R_DIRW_F = 2 * 4 * NS * CHUNK_F;
+    static constexpr int R_F32 = R_DIRW_F;                   // + (R_x - R_BIAS) for the fp32 entries
+    static constexpr int R_TOTAL = R_F32 + (vn::R_TOTAL - vn::R_BIAS);
+    static constexpr int R_TOTAL_PAD = (R_TOTAL + 255) / 256 * 256;
+    static constexpr size_t PK_FWD = 0;
+    static constexpr size_t PK_BWD = PK_FWD + (size_t)F_STAGES * STAGE_F;
+    static constexpr size_t PK_RES = PK_BWD + (size_t)B_STAGES * STAGE_F;
+    static constexpr size_t PK_TOTAL_F = PK_RES + R_TOTAL_PAD;
+    static constexpr int LDS_F = R_TOTAL_PAD + 2 * STAGE_F;
+};
+
+// float offsets inside the packed buffer: [fp32 image][bf16x3 image] or [fp32 image][bf16x6 image]
+__host__ __device__ inline size_t packed_total_floats(int precision) {
+    return PK_TOTAL_F + (precision == 1 ? BfPlan<2>::PK_TOTAL_F : (precision == 2 ? BfPlan<3>::PK_TOTAL_F : 0));
+}
+
+#if defined(__HIPCC__)
+// part i of the split of x (i = 0: bf16(x); 1: bf16(x - x0); 2: bf16(x - x0 - x1)), round-to-nearest-even
+__device__ __forceinline__ __bf16 split_part(float x, int i) {
+    __bf16 p = (__bf16)x;
+    for (int k = 0; k < i; ++k) { x = x - (float)p; p = (__bf16)x; }
+    return p;
+}
+template <int NS>
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&out)[NS]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float r = x[e];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const __bf16 p = (__bf16)r;
+            out[i][e] = p;
+            r = r - (float)p;
+        }
+    }
+}
+
+__device__ __forceinline__ floatx16 mfma_bf(bf16x8 a, bf16x8 b, floatx16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// acc[t] += A(k-step, tile) * B(k-step) over the significant cross terms; smallest terms first
+template <int NS>
+__device__ __forceinline__ floatx16 mfma_split(const bf16x8 (&a)[NS], const bf16x8 (&b)[NS], floatx16 c) {
+    if (NS == 3) {
+        c = mfma_bf(a[1], b[1], c);
+        c = mfma_bf(a[2], b[0], c);
+        c = mfma_bf(a[0], b[2], c);
+    }
+    c = mfma_bf(a[1], b[0], c);
+    c = mfma_bf(a[0], b[1], c);
+    c = mfma_bf(a[0], b[0], c);
+    return c;
+}
+
+// `stage` holds NKS k-steps x NT tiles x NS parts, chunk index (ks * NT + t) * NS + part; B[s] = the NS parts of
+// k-step s (global k-step index KS0 + ks)
+#define VN_GEMM_STAGE_BF(stage, NT, NKS, KS0, NS, acc, BARR)                                             \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < (NKS); ++ks_) {                                            \
+        _Pragma("unroll") for (int t_ = 0; t_ < (NT); ++t_) {                                            \
+            bf16x8 a_[NS];                                                                               \
+            _Pragma("unroll") for (int i_ = 0; i_ < (NS); ++i_)                                          \
+                a_[i_] = *(const bf16x8 *)((stage) + ((ks_ * (NT) + t_) * (NS) + i_) * CHUNK_F + lane * 4); \
+            acc[t_] = mfma_split<NS>(a_, BARR[(KS0) + ks_], acc[t_]);                                    \
+        }                                                                                                \
+    }
+
+// weight stream with a compile-time stage size (chunks)
+template <int CH>
+struct WStreamT {
+    const float *g;
+    float *buf;
+    int n_left, cur, lane, wave;
+    static constexpr int SF = CH * CHUNK_F;
+    __device__ __forceinline__ void fetch(int b) {
+        // CH chunks over 4 waves
+        constexpr int PER_WAVE = CH / 4;
+        const float *src = g + (wave * PER_WAVE) * CHUNK_F + lane * 4;
+        float *dst = buf + b * SF + (wave * PER_WAVE) * CHUNK_F;
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * CHUNK_F),
+                                             (__attribute__((address_space(3))) void *)(dst + i * CHUNK_F), 16, 0, 0);
+        g += SF;
+        --n_left;
+    }
+    __device__ __forceinline__ void start(const float *stream, int n_stages, float *lds_buf, int lane_, int wave_) {
+        g = stream; buf = lds_buf; n_left = n_stages; cur = 0; lane = lane_; wave = wave_;
+        fetch(0);
+    }
+    __device__ __forceinline__ const float *next() {
+        __syncthreads();
+        const float *ret = buf + cur * SF;
+        cur ^= 1;
+        if (n_left > 0) fetch(cur);
+        return ret;
+    }
+};
+#endif
+
+int launch_pack_bf16(const vipnerf_mlp_params *p, int precision, void *packed_bf, hipStream_t st);
+
+}  // namespace vn

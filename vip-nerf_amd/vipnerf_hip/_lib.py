@@ -23,7 +23,7 @@ class VipNerfHipError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [('ndc', C.c_int32), ('n_coarse', C.c_int32), ('n_fine', C.c_int32), ('n_sec', C.c_int32),
                 ('train', C.c_int32), ('lindisp', C.c_int32), ('white_bkgd', C.c_int32), ('save_acts', C.c_int32),
-                ('noise_std', C.c_float), ('given_z_fine', C.c_int32), ('perturb', C.c_int32), ('reserved', C.c_int32 * 5)]
+                ('noise_std', C.c_float), ('given_z_fine', C.c_int32), ('perturb', C.c_int32), ('precision', C.c_int32), ('reserved', C.c_int32 * 4)]
 
 
 class Rays(C.Structure):
@@ -116,6 +116,10 @@ SYMBOLS = {
     'vipnerf_last_error': (C.c_int32, [C.c_char_p, C.c_size_t]),
     'vipnerf_packed_weights_bytes': (C.c_size_t, []),
     'vipnerf_pack_weights': (C.c_int32, [P(MlpParams), c_f, c_f]),
+    'vipnerf_packed_weights_bytes_p': (C.c_size_t, [C.c_int32]),
+    'vipnerf_pack_weights_p': (C.c_int32, [P(MlpParams), C.c_int32, c_f, c_f]),
+    'vipnerf_mlp_forward_p': (C.c_int32, [C.c_int64, C.c_int32, c_f, c_f, c_f, c_f, C.c_float, C.c_int32, c_f, c_f, c_f,
+                                          c_f, c_f, c_f]),
     'vipnerf_query_workspace': (C.c_int32, [P(Config), C.c_int64, P(C.c_size_t), P(C.c_size_t)]),
     'vipnerf_render_forward': (C.c_int32, [P(Config), P(Rays), P(Rng), c_f, c_f, P(Outputs), c_f, c_f]),
     'vipnerf_render_backward': (C.c_int32, [P(Config), P(Rays), c_f, c_f, P(Outputs), P(OutGrads), c_f, c_f,

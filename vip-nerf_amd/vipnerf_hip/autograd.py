@@ -32,8 +32,8 @@ class RenderFunction(torch.autograd.Function):
     def forward(ctx, state: RenderState, *params):
         cfg = state.cfg
         two = cfg.n_fine > 0
-        pc = ops.pack_weights(list(params[:L.VIPNERF_N_PARAMS]))
-        pf = ops.pack_weights(list(params[L.VIPNERF_N_PARAMS:])) if two else None
+        pc = ops.pack_weights(list(params[:L.VIPNERF_N_PARAMS]), precision=cfg.precision)
+        pf = ops.pack_weights(list(params[L.VIPNERF_N_PARAMS:]), precision=cfg.precision) if two else None
         need_bwd = state.grad_enabled and any(ctx.needs_input_grad)   # grad mode as seen by the caller of apply()
         cfg.save_acts = int(need_bwd)
         acts = None

@@ -36,8 +36,9 @@ def f32c(t: torch.Tensor) -> torch.Tensor:
 
 
 def make_config(ndc, n_coarse, n_fine, n_sec, train, noise_std=0.0, lindisp=False, white_bkgd=False,
-                save_acts=False, perturb=None) -> L.Config:
+                save_acts=False, perturb=None, precision=0) -> L.Config:
     c = L.Config()
+    c.precision = int(precision)
     c.perturb = int(bool(train if perturb is None else perturb))
     c.ndc, c.n_coarse, c.n_fine, c.n_sec = int(bool(ndc)), int(n_coarse), int(n_fine), int(n_sec)
     c.train, c.lindisp, c.white_bkgd, c.save_acts = int(bool(train)), int(bool(lindisp)), int(bool(white_bkgd)), int(bool(save_acts))
@@ -45,11 +46,14 @@ def make_config(ndc, n_coarse, n_fine, n_sec, train, noise_std=0.0, lindisp=Fals
     return c
 
 
-def packed_bytes() -> int:
-    return L.load().vipnerf_packed_weights_bytes()
+PRECISIONS = {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2}
 
 
-def pack_weights(params: List[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def packed_bytes(precision: int = 0) -> int:
+    return L.load().vipnerf_packed_weights_bytes_p(int(precision))
+
+
+def pack_weights(params: List[torch.Tensor], out: Optional[torch.Tensor] = None, precision: int = 0) -> torch.Tensor:
     """params: the 24 tensors of one MLP in PARAM_ORDER."""
     lib = L.load()
     if len(params) != L.VIPNERF_N_PARAMS:
@@ -64,8 +68,8 @@ def pack_weights(params: List[torch.Tensor], out: Optional[torch.Tensor] = None)
         keep.append(tc)
         mp.p[i] = _p(tc, name=PARAM_ORDER[i])
     if out is None:
-        out = torch.empty(packed_bytes() // 4, dtype=torch.float32, device=params[0].device)
-    L.check(lib.vipnerf_pack_weights(C.byref(mp), _p(out), _stream()), 'vipnerf_pack_weights')
+        out = torch.empty(packed_bytes(precision) // 4, dtype=torch.float32, device=params[0].device)
+    L.check(lib.vipnerf_pack_weights_p(C.byref(mp), int(precision), _p(out), _stream()), 'vipnerf_pack_weights_p')
     return out
 
 
@@ -222,7 +226,7 @@ def sample_fine(z_coarse, w_coarse, n_fine, u=None):
     return zf, inds, zs
 
 
-def mlp_forward(packed, pts, view_dirs, view_dirs2=None, noise=None, noise_std=1.0):
+def mlp_forward(packed, pts, view_dirs, view_dirs2=None, noise=None, noise_std=1.0, precision=0):
     P = pts.shape[0]
     V = 0 if view_dirs2 is None else view_dirs2.shape[1]
     dev = pts.device
@@ -234,8 +238,8 @@ def mlp_forward(packed, pts, view_dirs, view_dirs2=None, noise=None, noise_std=1
     vis2 = e(P, V) if V > 0 else None
     if P == 0:
         return {'sigma': sigma, 'rgb': rgb, 'visibility': vis, 'visibility2': vis2}
-    L.check(L.load().vipnerf_mlp_forward(P, V, _p(pts), _p(vd), _p(vd2), _p(nz), float(noise_std), _p(packed),
-                                         _p(sigma), _p(rgb), _p(vis), _p(vis2), _stream()), 'vipnerf_mlp_forward')
+    L.check(L.load().vipnerf_mlp_forward_p(P, V, _p(pts), _p(vd), _p(vd2), _p(nz), float(noise_std), int(precision),
+                                           _p(packed), _p(sigma), _p(rgb), _p(vis), _p(vis2), _stream()), 'vipnerf_mlp_forward_p')
     return {'sigma': sigma, 'rgb': rgb, 'visibility': vis, 'visibility2': vis2}
 
 

@@ -65,7 +65,7 @@ typedef struct vipnerf_config {
     int32_t given_z_fine; /* parity tests (teacher forcing): out->fine.z_vals already holds the fine depths on
                              entry; importance sampling is skipped.  0 in production. */
     int32_t perturb;      /* configs['model']['perturb'] && training: stratified jitter + random inverse-CDF draws */
-    int32_t precision;    /* VIPNERF_PREC_*: arithmetic of the MLP GEMMs (forward; backward GEMMs are fp32) */
+    int32_t precision;    /* VIPNERF_PREC_*: arithmetic of the MLP GEMMs */
     int32_t reserved[4];
 } vipnerf_config;
 

@@ -75,7 +75,7 @@ KEYMAP = {'rgb': 'rgb', 'acc': 'acc', 'depth': 'depth', 'depth_var': 'depth_var'
           'raw_visibility': 'raw_vis', 'raw_visibility2': 'raw_vis2'}
 
 
-def grad_close(a, ref, what, scale=0.0):
+def grad_close(a, ref, what, scale=0.0, l2_tol=2e-3):
     """Gradients are sums over ~1e4..1e6 fp32 products in a different order, and a ReLU whose pre-activation sits
     within rounding of 0 may fall on the other side in the two implementations (a single point's contribution then
     appears/disappears).  So: relative L2 error <= 2e-3 and no element off by more than 2 % of the largest."""
@@ -84,7 +84,7 @@ def grad_close(a, ref, what, scale=0.0):
     nrm = max(np.linalg.norm(ref), scale * np.sqrt(ref.size), 1e-30)
     l2 = np.linalg.norm(a - ref) / nrm
     mx = np.abs(a - ref).max() / max(np.abs(ref).max(), scale, 1e-30)
-    assert l2 <= 2e-3 and mx <= 2e-2, f'{what}: rel L2 err {l2:.3e}, max err / max|g| {mx:.3e}'
+    assert l2 <= l2_tol and mx <= 10 * l2_tol, f'{what}: rel L2 err {l2:.3e}, max err / max|g| {mx:.3e}'
 
 
 # ------------------------------------------------------------------------------------------------ stage-wise

@@ -11,6 +11,7 @@ from models.ModelFactory import get_model
 from loss_functions.LossComputerHip01 import LossComputerHip
 dev = torch.device('cuda:0')
 cfg = bench.model_configs()
+cfg['model']['hip_precision'] = os.environ.get('HIP_PRECISION', 'fp32')
 torch.manual_seed(0)
 model = get_model(cfg, None).to(dev).train()
 lossc = LossComputerHip(cfg)
@@ -26,4 +27,4 @@ K = 5
 for _ in range(K): step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
 pr = ops.profile_read()
-print(os.environ.get('VIPNERF_HIP_LIB', 'default'), 'step %.2f ms |' % (dt * 1e3), ' '.join('%s %.2f' % (k, v[1] / K) for k, v in sorted(pr.items()) if v[1] / K > 0.05))
+print(os.environ.get('VIPNERF_HIP_LIB', 'default'), cfg['model']['hip_precision'], 'step %.2f ms |' % (dt * 1e3), ' '.join('%s %.2f' % (k, v[1] / K) for k, v in sorted(pr.items()) if v[1] / K > 0.05))

@@ -69,6 +69,7 @@ static int check_cfg(const vipnerf_config *cfg) {
 }
 
 int launch_mlp_fwd_bf16(const MlpFwdArgs &a, int precision, hipStream_t st);
+int launch_mlp_bwd_bf16(const MlpBwdArgs &a, int precision, hipStream_t st);
 
 static int launch_mlp_fwd_any(MlpFwdArgs &a, int precision, hipStream_t st) {
     if (precision == VIPNERF_PREC_FP32) return launch_mlp_fwd(a, st);
@@ -333,10 +334,12 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
         mb.bwd = bw; mb.bl = bl;
         {
             ProfScope ps(lv ? "mlp_dgrad_fine" : "mlp_dgrad_coarse", st);
-            if ((rc = launch_mlp_bwd(mb, st))) return rc;
+            if (cfg->precision == VIPNERF_PREC_FP32) rc = launch_mlp_bwd(mb, st);
+            else { mb.packed += PK_TOTAL_F; rc = launch_mlp_bwd_bf16(mb, cfg->precision, st); }
+            if (rc) return rc;
         }
         // 3. weight gradients: dW = dY^T H as MFMA GEMMs over the point axis
-        if ((rc = launch_wgrad(P, V, mb.acts, mb.al, bw, bl, G, st))) return rc;
+        if ((rc = launch_wgrad(P, V, mb.acts, mb.al, bw, bl, G, cfg->precision, st))) return rc;
     }
     return VIPNERF_OK;
 }

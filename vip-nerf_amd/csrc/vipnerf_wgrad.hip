@@ -157,6 +157,139 @@ __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
     }
 }
 
+
+// The 256x256 class on split-precision bf16 MFMA ("bf16x3": hi/lo parts, 3 cross terms, fp32 accumulate).  The fp32
+// rows of A and B are split while they are staged: a thread holds 4 features x 8 points of each operand (its linear
+// 16 B/lane tile loads), converts them to two bf16 planes and writes, per feature and plane, the 8 points as ONE
+// 16-byte LDS store -- the transposition the fragment needs (lane = feature, 8 consecutive k = points) happens in
+// that write.  LDS plane layout: [feature][4 slots of 8 points], slot XOR-swizzled by (feature >> 2) & 3 so that
+// the 16-lane groups of ds_read_b128 hit 16 distinct slots.  The order of the 32 points inside a block is a fixed
+// permutation (slot = loading wave), identical for A and B, which a contraction index may be.
+__global__ __launch_bounds__(256) void k_wgrad_bf16x3(WgArgs a) {
+    constexpr int MTW = 2, KTW = 8, Mp = 256, Kp = 256;
+    constexpr int PLANE = 256 * 64;                       // bytes: one operand, one part, 256 features x 32 points
+    constexpr int BUF = 4 * PLANE;                        // A hi, A lo, B hi, B lo
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char *lb = (char *)lds;
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+    const WgDesc &d = a.d[blockIdx.y];
+    if ((int)blockIdx.x >= d.n_chunks) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int64_t p0 = (int64_t)blockIdx.x * a.chunk_pts;
+    const int64_t p1 = p0 + a.chunk_pts < a.P ? p0 + a.chunk_pts : a.P;
+    const int nblk = (int)((p1 - p0 + 31) / 32);
+
+    floatx16 acc[MTW][KTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int j = 0; j < KTW; ++j) acc[i][j] = (floatx16)(0.f);
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};                   // column sums of A for this thread's 4 features (its 8 points per block)
+
+    float4 ra[8], rb[8];                                  // rows wave + 4 i, features 4 (tid & 63) .. + 3
+    auto gload = [&](int blk) {
+        const int64_t pb = p0 + (int64_t)blk * 32;
+        if (pb + 32 <= p1) {
+            const float4 *ta = (const float4 *)(d.A + (size_t)pb * Mp) + tid;
+            const float4 *tb = (const float4 *)(d.B + (size_t)pb * Kp) + tid;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { ra[i] = ta[256 * i]; rb[i] = tb[256 * i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t row = pb + wave + 4 * i;
+                const bool ok = row < p1;
+                ra[i] = ok ? *((const float4 *)(d.A + (size_t)row * Mp) + lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[i] = ok ? *((const float4 *)(d.B + (size_t)row * Kp) + lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto put = [&](char *plane, int f, const float (&x)[8]) {   // 8 points of feature f -> hi / lo planes
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { hi[e] = (__bf16)x[e]; lo[e] = (__bf16)(x[e] - (float)hi[e]); }
+        const int off = f * 64 + ((wave ^ ((f >> 2) & 3)) << 4);
+        *(bf16x8 *)(plane + off) = hi;
+        *(bf16x8 *)(plane + PLANE + off) = lo;
+    };
+    auto lstore = [&](int buf) {
+        char *base = lb + buf * BUF;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float xa[8], xb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                xa[i] = c == 0 ? ra[i].x : (c == 1 ? ra[i].y : (c == 2 ? ra[i].z : ra[i].w));
+                xb[i] = c == 0 ? rb[i].x : (c == 1 ? rb[i].y : (c == 2 ? rb[i].z : rb[i].w));
+                bs[c] += xa[i];
+            }
+            put(base, 4 * lane + c, xa);
+            put(base + 2 * PLANE, 4 * lane + c, xb);
+        }
+    };
+
+    if (nblk > 0) { gload(0); lstore(0); }
+    __syncthreads();
+    int cur = 0;
+    for (int blk = 0; blk < nblk; ++blk) {
+        if (blk + 1 < nblk) gload(blk + 1);
+        const char *base = lb + cur * BUF;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int slot = 2 * ks + h;
+            bf16x8 af[MTW][2], bf[KTW][2];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+                const int f = 32 * (wave * MTW + i) + l31;
+                const int off = f * 64 + ((slot ^ ((f >> 2) & 3)) << 4);
+                af[i][0] = *(const bf16x8 *)(base + off);
+                af[i][1] = *(const bf16x8 *)(base + PLANE + off);
+            }
+#pragma unroll
+            for (int j = 0; j < KTW; ++j) {
+                const int f = 32 * j + l31;
+                const int off = f * 64 + ((slot ^ ((f >> 2) & 3)) << 4);
+                bf[j][0] = *(const bf16x8 *)(base + 2 * PLANE + off);
+                bf[j][1] = *(const bf16x8 *)(base + 3 * PLANE + off);
+            }
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                for (int j = 0; j < KTW; ++j) {
+                    floatx16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        }
+        if (blk + 1 < nblk) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    float *part = a.partial + d.part_off + (size_t)blockIdx.x * d.part_stride;
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int ot = wave * MTW + i;
+#pragma unroll
+        for (int j = 0; j < KTW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * h;
+                part[(size_t)o * Kp + 32 * j + l31] = acc[i][j][r];
+            }
+    }
+    // bias column sums: every wave holds the sums of ITS points for all 256 features -> fold the 4 waves through LDS
+    float *red = (float *)lb;                              // all fragment reads are behind the loop's last barrier
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[wave * 256 + 4 * lane + c] = bs[c];
+    __syncthreads();
+    part[(size_t)Mp * Kp + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+}
+
 __global__ void k_wgrad_reduce(WgReduceArgs a) {
     const WgGroup &g = a.g[blockIdx.y];
     const int n_w = g.m_valid * g.k_valid;
@@ -194,7 +327,7 @@ static int launch_class(const WgArgs &args, int n_desc, int n_chunks, hipStream_
 }
 
 int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float *bwd, const BwdLayout &bl,
-                 const vipnerf_mlp_grads *G, hipStream_t st) {
+                 const vipnerf_mlp_grads *G, int precision, hipStream_t st) {
     if (P == 0) return VIPNERF_OK;
     const int n_chunks = wgrad_chunks(P), n_small = wgrad_chunks_small(P);
     const int chunk_pts = wgrad_chunk_pts(P), chunk_small = chunk_pts / WGRAD_SMALL_SPLIT;
@@ -276,7 +409,14 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
     int rc;
     {
         ProfScope ps("wgrad_256x256", st);
-        if ((rc = launch_class<2, 8, 4>(c88, n88, n_chunks, st))) return rc;
+        if (precision == VIPNERF_PREC_FP32) {
+            if ((rc = launch_class<2, 8, 4>(c88, n88, n_chunks, st))) return rc;
+        } else {                                   // bf16x3 and bf16x6 both use the hi/lo kernel for the weight gradients
+            const size_t ldsb = (size_t)2 * 4 * 256 * 64;
+            VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+            hipLaunchKernelGGL(k_wgrad_bf16x3, dim3(n_chunks, n88), dim3(256), ldsb, st, c88);
+            VN_HIP(hipGetLastError());
+        }
     }
     ProfScope ps("wgrad_small", st);
     if ((rc = launch_class<1, 8, 4>(c48, n48, n_small, st))) return rc;

@@ -27,6 +27,13 @@ sys.path.insert(0, os.path.join(ROOT, 'vip-nerf_amd', 'src'))
 MAC_PER_POINT = 630272          # trunk+sigma+feature 556,800 + 2 x 36,736 view-branch evaluations (V = 1)
 POINTS_PER_RAY = 64 + 192
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
+# fp32-equivalent peak of each arithmetic: the split modes spend 6 / 3 bf16 MFMAs per fp32 multiply-add
+PEAK = {'fp32': (FP32_MFMA_PEAK_TFLOPS, 'fp32 MFMA peak (v_mfma_f32_32x32x2_f32)'),
+        'bf16x6': (BF16_MFMA_PEAK_TFLOPS / 6, 'dense bf16 MFMA peak 2500 TFLOP/s / 6 cross terms per fp32-grade product'),
+        'bf16x3': (BF16_MFMA_PEAK_TFLOPS / 3, 'dense bf16 MFMA peak 2500 TFLOP/s / 3 cross terms per product')}
+DTYPE = {'fp32': 'f32', 'bf16x6': 'f32 via 3-way bf16 split (6 bf16 MFMAs per product, fp32 accumulate; fp32-grade error)',
+         'bf16x3': 'f32 via 2-way bf16 split (3 bf16 MFMAs per product, fp32 accumulate; ~5e-6 relative error)'}
 
 
 def model_configs(n_views=2):
@@ -82,6 +89,9 @@ def main():
     ap.add_argument('--cpu-rays', type=int, default=1024)
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--no-render', action='store_true')
+    ap.add_argument('--precision', default='bf16x6', choices=['fp32', 'bf16x6', 'bf16x3'],
+                    help='MLP GEMM arithmetic of the headline number (all three are parity-tested; see DESIGN.md)')
+    ap.add_argument('--no-other-precisions', action='store_true')
     args = ap.parse_args()
 
     from vipnerf_hip import dist as vdist
@@ -97,6 +107,7 @@ def main():
     from loss_functions.LossComputerHip01 import LossComputerHip
 
     cfg = model_configs()
+    cfg['model']['hip_precision'] = args.precision
     torch.manual_seed(0)
     model = get_model(cfg, None).to(dev)
     vdist.broadcast_parameters(model)
@@ -159,21 +170,40 @@ def main():
     dom = max(stage_ms, key=stage_ms.get)
     flop_per_launch = MAC_PER_POINT * 2.0 * POINTS_PER_RAY * args.rays
     achieved = flop_per_launch / (stage_ms[dom] * 1e-3) / 1e12 if stage_ms[dom] > 0 else 0.0
-    roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+    peak, peak_note = PEAK[args.precision]
+    roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': round(peak, 1),
+                'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': None, 'peak_note': peak_note,
+                'frac_of_fp32_mfma_peak': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                 'stage_ms_per_step': {k: round(v, 3) for k, v in stage_ms.items()},
                 'other_kernels_ms_per_step': round(other_ms, 3),
-                'step_flop_frac': round(3 * flop_per_launch / (elapsed / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+                'step_flop_frac': round(3 * flop_per_launch / (elapsed / args.steps) / 1e12 / peak, 4)}
 
     result = {
         'metric': 'train_rays_per_sec', 'value': round(value, 1), 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE[args.precision], 'data': 'synthetic',
         'config': {'workload': 'LLFF-fern 2-view geometry, %d rays/iter/GPU x (64+128) samples, coarse+fine 8x256 MLP, '
                                'V=1 secondary view, losses MSE+Visibility+VisibilityPrior, Adam' % args.rays,
-                   'rays_per_gpu': args.rays, 'parallelism': f'ray-sharded dp{world}'},
+                   'rays_per_gpu': args.rays, 'parallelism': f'ray-sharded dp{world}', 'gemm_arithmetic': args.precision},
         'roofline': roofline,
     }
+
+    if world == 1 and not args.no_other_precisions:
+        # the same step in the other two arithmetics (10 steps each, same process, same batches)
+        others = {}
+        for prec in ('fp32', 'bf16x6', 'bf16x3'):
+            if prec == args.precision:
+                continue
+            model.configs['model']['hip_precision'] = prec
+            for i in range(3):
+                step(i)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for i in range(10):
+                step(args.warmup + i)
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+            others[prec] = {'rays_per_sec': round(args.rays / dt, 1), 'ms_per_step': round(dt * 1e3, 3)}
+        model.configs['model']['hip_precision'] = args.precision
+        result['other_precisions'] = others
 
     if world == 1 and not args.no_render:
         # full-frame eval render, camera -> uint8 image on the GPU (756 x 1008 rays, no secondary views):

@@ -132,7 +132,7 @@ struct BwdLayout {
 };
 // wgrad work split: the point axis is cut into chunks; every (GEMM, chunk) pair is one workgroup that writes
 // its partial product to `partial`, then an ordered reduction sums the chunks (deterministic, no atomics).
-constexpr int WGRAD_CHUNK_PTS = 4096;
+constexpr int WGRAD_CHUNK_PTS = 8192;
 constexpr int WGRAD_MAX_CHUNKS = 256;
 __host__ __device__ inline int wgrad_chunks(size_t P) {
     size_t c = (P + WGRAD_CHUNK_PTS - 1) / WGRAD_CHUNK_PTS;

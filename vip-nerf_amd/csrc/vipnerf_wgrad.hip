@@ -290,7 +290,43 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16x3(WgArgs a) {
     part[(size_t)Mp * Kp + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
 }
 
-__global__ void k_wgrad_reduce(WgReduceArgs a) {
+// Ordered sum over chunks.  A workgroup of 256 threads handles 64 consecutive output elements: thread (e, q) sums
+// every 4th chunk starting at q (4 independent load streams per element), the four partial sums are folded in a
+// fixed order through LDS -> deterministic, and 4x the memory-level parallelism of one thread per element.
+__global__ __launch_bounds__(256) void k_wgrad_reduce(WgReduceArgs a) {
+    __shared__ float sh[4][64];
+    const WgGroup &g = a.g[blockIdx.y];
+    const int n_w = g.m_valid * g.k_valid;
+    const int n_all = n_w + (g.dbias ? g.m_valid : 0);
+    const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
+    for (int e0 = blockIdx.x * 64; e0 < n_all; e0 += gridDim.x * 64) {
+        const int e = e0 + el;
+        float s = 0.f;
+        size_t off = 0;
+        float *dst = nullptr;
+        if (e < n_all) {
+            if (e < n_w) {
+                const int m = e / g.k_valid, k = e % g.k_valid;
+                off = (size_t)m * g.Kp + k;
+                dst = g.dW + (size_t)m * g.ldw + g.col_off + k;
+            } else {
+                const int m = e - n_w;
+                off = (size_t)g.Mp * g.Kp + m;
+                dst = g.dbias + m;
+            }
+            for (int dd = 0; dd < g.n_desc; ++dd) {
+                const float *pp = a.partial + g.part_off + (size_t)dd * g.desc_stride + off;
+                for (int c = q; c < g.n_chunks; c += 4) s += pp[(size_t)c * g.part_stride];
+            }
+        }
+        sh[q][el] = s;
+        __syncthreads();
+        if (q == 0 && e < n_all) *dst = (sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el]);
+        __syncthreads();
+    }
+}
+
+__global__ void k_wgrad_reduce_old(WgReduceArgs a) {
     const WgGroup &g = a.g[blockIdx.y];
     const int n_w = g.m_valid * g.k_valid;
     const int n_all = n_w + (g.dbias ? g.m_valid : 0);
@@ -424,7 +460,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
     if ((rc = launch_class<1, 1, 4>(c41, n41, n_small, st))) return rc;
     if ((rc = launch_class<1, 2, 1>(c18, n18, n_small, st))) return rc;
     if ((rc = launch_class<1, 1, 1>(c14, n14, n_small, st))) return rc;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(256, ng), dim3(256), 0, st, red);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(512, ng), dim3(256), 0, st, red);
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;
 }

@@ -55,7 +55,12 @@ ProfScope::~ProfScope() {
     if (idx < (int)g_recs.size()) hipEventRecord(g_recs[idx].e1, st);
 }
 
+// hipGetLastError() is sticky per thread: an error left behind by an unrelated earlier HIP call (e.g. a probe while
+// the device was still waking up) must not be reported as the failure of one of our launches.
+static inline void clear_stale_hip_error() { (void)hipGetLastError(); }
+
 static int check_cfg(const vipnerf_config *cfg) {
+    clear_stale_hip_error();
     if (!cfg) { set_error("cfg is NULL"); return VIPNERF_E_ARG; }
     if (cfg->n_coarse < 32 || cfg->n_coarse > 256 || cfg->n_coarse % 32) {
         set_error("n_coarse=%d unsupported (multiple of 32 in [32,256])", cfg->n_coarse); return VIPNERF_E_UNSUPPORTED; }
@@ -125,6 +130,7 @@ int32_t vipnerf_last_error(char *buf, size_t n) {
 size_t vipnerf_packed_weights_bytes(void) { return PK_TOTAL_F * sizeof(float); }
 
 int32_t vipnerf_pack_weights(const vipnerf_mlp_params *params, void *packed, vipnerf_stream_t stream) {
+    clear_stale_hip_error();
     if (!params || !packed) { set_error("pack_weights: NULL argument"); return VIPNERF_E_ARG; }
     for (int i = 0; i < VIPNERF_N_PARAMS; ++i)
         if (!params->p[i]) { set_error("pack_weights: parameter %d is NULL", i); return VIPNERF_E_ARG; }
@@ -157,6 +163,7 @@ int32_t vipnerf_query_workspace(const vipnerf_config *cfg, int64_t n_rays, size_
 
 int32_t vipnerf_coarse_depths(int64_t n_rays, int32_t n_samples, int32_t lindisp, const float *near,
                               const float *far, const float *t_rand, float *z_out, vipnerf_stream_t stream) {
+    clear_stale_hip_error();
     if (!near || !far || !z_out) { set_error("coarse_depths: NULL argument"); return VIPNERF_E_ARG; }
     if (n_samples < 2) { set_error("coarse_depths: n_samples < 2"); return VIPNERF_E_UNSUPPORTED; }
     return launch_coarse_z(n_rays, n_samples, lindisp, near, far, t_rand, 0, 0, 0, z_out, (hipStream_t)stream);
@@ -165,6 +172,7 @@ int32_t vipnerf_coarse_depths(int64_t n_rays, int32_t n_samples, int32_t lindisp
 int32_t vipnerf_sample_fine(int64_t n_rays, int32_t n_coarse, int32_t n_fine, const float *z_coarse,
                             const float *weights_coarse, const float *u, float *z_fine, int32_t *inds,
                             float *z_samples, vipnerf_stream_t stream) {
+    clear_stale_hip_error();
     if (!z_coarse || !weights_coarse || !z_fine) { set_error("sample_fine: NULL argument"); return VIPNERF_E_ARG; }
     if (n_coarse < 3 || n_fine < 1 || n_coarse + n_fine > 1024) { set_error("sample_fine: unsupported sizes"); return VIPNERF_E_UNSUPPORTED; }
     SampleArgs a;
@@ -185,6 +193,7 @@ int32_t vipnerf_mlp_forward_p(int64_t n_points, int32_t n_sec, const float *pts,
                               const float *view_dirs2, const float *noise, float noise_std, int32_t precision,
                               const void *packed, float *sigma, float *rgb, float *vis, float *vis2,
                               vipnerf_stream_t stream) {
+    clear_stale_hip_error();
     if (precision < 0 || precision > VIPNERF_PREC_BF16X6) { set_error("mlp_forward: precision=%d unsupported", precision); return VIPNERF_E_UNSUPPORTED; }
     if (n_points == 0) return VIPNERF_OK;
     if (!pts || !view_dirs || !packed || !sigma || !rgb || !vis || (n_sec > 0 && (!view_dirs2 || !vis2))) {
@@ -370,6 +379,7 @@ int32_t vipnerf_losses_forward(const vipnerf_config *cfg, int64_t n_rays, const 
 
 int32_t vipnerf_generate_rays(const vipnerf_raygen *gen, int64_t n_rays, const vipnerf_ray_batch *out,
                               vipnerf_stream_t stream) {
+    clear_stale_hip_error();
     if (!gen || !out || !gen->cameras || !out->rays_o || !out->rays_d) { set_error("generate_rays: NULL argument"); return VIPNERF_E_ARG; }
     if (gen->height <= 0 || gen->width <= 0 || gen->n_frames <= 0 || n_rays < 0) { set_error("generate_rays: bad sizes"); return VIPNERF_E_ARG; }
     if (gen->ndc && (!out->rays_o_ndc || !out->rays_d_ndc)) { set_error("generate_rays: ndc set but NDC outputs are NULL"); return VIPNERF_E_ARG; }
@@ -383,6 +393,7 @@ int32_t vipnerf_postprocess_frame(int64_t n_pixels, const float *rgb, const floa
                                   const float *depth_ndc, const float *depth_var_ndc, uint8_t *image,
                                   float *o_depth, float *o_depth_var, float *o_depth_ndc, float *o_depth_var_ndc,
                                   vipnerf_stream_t stream) {
+    clear_stale_hip_error();
     if (n_pixels < 0) { set_error("postprocess_frame: n_pixels < 0"); return VIPNERF_E_ARG; }
     ProfScope ps("postprocess", (hipStream_t)stream);
     return launch_postprocess(n_pixels, rgb, depth, depth_var, depth_ndc, depth_var_ndc, image, o_depth, o_depth_var,
@@ -391,6 +402,7 @@ int32_t vipnerf_postprocess_frame(int64_t n_pixels, const float *rgb, const floa
 
 int32_t vipnerf_visibility_prior(const vipnerf_psv *psv, double *weights64, float *weights32, uint8_t *mask,
                                  vipnerf_stream_t stream) {
+    clear_stale_hip_error();
     if (!psv || !psv->planes || !psv->frame1 || !psv->frame2) { set_error("visibility_prior: NULL argument"); return VIPNERF_E_ARG; }
     if (psv->height <= 0 || psv->width <= 0 || psv->n_planes <= 0 || !(psv->temperature > 0)) { set_error("visibility_prior: bad sizes"); return VIPNERF_E_ARG; }
     ProfScope ps("visibility_prior", (hipStream_t)stream);

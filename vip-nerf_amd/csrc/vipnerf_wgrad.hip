@@ -326,31 +326,6 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgReduceArgs a) {
     }
 }
 
-__global__ void k_wgrad_reduce_old(WgReduceArgs a) {
-    const WgGroup &g = a.g[blockIdx.y];
-    const int n_w = g.m_valid * g.k_valid;
-    const int n_all = n_w + (g.dbias ? g.m_valid : 0);
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_all; e += gridDim.x * blockDim.x) {
-        size_t off;
-        float *dst;
-        if (e < n_w) {
-            const int m = e / g.k_valid, k = e % g.k_valid;
-            off = (size_t)m * g.Kp + k;
-            dst = g.dW + (size_t)m * g.ldw + g.col_off + k;
-        } else {
-            const int m = e - n_w;
-            off = (size_t)g.Mp * g.Kp + m;
-            dst = g.dbias + m;
-        }
-        float s = 0.f;
-        for (int dd = 0; dd < g.n_desc; ++dd) {
-            const float *pp = a.partial + g.part_off + (size_t)dd * g.desc_stride + off;
-            for (int c = 0; c < g.n_chunks; ++c) s += pp[(size_t)c * g.part_stride];
-        }
-        *dst = s;
-    }
-}
-
 template <int MTW, int KTW, int WAVES_M>
 static int launch_class(const WgArgs &args, int n_desc, int n_chunks, hipStream_t st) {
     if (n_desc == 0) return VIPNERF_OK;

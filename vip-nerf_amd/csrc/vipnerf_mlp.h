@@ -194,7 +194,6 @@ __device__ __forceinline__ void secondary_dir(const PointSrc &s, const PointCtx 
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
-
 // C/D-fragment <-> row-major [P][ld] helpers: lane (point j, half h) owns, for tile t and register group q,
 // the 4 consecutive features 32t + 8q + 4h .. +3 = registers 4q..4q+3 of acc[t].
 template <int NT>

@@ -158,6 +158,162 @@ __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
 }
 
 
+// Weight-gradient GEMMs on split-precision bf16 MFMA ("bf16x3": hi/lo parts, 3 cross terms, fp32 accumulate),
+// for M = 32*MT, K = 32*KT with MT in {4, 8} (4 waves split the M tiles), KT in {2, 8}.  The fp32 rows of A and B
+// are split while they are staged: a staging task is (4 consecutive features, one 8-point slot); the thread loads
+// those 8 float4, converts to two bf16 planes and writes, per feature and plane, the 8 points as ONE 16-byte LDS
+// store -- the transposition the fragment needs (lane = feature, 8 consecutive k = points) happens in that write.
+// LDS plane layout: [feature][4 slots of 8 points], slot XOR-swizzled by (feature >> 2) & 3 so that the 16-lane
+// groups of ds_read_b128 hit 16 distinct slots.  Point q of a 32-point block sits in slot q & 3, element q >> 2:
+// a fixed permutation of the contraction index, identical for A and B.
+template <int MT, int KT>
+__global__ __launch_bounds__(256) void k_wgrad_bf16x3(WgArgs a) {
+    constexpr int MTW = MT / 4, Mp = 32 * MT, Kp = 32 * KT;
+    constexpr int PA = Mp * 64, PB = Kp * 64;             // bytes of one plane (one part) of A / B
+    constexpr int BUF = 2 * PA + 2 * PB;                  // A hi, A lo, B hi, B lo
+    constexpr int TA = Mp / 4 * 4, TB = Kp / 4 * 4;       // staging tasks: (features / 4) x 4 slots = Mp, Kp
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char *lb = (char *)lds;
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+    const WgDesc &d = a.d[blockIdx.y];
+    if ((int)blockIdx.x >= d.n_chunks) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int64_t p0 = (int64_t)blockIdx.x * a.chunk_pts;
+    const int64_t p1 = p0 + a.chunk_pts < a.P ? p0 + a.chunk_pts : a.P;
+    const int nblk = (int)((p1 - p0 + 31) / 32);
+
+    floatx16 acc[MTW][KT];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int j = 0; j < KT; ++j) acc[i][j] = (floatx16)(0.f);
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};                   // column sums of A: this thread's 4 features over its slot's points
+
+    // task of this thread for A / B: feature group c (features 4c..4c+3) and slot sl (points sl + 4e, e = 0..7)
+    const bool hasA = tid < TA, hasB = tid < TB;
+    const int cA = tid % (Mp / 4), slA = tid / (Mp / 4), cB = tid % (Kp / 4), slB = tid / (Kp / 4);
+    float4 ra[8], rb[8];
+    const bool fullA = d.m_load == Mp, fullB = d.k_load == Kp;
+    auto gload = [&](int blk) {
+        const int64_t pb = p0 + (int64_t)blk * 32;
+        if (pb + 32 <= p1 && fullA && fullB) {             // whole block in range, all columns valid: no predication
+            if (hasA) {
+                const float4 *ta = (const float4 *)(d.A + (size_t)(pb + slA) * d.lda) + cA;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ra[e] = ta[(size_t)e * d.lda];          // rows slA + 4e: 4*lda floats = lda float4
+            }
+            if (hasB) {
+                const float4 *tb = (const float4 *)(d.B + (size_t)(pb + slB) * d.ldb) + cB;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rb[e] = tb[(size_t)e * d.ldb];
+            }
+            return;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t rA = pb + slA + 4 * e, rB = pb + slB + 4 * e;
+            ra[e] = (hasA && rA < p1 && 4 * cA < d.m_load) ? *((const float4 *)(d.A + (size_t)rA * d.lda) + cA) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[e] = (hasB && rB < p1 && 4 * cB < d.k_load) ? *((const float4 *)(d.B + (size_t)rB * d.ldb) + cB) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto put = [&](char *plane, int psize, int f, int sl, const float (&x)[8]) {   // 8 points of feature f -> hi / lo planes
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { hi[e] = (__bf16)x[e]; lo[e] = (__bf16)(x[e] - (float)hi[e]); }
+        const int off = f * 64 + ((sl ^ ((f >> 2) & 3)) << 4);
+        *(bf16x8 *)(plane + off) = hi;
+        *(bf16x8 *)(plane + psize + off) = lo;
+    };
+    auto lstore = [&](int buf) {
+        char *base = lb + buf * BUF;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float xa[8], xb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                xa[i] = c == 0 ? ra[i].x : (c == 1 ? ra[i].y : (c == 2 ? ra[i].z : ra[i].w));
+                xb[i] = c == 0 ? rb[i].x : (c == 1 ? rb[i].y : (c == 2 ? rb[i].z : rb[i].w));
+                bs[c] += xa[i];
+            }
+            if (hasA) put(base, PA, 4 * cA + c, slA, xa);
+            if (hasB) put(base + 2 * PA, PB, 4 * cB + c, slB, xb);
+        }
+    };
+
+    if (nblk > 0) { gload(0); lstore(0); }
+    __syncthreads();
+    int cur = 0;
+    for (int blk = 0; blk < nblk; ++blk) {
+        if (blk + 1 < nblk) gload(blk + 1);
+        const char *base = lb + cur * BUF;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int slot = 2 * ks + h;
+            bf16x8 af[MTW][2], bf[KT][2];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+                const int f = 32 * (wave * MTW + i) + l31;
+                const int off = f * 64 + ((slot ^ ((f >> 2) & 3)) << 4);
+                af[i][0] = *(const bf16x8 *)(base + off);
+                af[i][1] = *(const bf16x8 *)(base + PA + off);
+            }
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {
+                const int f = 32 * j + l31;
+                const int off = f * 64 + ((slot ^ ((f >> 2) & 3)) << 4);
+                bf[j][0] = *(const bf16x8 *)(base + 2 * PA + off);
+                bf[j][1] = *(const bf16x8 *)(base + 2 * PA + PB + off);
+            }
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                for (int j = 0; j < KT; ++j) {
+                    floatx16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        }
+        if (blk + 1 < nblk) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    float *part = a.partial + d.part_off + (size_t)blockIdx.x * d.part_stride;
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int ot = wave * MTW + i;
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * h;
+                part[(size_t)o * Kp + 32 * j + l31] = acc[i][j][r];
+            }
+    }
+    // bias column sums: each A task holds the sums of ITS slot's points for 4 features -> fold the 4 slots through LDS
+    float *red = (float *)lb;                              // all fragment reads are behind the loop's last barrier
+    if (hasA)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[slA * Mp + 4 * cA + c] = bs[c];
+    __syncthreads();
+    if (tid < Mp) part[(size_t)Mp * Kp + tid] = (red[tid] + red[Mp + tid]) + (red[2 * Mp + tid] + red[3 * Mp + tid]);
+}
+
+template <int MT, int KT>
+static int launch_bf16x3(const WgArgs &args, int n_desc, int n_chunks, hipStream_t st) {
+    if (n_desc == 0) return VIPNERF_OK;
+    const size_t ldsb = (size_t)2 * 2 * (32 * MT + 32 * KT) * 64;
+    VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_bf16x3<MT, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    hipLaunchKernelGGL((k_wgrad_bf16x3<MT, KT>), dim3(n_chunks, n_desc), dim3(256), ldsb, st, args);
+    VN_HIP(hipGetLastError());
+    return VIPNERF_OK;
+}
+
+// The 256x256 class (8 of the 14 GEMMs, 95 % of the work), hand-specialised: compile-time strides, linear tile loads.
 // The 256x256 class on split-precision bf16 MFMA ("bf16x3": hi/lo parts, 3 cross terms, fp32 accumulate).  The fp32
 // rows of A and B are split while they are staged: a thread holds 4 features x 8 points of each operand (its linear
 // 16 B/lane tile loads), converts them to two bf16 planes and writes, per feature and plane, the 8 points as ONE
@@ -165,7 +321,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
 // that write.  LDS plane layout: [feature][4 slots of 8 points], slot XOR-swizzled by (feature >> 2) & 3 so that
 // the 16-lane groups of ds_read_b128 hit 16 distinct slots.  The order of the 32 points inside a block is a fixed
 // permutation (slot = loading wave), identical for A and B, which a contraction index may be.
-__global__ __launch_bounds__(256) void k_wgrad_bf16x3(WgArgs a) {
+__global__ __launch_bounds__(256) void k_wgrad_bf16x3_256(WgArgs a) {
     constexpr int MTW = 2, KTW = 8, Mp = 256, Kp = 256;
     constexpr int PLANE = 256 * 64;                       // bytes: one operand, one part, 256 features x 32 points
     constexpr int BUF = 4 * PLANE;                        // A hi, A lo, B hi, B lo
@@ -424,14 +580,19 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
             if ((rc = launch_class<2, 8, 4>(c88, n88, n_chunks, st))) return rc;
         } else {                                   // bf16x3 and bf16x6 both use the hi/lo kernel for the weight gradients
             const size_t ldsb = (size_t)2 * 4 * 256 * 64;
-            VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-            hipLaunchKernelGGL(k_wgrad_bf16x3, dim3(n_chunks, n88), dim3(256), ldsb, st, c88);
+            VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_bf16x3_256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+            hipLaunchKernelGGL(k_wgrad_bf16x3_256, dim3(n_chunks, n88), dim3(256), ldsb, st, c88);
             VN_HIP(hipGetLastError());
         }
     }
     ProfScope ps("wgrad_small", st);
-    if ((rc = launch_class<1, 8, 4>(c48, n48, n_small, st))) return rc;
-    if ((rc = launch_class<2, 2, 4>(c82, n82, n_small, st))) return rc;
+    if (precision == VIPNERF_PREC_FP32) {
+        if ((rc = launch_class<1, 8, 4>(c48, n48, n_small, st))) return rc;
+        if ((rc = launch_class<2, 2, 4>(c82, n82, n_small, st))) return rc;
+    } else {
+        if ((rc = launch_bf16x3<4, 8>(c48, n48, n_small, st))) return rc;
+        if ((rc = launch_bf16x3<8, 2>(c82, n82, n_small, st))) return rc;
+    }
     if ((rc = launch_class<1, 1, 4>(c41, n41, n_small, st))) return rc;
     if ((rc = launch_class<1, 2, 1>(c18, n18, n_small, st))) return rc;
     if ((rc = launch_class<1, 1, 1>(c14, n14, n_small, st))) return rc;

@@ -118,12 +118,7 @@ struct WStreamT {
     __device__ __forceinline__ void fetch(int b) {
         // CH chunks over 4 waves
         constexpr int PER_WAVE = CH / 4;
-        const float *src = g + (wave * PER_WAVE) * CHUNK_F + lane * 4;
-        float *dst = buf + b * SF + (wave * PER_WAVE) * CHUNK_F;
-#pragma unroll
-        for (int i = 0; i < PER_WAVE; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * CHUNK_F),
-                                             (__attribute__((address_space(3))) void *)(dst + i * CHUNK_F), 16, 0, 0);
+        glds_run<PER_WAVE>(g + (wave * PER_WAVE) * CHUNK_F + lane * 4, buf + b * SF + (wave * PER_WAVE) * CHUNK_F);
         g += SF;
         --n_left;
     }
@@ -132,13 +127,69 @@ struct WStreamT {
         fetch(0);
     }
     __device__ __forceinline__ const float *next() {
+        const float *ret = wait();
+        prefetch();
+        return ret;
+    }
+    // the two halves of next(): wait() = barrier, returns the stage to consume; prefetch() = start the DMA of the
+    // stage after it into the buffer every wave has just left.  gemm_stage_bf issues its first fragment reads
+    // between the two so that their LDS latency covers the DMA issue sequence.
+    __device__ __forceinline__ const float *wait() {
+        glds_drain();
         __syncthreads();
         const float *ret = buf + cur * SF;
         cur ^= 1;
-        if (n_left > 0) fetch(cur);
         return ret;
     }
+    __device__ __forceinline__ void prefetch() {
+        if (n_left > 0) fetch(cur);
+    }
 };
+
+// One stage of a layer, software-pipelined by hand: the stage's (k-step, tile) cells are walked in groups of two
+// tiles; the A fragments of the group D steps ahead are read from LDS while the MFMAs of the current group issue,
+// with scheduling barriers so the compiler keeps that order (left alone it sinks every read next to its MFMA and
+// waits lgkmcnt(0) per tile, which leaves the MFMA pipe idle half the time at one wave per SIMD).  The lead is
+// 12 MFMAs = 384 cycles for both NS against ~100-200 cycles of ds_read_b128 latency; the reads in flight stay
+// <= 12 because lgkmcnt is a 4-bit counter (with 16 outstanding the compiler falls back to lgkmcnt(0)).
+//   acc[t] += A(ks, t) * B[ks0 + ks],  chunk index (ks * NT + t) * NS + part
+template <int NT, int NKS, int NS, int NB, typename WS>
+__device__ __forceinline__ void gemm_stage_bf(const float *stage, int lane, floatx16 (&acc)[NT],
+                                              const bf16x8 (&B)[NB][NS], int ks0, WS *ws) {
+    constexpr int G = 2;
+    constexpr int D = NS == 2 ? 2 : 1;
+    constexpr int NBUF = D + 1;
+    constexpr int NG = NKS * NT / G;
+    static_assert(NT % G == 0 && NG >= D, "group shape");
+    bf16x8 fr[NBUF][G][NS];
+    const float *base = stage + lane * 4;
+#pragma unroll
+    for (int g = 0; g < D; ++g)
+#pragma unroll
+        for (int tt = 0; tt < G; ++tt)
+#pragma unroll
+            for (int i = 0; i < NS; ++i) fr[g][tt][i] = *(const bf16x8 *)(base + ((g * G + tt) * NS + i) * CHUNK_F);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ws) ws->prefetch();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + D < NG) {
+#pragma unroll
+            for (int tt = 0; tt < G; ++tt)
+#pragma unroll
+                for (int i = 0; i < NS; ++i)
+                    fr[(g + D) % NBUF][tt][i] = *(const bf16x8 *)(base + (((g + D) * G + tt) * NS + i) * CHUNK_F);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tt = 0; tt < G; ++tt) {
+            const int lin = g * G + tt, ks = lin / NT, t = lin % NT;
+            acc[t] = mfma_split<NS>(fr[g % NBUF][tt], B[ks0 + ks], acc[t]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 #endif
 
 int launch_pack_bf16(const vipnerf_mlp_params *p, int precision, void *packed_bf, hipStream_t st);

@@ -202,6 +202,48 @@ __device__ __forceinline__ float wave_rscan_add(float v, int lane) {   // inclus
     return v;
 }
 
+// LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = one 1 KiB chunk per instruction), N consecutive chunks.
+// Issued from inline asm on purpose: with the builtin hipcc sees a pending FLAT access for as long as the DMA is
+// in flight (= the whole stage) and degrades every LDS wait to lgkmcnt(0), which serialises the ds_read -> MFMA
+// pipeline of the consumer.  The statement has no VGPR destination, so it is register-safe; its completion is
+// the caller's job (s_waitcnt vmcnt(0) before the barrier that publishes the stage, see WStream::wait).
+// `lds_dst` is the wave-uniform LDS byte address of chunk 0, `gsrc` this lane's 16 bytes of chunk 0; the
+// instruction offset advances the global and the LDS address together (chunks are 1 KiB apart in both).
+template <int N>
+__device__ __forceinline__ void glds_chunks(const float *gsrc, unsigned lds_dst) {
+    static_assert(N >= 1 && N <= 4, "13-bit instruction offset: at most 4 chunks per base");
+    unsigned keep;
+    if (N == 4)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    else if (N == 3)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    else if (N == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// PER_WAVE consecutive chunks from gsrc (this lane's pointer into chunk 0) to the LDS address of dst
+template <int PER_WAVE>
+__device__ __forceinline__ void glds_run(const float *gsrc, const float *dst) {
+    const unsigned d0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dst);
+#pragma unroll
+    for (int i = 0; i + 4 <= PER_WAVE; i += 4) glds_chunks<4>(gsrc + i * CHUNK_F, d0 + i * CHUNK_F * 4);
+    constexpr int REM = PER_WAVE % 4, DONE = PER_WAVE - REM;
+    if (REM) glds_chunks<REM ? REM : 1>(gsrc + DONE * CHUNK_F, d0 + DONE * CHUNK_F * 4);
+}
+// all outstanding LDS-DMA (and stores) of this wave have landed
+__device__ __forceinline__ void glds_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // Philox4x32-10 (Salmon et al. 2011): one 128-bit counter -> four 32-bit words.
 __device__ __forceinline__ uint4 philox4x32(uint4 c, uint2 k) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;

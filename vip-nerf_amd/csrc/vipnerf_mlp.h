@@ -68,12 +68,7 @@ struct WStream {
 
     __device__ __forceinline__ void fetch(int b) {
         constexpr int PER_WAVE = STAGE_CHUNKS / 4;
-        const float *src = g + (wave * PER_WAVE) * CHUNK_F + lane * 4;
-        float *dst = buf + b * STAGE_F + (wave * PER_WAVE) * CHUNK_F;
-#pragma unroll
-        for (int i = 0; i < PER_WAVE; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * CHUNK_F),
-                                             (__attribute__((address_space(3))) void *)(dst + i * CHUNK_F), 16, 0, 0);
+        glds_run<PER_WAVE>(g + (wave * PER_WAVE) * CHUNK_F + lane * 4, buf + b * STAGE_F + (wave * PER_WAVE) * CHUNK_F);
         g += STAGE_F;
         --n_left;
     }
@@ -88,6 +83,7 @@ struct WStream {
 #elif defined(VN_EXP) && VN_EXP == 4
         if (n_left == 1000) __syncthreads();      // timing experiment only (races): no barriers
 #else
+        glds_drain();                             // the DMA is issued from asm: hipcc does not wait for it
         __syncthreads();
 #endif
         const float *ret = buf + cur * STAGE_F;
@@ -113,6 +109,36 @@ __device__ __forceinline__ floatx16 mfma(float a, float b, floatx16 c) {
             { const int r_ = 4 * ((KG0) + gl_) + 3; acc[t_] = mfma(a_.w, BEXPR, acc[t_]); }         \
         }                                                                                           \
     }
+
+// The same product, software-pipelined by hand (see gemm_stage_bf in vipnerf_bf16.h for the why): cells are walked
+// in groups of two tiles, the float4 A fragments of the next group are in flight while this group's 8 MFMAs
+// (512 cycles) issue; the two tiles' MFMAs alternate so no accumulator is used back to back.  Per accumulator the
+// order of the additions is that of VN_GEMM_STAGE, so results are bit-identical.  bfun(r) = B row r.
+template <int NT, int NKG, typename BF>
+__device__ __forceinline__ void gemm_stage_f32(const float *stage, int lane, floatx16 (&acc)[NT], int kg0, BF bfun) {
+    constexpr int G = 2;
+    constexpr int NG = NKG * NT / G;
+    static_assert(NT % G == 0, "group shape");
+    float4 fr[2][G];
+    const float *base = stage + lane * 4;
+#pragma unroll
+    for (int tt = 0; tt < G; ++tt) fr[0][tt] = *(const float4 *)(base + tt * CHUNK_F);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int tt = 0; tt < G; ++tt) fr[(g + 1) & 1][tt] = *(const float4 *)(base + ((g + 1) * G + tt) * CHUNK_F);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int lin = g * G, gl = lin / NT, t0 = lin % NT, r0 = 4 * (kg0 + gl);
+        const float4 a0 = fr[g & 1][0], a1 = fr[g & 1][1];
+        acc[t0] = mfma(a0.x, bfun(r0), acc[t0]);         acc[t0 + 1] = mfma(a1.x, bfun(r0), acc[t0 + 1]);
+        acc[t0] = mfma(a0.y, bfun(r0 + 1), acc[t0]);     acc[t0 + 1] = mfma(a1.y, bfun(r0 + 1), acc[t0 + 1]);
+        acc[t0] = mfma(a0.z, bfun(r0 + 2), acc[t0]);     acc[t0 + 1] = mfma(a1.z, bfun(r0 + 2), acc[t0 + 1]);
+        acc[t0] = mfma(a0.w, bfun(r0 + 3), acc[t0]);     acc[t0 + 1] = mfma(a1.w, bfun(r0 + 3), acc[t0 + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 
 // ------------------------------------------------------------------------------------------- encodings
 // gamma_L(v): feature f < 3 -> v[f]; f = 3 + 6*l + 3*c + d -> (c ? cos : sin)(2^l v[d])   (VipNeRF01.py:424-448)

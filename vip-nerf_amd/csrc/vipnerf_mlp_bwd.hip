@@ -97,7 +97,7 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_bwd(MlpBwdArgs a) {
 #pragma unroll
     for (int jj = 0; jj < ST_VIEW_B; ++jj) {
         const float *st = ws.next();
-        VN_GEMM_STAGE(st, 8, KGS8, KGS8 * jj, acc, vsum[r_ >> 4][r_ & 15])
+        gemm_stage_f32<8, KGS8>(st, lane, acc, KGS8 * jj, [&](int r) { return vsum[r >> 4][r & 15]; });
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) in[t] = acc[t];
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_bwd(MlpBwdArgs a) {
 #pragma unroll
             for (int tt = 0; tt < 8 / ST_256; ++tt) store_tile(dy_dst, p, W, h, jj * (8 / ST_256) + tt, in[jj * (8 / ST_256) + tt], valid);
             __builtin_amdgcn_sched_barrier(0);
-            VN_GEMM_STAGE(st, 8, KGS8, KGS8 * jj, acc, in[r_ >> 4][r_ & 15])
+            gemm_stage_f32<8, KGS8>(st, lane, acc, KGS8 * jj, [&](int r) { return in[r >> 4][r & 15]; });
         }
         if (it == 0) {                                   // h_8 also feeds the sigma head
             const float *wsg = res + R_WSIG + h * 128;

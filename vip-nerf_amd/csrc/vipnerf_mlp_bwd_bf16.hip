@@ -102,8 +102,8 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_bwd_bf16(MlpBwdArgs a) {
     for (int t = 0; t < 8; ++t) acc[t] = (floatx16)(0.f);
 #pragma unroll
     for (int jj = 0; jj < PL::ST_VIEW_B; ++jj) {
-        const float *st = ws.next();
-        VN_GEMM_STAGE_BF(st, 8, PL::KSB, PL::KSB * jj, NS, acc, bin)
+        const float *st = ws.wait();
+        gemm_stage_bf<8, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, &ws);
     }
     // dY of the feature layer: store (fp32, for wgrad) and split
 #pragma unroll
@@ -127,8 +127,8 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_bwd_bf16(MlpBwdArgs a) {
         for (int t = 0; t < 8; ++t) acc[t] = (floatx16)(0.f);
 #pragma unroll
         for (int jj = 0; jj < PL::ST_256; ++jj) {
-            const float *st = ws.next();
-            VN_GEMM_STAGE_BF(st, 8, PL::KSB, PL::KSB * jj, NS, acc, bin)
+            const float *st = ws.wait();
+            gemm_stage_bf<8, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, &ws);
         }
         float *dst = a.bwd + a.bl.dy[layer];
 #pragma unroll

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_fwd(MlpFwdArgs a) {
 #pragma unroll
             for (int jj = 0; jj < ST_PE; ++jj) {
                 const float *st = ws.next();
-                VN_GEMM_STAGE(st, 8, KGS8, KGS8 * jj, acc, pe[r_])
+                gemm_stage_f32<8, KGS8>(st, lane, acc, KGS8 * jj, [&](int r) { return pe[r]; });
             }
         }
         if (layer != 0) {
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_fwd(MlpFwdArgs a) {
                         store_tile(a.acts + a.al.h[layer - 1], p, W, h, jj * (8 / ST_256) + tt, in[jj * (8 / ST_256) + tt], valid);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                VN_GEMM_STAGE(st, 8, KGS8, KGS8 * jj, acc, in[r_ >> 4][r_ & 15])
+                gemm_stage_f32<8, KGS8>(st, lane, acc, KGS8 * jj, [&](int r) { return in[r >> 4][r & 15]; });
             }
         }
         if (layer < 8) {
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_fwd(MlpFwdArgs a) {
                 store_tile(a.acts + a.al.feat, p, W, h, jj * (8 / ST_VIEW_F) + tt, in[jj * (8 / ST_VIEW_F) + tt], valid);
             __builtin_amdgcn_sched_barrier(0);
         }
-        VN_GEMM_STAGE(st, 4, KGS4, KGS4 * jj, vb, in[r_ >> 4][r_ & 15])
+        gemm_stage_f32<4, KGS4>(st, lane, vb, KGS4 * jj, [&](int r) { return in[r >> 4][r & 15]; });
     }
 
     for (int dsel = 0; dsel <= a.src.V; ++dsel) {
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_fwd(MlpFwdArgs a) {
         floatx16 g[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) g[t] = vb[t];
-        VN_GEMM_STAGE(res + R_DIRW, 4, 4, 0, g, ped[r_])
+        gemm_stage_f32<4, 4>(res + R_DIRW, lane, g, 0, [&](int r) { return ped[r]; });
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll

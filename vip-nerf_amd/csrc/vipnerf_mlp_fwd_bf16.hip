@@ -83,15 +83,15 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_fwd_bf16(MlpFwdArgs a) {
             for (int s = 0; s < 4; ++s) split8<NS>(pe[s], bpe[s]);
 #pragma unroll
             for (int jj = 0; jj < PL::ST_PE; ++jj) {
-                const float *st = ws.next();
-                VN_GEMM_STAGE_BF(st, 8, PL::KSB, PL::KSB * jj, NS, acc, bpe)
+                const float *st = ws.wait();
+                gemm_stage_bf<8, PL::KSB, NS>(st, lane, acc, bpe, PL::KSB * jj, &ws);
             }
         }
         if (layer != 0) {
 #pragma unroll
             for (int jj = 0; jj < PL::ST_256; ++jj) {
-                const float *st = ws.next();
-                VN_GEMM_STAGE_BF(st, 8, PL::KSB, PL::KSB * jj, NS, acc, bin)
+                const float *st = ws.wait();
+                gemm_stage_bf<8, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, &ws);
             }
         }
         // epilogue: ReLU (trunk), activation store, mask, sigma head, split into the next layer's B fragments
@@ -152,8 +152,8 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_fwd_bf16(MlpFwdArgs a) {
     for (int t = 0; t < 4; ++t) vb[t] = *(const floatx16 *)(rf + R_BVIEW + t * 32 + h * 16);
 #pragma unroll
     for (int jj = 0; jj < PL::ST_VIEW_F; ++jj) {
-        const float *st = ws.next();
-        VN_GEMM_STAGE_BF(st, 4, PL::KSV, PL::KSV * jj, NS, vb, bin)
+        const float *st = ws.wait();
+        gemm_stage_bf<4, PL::KSV, NS>(st, lane, vb, bin, PL::KSV * jj, &ws);
     }
 
 #pragma unroll 1
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_fwd_bf16(MlpFwdArgs a) {
         floatx16 g[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) g[t] = vb[t];
-        VN_GEMM_STAGE_BF(res + PL::R_DIRW, 4, 2, 0, NS, g, bpd)
+        gemm_stage_bf<4, 2, NS>(res + PL::R_DIRW, lane, g, bpd, 0, (WStreamT<PL::CH> *)nullptr);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll

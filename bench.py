@@ -113,7 +113,7 @@ def main():
     vdist.broadcast_parameters(model)
     model.train()
     lossc = LossComputerHip(cfg)
-    opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.999))
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.999), fused=True)   # same update, one kernel
     bucket = vdist.FlatGradBucket(model.parameters())
 
     n_batches = args.steps + args.warmup
@@ -123,7 +123,7 @@ def main():
     def step(i):
         b = dict(batches[i])
         b['common_data'] = {'poses': batches[i]['common_data']['poses']}
-        bucket.zero()
+        bucket.release()
         out = model(b)
         losses = lossc.compute_losses(b, out)
         losses['TotalLoss'].backward()

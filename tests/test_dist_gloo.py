@@ -57,6 +57,27 @@ def worker(rank, world, port, ret):
     assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views)), 'grads left the bucket'
     bucket.all_reduce_mean()
     ret[rank] = bucket.flat.clone().numpy()
+    # (b) gradients dropped first (release): the oracle's backward leaves 48 separate tensors, which the bucket
+    #     gathers before its single collective
+    bucket.release()
+    step_grads(model, batch, rng, vdist.shard_rows(N_RAYS, rank, world))
+    assert bucket.adopted() is None
+    bucket.all_reduce_mean()
+    ret[f'gathered{rank}'] = torch.cat([p.grad.reshape(-1) for p in bucket.params]).numpy()
+    # (c) gradients handed over as consecutive views of one foreign buffer (what the HIP backward returns): reduced
+    #     in place, no copy
+    bucket.release()
+    step_grads(model, batch, rng, vdist.shard_rows(N_RAYS, rank, world))
+    foreign = torch.cat([p.grad.reshape(-1) for p in bucket.params])
+    o = 0
+    for p in bucket.params:
+        p.grad = foreign[o:o + p.numel()].view_as(p)
+        o += p.numel()
+    adopted = bucket.adopted()
+    assert adopted is not None and adopted.data_ptr() == foreign.data_ptr() and adopted.numel() == foreign.numel()
+    bucket.all_reduce_mean()
+    assert bucket.params[0].grad.data_ptr() == foreign.data_ptr(), 'the adopted buffer must be reduced in place'
+    ret[f'adopted{rank}'] = foreign.numpy().copy()
     dist.destroy_process_group()
 
 
@@ -68,6 +89,9 @@ def test_two_rank_sharded_step_matches_single_process():
     ret = mgr.dict()
     mp.spawn(worker, args=(world, port, ret), nprocs=world, join=True)
     assert np.array_equal(ret[0], ret[1]), 'ranks disagree after the all-reduce'
+    for r in range(world):
+        assert np.array_equal(ret[f'gathered{r}'], ret[0]), 'gathered path differs from the in-bucket path'
+        assert np.array_equal(ret[f'adopted{r}'], ret[0]), 'adopted path differs from the in-bucket path'
     model = OracleModule(vo.init_params(5, scale=1.6))
     bucket = vdist.FlatGradBucket(model.parameters())
     bucket.zero()

@@ -298,6 +298,36 @@ def test_train_step_golden(dev, tag):
         np.testing.assert_allclose(digest(p)[2:], g['adig_' + k][2:], rtol=0, atol=1.1e-3, err_msg=f'{tag} Adam step of {k}')
 
 
+def test_gradients_arrive_in_one_flat_buffer(dev):
+    """With .grad dropped beforehand, the 48 parameter gradients of a step are consecutive views of ONE buffer
+    (no per-tensor fill / add / copy; one collective reduces it), and they equal the accumulate-into-bucket path."""
+    from loss_functions.LossComputerHip01 import LossComputerHip
+    from vipnerf_hip import dist as vdist
+    b = vo.synthetic_batch(384, 21, scene='fern', nf=2)
+    params = vo.init_params(9, scale=1.6)
+    model, cfg = make_model(dev, b['ndc'], params)
+    model.train()
+    lossc = LossComputerHip(cfg)
+    rng = {k: cu(v.numpy(), dev) for k, v in vo.synthetic_rng(384, 64, 128, 4).items()}
+    bucket = vdist.FlatGradBucket(model.parameters())
+
+    def run():
+        model.injected_rng = rng
+        rb = ref_batch(b, dev, 40000)
+        lossc.compute_losses(rb, model(rb))['TotalLoss'].backward()
+
+    bucket.zero()
+    run()
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+    ref = bucket.flat.clone()
+    bucket.release()
+    run()
+    flat = bucket.adopted()
+    assert flat is not None, 'gradients were copied instead of adopted'
+    assert flat.numel() == 1191946 and flat.data_ptr() == bucket.params[0].grad.data_ptr()
+    assert torch.equal(flat, ref), 'same kernels, same inputs: the two paths must agree bit for bit'
+
+
 def test_backward_all_cotangents_vs_oracle(dev):
     """Every differentiable output gets a random cotangent; parameter gradients vs the oracle's autograd."""
     n = 40

@@ -19,6 +19,10 @@ template <int NS>
 struct BfPlan {
     static constexpr int KSB = NS == 2 ? 4 : 2;              // k-steps (of 16) per stage for an 8-tile layer
     static constexpr int CH = KSB * 8 * NS;                  // chunks (1 KiB) per stage: 64 (NS=2) / 48 (NS=3)
+    // LDS stage ring; the DMA runs NBUF-1 stages ahead.  Measured: a deeper ring of smaller stages (4 x 32 KiB /
+    // 5 x 24 KiB) is SLOWER than 2 x 64 / 2 x 48 KiB -- the stream is bound by the CU's LDS-DMA rate
+    // (~23-25 GB/s), not by its latency, and the extra barriers cost more than the smoothing gains.
+    static constexpr int NBUF = 2;
     static constexpr int STAGE_F = CH * CHUNK_F;             // in float units
     static constexpr int ST_256 = 16 / KSB;                  // stages of a 256-deep contraction over 8 tiles
     static constexpr int ST_PE = 4 / KSB;                    // gamma(x): K = 64 -> 4 k-steps
@@ -49,7 +53,8 @@ struct BfPlan {
     static constexpr size_t PK_BWD = PK_FWD + (size_t)F_STAGES * STAGE_F;
     static constexpr size_t PK_RES = PK_BWD + (size_t)B_STAGES * STAGE_F;
     static constexpr size_t PK_TOTAL_F = PK_RES + R_TOTAL_PAD;
-    static constexpr int LDS_F = R_TOTAL_PAD + 2 * STAGE_F;
+    static constexpr int LDS_F = R_TOTAL_PAD + NBUF * STAGE_F;
+    static_assert(LDS_F * 4 <= 160 * 1024, "LDS budget");
 };
 
 // float offsets inside the packed buffer: [fp32 image][bf16x3 image] or [fp32 image][bf16x6 image]
@@ -66,6 +71,9 @@ __device__ __forceinline__ __bf16 split_part(float x, int i) {
 }
 template <int NS>
 __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&out)[NS]) {
+#if defined(VN_EXP) && VN_EXP == 6
+    if (x[0] != 12345.f) return;                  // timing experiment only: no operand split
+#endif
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         float r = x[e];
@@ -108,44 +116,70 @@ __device__ __forceinline__ floatx16 mfma_split(const bf16x8 (&a)[NS], const bf16
         }                                                                                                \
     }
 
-// weight stream with a compile-time stage size (chunks)
-template <int CH>
+// Weight stream: a ring of NBUF LDS stage buffers filled by LDS-DMA NBUF-1 stages ahead of the consumer.
+//   wait():     counted s_waitcnt (this wave's DMA of the stage to consume has landed; with NBUF > 2 the younger
+//               stages' stay in flight: VM_CNT retires in issue order, stores included) + raw s_barrier (every
+//               wave's part has landed, and every wave is done reading the stage consumed before)
+//   prefetch(): DMA of stage (current + NBUF-1) into the buffer that barrier has just freed
+template <int CH, int NBUF>
 struct WStreamT {
     const float *g;
     float *buf;
-    int n_left, cur, lane, wave;
+    int n_left;            // stages not yet requested
+    int in_flight;         // requested, not yet consumed
+    int cur, fill;         // ring slot to consume next / to fill next
+    int lane, wave;
     static constexpr int SF = CH * CHUNK_F;
-    __device__ __forceinline__ void fetch(int b) {
-        // CH chunks over 4 waves
-        constexpr int PER_WAVE = CH / 4;
-        glds_run<PER_WAVE>(g + (wave * PER_WAVE) * CHUNK_F + lane * 4, buf + b * SF + (wave * PER_WAVE) * CHUNK_F);
+    static constexpr int PER_WAVE = CH / 4;
+    static_assert(CH % 4 == 0 && PER_WAVE * (NBUF - 2) <= 63, "vmcnt is a 6-bit counter");
+    __device__ __forceinline__ void fetch() {
+#if defined(VN_EXP) && VN_EXP == 5
+        if (n_left < -1000)                       // timing experiment only: no weight DMA
+#endif
+        glds_run<PER_WAVE>(g + (wave * PER_WAVE) * CHUNK_F + lane * 4, buf + fill * SF + (wave * PER_WAVE) * CHUNK_F);
         g += SF;
         --n_left;
+        ++in_flight;
+        fill = fill + 1 == NBUF ? 0 : fill + 1;
     }
     __device__ __forceinline__ void start(const float *stream, int n_stages, float *lds_buf, int lane_, int wave_) {
-        g = stream; buf = lds_buf; n_left = n_stages; cur = 0; lane = lane_; wave = wave_;
-        fetch(0);
+        g = stream; buf = lds_buf; n_left = n_stages; in_flight = 0; cur = 0; fill = 0; lane = lane_; wave = wave_;
+#pragma unroll
+        for (int i = 0; i < NBUF - 1; ++i)
+            if (n_left > 0) fetch();
+    }
+    __device__ __forceinline__ void wait_landed() {
+        const int y = in_flight - 1;              // stages requested after the one about to be consumed
+        if (NBUF >= 5 && y >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER_WAVE) : "memory");
+        else if (NBUF >= 4 && y >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE) : "memory");
+        else if (NBUF >= 3 && y >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * PER_WAVE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __device__ __forceinline__ const float *wait() {
+        if (NBUF == 2) {
+            glds_drain();
+            __syncthreads();
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+            wait_landed();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float *ret = buf + cur * SF;
+        cur = cur + 1 == NBUF ? 0 : cur + 1;
+        --in_flight;
+        return ret;
+    }
+    __device__ __forceinline__ void prefetch() {
+        if (n_left > 0) fetch();
     }
     __device__ __forceinline__ const float *next() {
         const float *ret = wait();
         prefetch();
         return ret;
     }
-    // the two halves of next(): wait() = barrier, returns the stage to consume; prefetch() = start the DMA of the
-    // stage after it into the buffer every wave has just left.  gemm_stage_bf issues its first fragment reads
-    // between the two so that their LDS latency covers the DMA issue sequence.
-    __device__ __forceinline__ const float *wait() {
-        glds_drain();
-        __syncthreads();
-        const float *ret = buf + cur * SF;
-        cur ^= 1;
-        return ret;
-    }
-    __device__ __forceinline__ void prefetch() {
-        if (n_left > 0) fetch(cur);
-    }
 };
-
 // One stage of a layer, software-pipelined by hand: the stage's (k-step, tile) cells are walked in groups of two
 // tiles; the A fragments of the group D steps ahead are read from LDS while the MFMAs of the current group issue,
 // with scheduling barriers so the compiler keeps that order (left alone it sinks every read next to its MFMA and
@@ -153,9 +187,12 @@ struct WStreamT {
 // 12 MFMAs = 384 cycles for both NS against ~100-200 cycles of ds_read_b128 latency; the reads in flight stay
 // <= 12 because lgkmcnt is a 4-bit counter (with 16 outstanding the compiler falls back to lgkmcnt(0)).
 //   acc[t] += A(ks, t) * B[ks0 + ks],  chunk index (ks * NT + t) * NS + part
+struct NoStream {
+    __device__ __forceinline__ void prefetch() {}
+};
 template <int NT, int NKS, int NS, int NB, typename WS>
 __device__ __forceinline__ void gemm_stage_bf(const float *stage, int lane, floatx16 (&acc)[NT],
-                                              const bf16x8 (&B)[NB][NS], int ks0, WS *ws) {
+                                              const bf16x8 (&B)[NB][NS], int ks0, WS &ws) {
     constexpr int G = 2;
     constexpr int D = NS == 2 ? 2 : 1;
     constexpr int NBUF = D + 1;
@@ -170,7 +207,7 @@ __device__ __forceinline__ void gemm_stage_bf(const float *stage, int lane, floa
 #pragma unroll
             for (int i = 0; i < NS; ++i) fr[g][tt][i] = *(const bf16x8 *)(base + ((g * G + tt) * NS + i) * CHUNK_F);
     __builtin_amdgcn_sched_barrier(0);
-    if (ws) ws->prefetch();
+    ws.prefetch();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_bwd_bf16(MlpBwdArgs a) {
     const int64_t p = valid ? p_raw : a.src.P - 1;
     const int V = a.src.V;
 
-    WStreamT<PL::CH> ws;
+    WStreamT<PL::CH, PL::NBUF> ws;
     ws.start(a.packed + PL::PK_BWD, PL::B_STAGES, stage_buf, lane, wave);
     {
         const float4 *g4 = (const float4 *)(a.packed + PL::PK_RES);
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_bwd_bf16(MlpBwdArgs a) {
 #pragma unroll
     for (int jj = 0; jj < PL::ST_VIEW_B; ++jj) {
         const float *st = ws.wait();
-        gemm_stage_bf<8, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, &ws);
+        gemm_stage_bf<8, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
     }
     // dY of the feature layer: store (fp32, for wgrad) and split
 #pragma unroll
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_bwd_bf16(MlpBwdArgs a) {
 #pragma unroll
         for (int jj = 0; jj < PL::ST_256; ++jj) {
             const float *st = ws.wait();
-            gemm_stage_bf<8, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, &ws);
+            gemm_stage_bf<8, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
         }
         float *dst = a.bwd + a.bl.dy[layer];
 #pragma unroll

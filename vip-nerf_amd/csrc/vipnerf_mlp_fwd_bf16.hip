@@ -20,7 +20,11 @@ __device__ __forceinline__ void encode_bf(const float v[3], int h, float (&out)[
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             float s, c;
+#if defined(VN_EXP) && VN_EXP == 7
+            s = v[d] * (float)(1 << l); c = s + 1.f;   // timing experiment only: no sincos
+#else
             sincosf(v[d] * (float)(1 << l), &s, &c);
+#endif
             val[3 + 6 * l + d] = s;
             val[3 + 6 * l + 3 + d] = c;
         }
@@ -44,7 +48,7 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_fwd_bf16(MlpFwdArgs a) {
     const bool valid = p_raw < a.src.P;
     const int64_t p = valid ? p_raw : a.src.P - 1;
 
-    WStreamT<PL::CH> ws;
+    WStreamT<PL::CH, PL::NBUF> ws;
     ws.start(a.packed + PL::PK_FWD, PL::F_STAGES, stage_buf, lane, wave);
     {
         const float4 *g4 = (const float4 *)(a.packed + PL::PK_RES);
@@ -84,14 +88,14 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_fwd_bf16(MlpFwdArgs a) {
 #pragma unroll
             for (int jj = 0; jj < PL::ST_PE; ++jj) {
                 const float *st = ws.wait();
-                gemm_stage_bf<8, PL::KSB, NS>(st, lane, acc, bpe, PL::KSB * jj, &ws);
+                gemm_stage_bf<8, PL::KSB, NS>(st, lane, acc, bpe, PL::KSB * jj, ws);
             }
         }
         if (layer != 0) {
 #pragma unroll
             for (int jj = 0; jj < PL::ST_256; ++jj) {
                 const float *st = ws.wait();
-                gemm_stage_bf<8, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, &ws);
+                gemm_stage_bf<8, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
             }
         }
         // epilogue: ReLU (trunk), activation store, mask, sigma head, split into the next layer's B fragments
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_fwd_bf16(MlpFwdArgs a) {
 #pragma unroll
     for (int jj = 0; jj < PL::ST_VIEW_F; ++jj) {
         const float *st = ws.wait();
-        gemm_stage_bf<4, PL::KSV, NS>(st, lane, vb, bin, PL::KSV * jj, &ws);
+        gemm_stage_bf<4, PL::KSV, NS>(st, lane, vb, bin, PL::KSV * jj, ws);
     }
 
 #pragma unroll 1
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_fwd_bf16(MlpFwdArgs a) {
         floatx16 g[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) g[t] = vb[t];
-        gemm_stage_bf<4, 2, NS>(res + PL::R_DIRW, lane, g, bpd, 0, (WStreamT<PL::CH> *)nullptr);
+        { NoStream none; gemm_stage_bf<4, 2, NS>(res + PL::R_DIRW, lane, g, bpd, 0, none); }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll

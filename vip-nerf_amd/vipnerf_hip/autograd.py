@@ -55,6 +55,7 @@ class RenderFunction(torch.autograd.Function):
                         nondiff.append(d[k])
         state.keys = keys
         ctx.mark_non_differentiable(*nondiff)
+        ctx.set_materialize_grads(False)          # outputs no loss touches arrive as None (= NULL = zero in the ABI)
         ctx.state, ctx.coarse, ctx.fine, ctx.acts, ctx.packed = state, coarse, fine, acts, (pc, pf)
         ctx.n_params = len(params)
         return tuple(outs)
@@ -74,8 +75,20 @@ class RenderFunction(torch.autograd.Function):
         dev = ctx.coarse['rgb'].device
         _, bb = ops.query_workspace(cfg, n)
         bwd_ws = torch.empty(bb // 4, dtype=torch.float32, device=dev)
-        gc = [torch.empty(s, dtype=torch.float32, device=dev) for s in ops.PARAM_SHAPES]
-        gf = [torch.empty(s, dtype=torch.float32, device=dev) for s in ops.PARAM_SHAPES] if ctx.fine is not None else None
+        # all parameter gradients of the call live in ONE buffer, in parameter order (coarse, then fine): with
+        # .grad = None beforehand autograd adopts the views as they are (no per-tensor fill / add / copy), and
+        # dist.FlatGradBucket reduces the buffer with a single collective
+        sizes = [int(torch.Size(s).numel()) for s in ops.PARAM_SHAPES]
+        levels = 2 if ctx.fine is not None else 1
+        flat = torch.empty(levels * sum(sizes), dtype=torch.float32, device=dev)
+        views, o = [], 0
+        for _ in range(levels):
+            for s, k in zip(ops.PARAM_SHAPES, sizes):
+                views.append(flat[o:o + k].view(s))
+                o += k
+        gc = views[:len(sizes)]
+        gf = views[len(sizes):] if ctx.fine is not None else None
+        del views, flat
         ops.render_backward(cfg, state.batch, ctx.packed[0], ctx.packed[1], ctx.coarse, ctx.fine, gl['coarse'],
                             gl['fine'] if ctx.fine is not None else None, ctx.acts, bwd_ws, gc, gf)
         ctx.acts = None

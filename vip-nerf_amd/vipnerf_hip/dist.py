@@ -55,11 +55,42 @@ class FlatGradBucket:
         self.flat.zero_()
         self.attach()
 
+    def release(self):
+        """Alternative to zero(): drop the gradients (like optimizer.zero_grad(set_to_none=True)).  The HIP render's
+        backward returns all parameter gradients as consecutive views of one buffer, which autograd then adopts
+        as .grad without any fill / add / copy kernel; all_reduce_mean() reduces that buffer in place."""
+        for p in self.params:
+            p.grad = None
+
+    def adopted(self):
+        """The flat tensor the current .grad tensors are consecutive views of (parameter order), or None."""
+        g0 = self.params[0].grad
+        if g0 is None:
+            return None
+        st, o = g0.untyped_storage(), g0.storage_offset()
+        base = st.data_ptr()
+        for p in self.params:
+            g = p.grad
+            if (g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.storage_offset() != o
+                    or g.untyped_storage().data_ptr() != base):
+                return None
+            o += g.numel()
+        n = o - g0.storage_offset()
+        return torch.empty(0, dtype=torch.float32, device=g0.device).set_(st, g0.storage_offset(), (n,))
+
     def all_reduce_mean(self):
-        """sum over ranks, then 1/world.  No-op in a single process."""
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.mul_(1.0 / dist.get_world_size())
+        """sum over ranks, then 1/world, with ONE collective.  No-op in a single process."""
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        flat = self.flat
+        if self.params[0].grad is None or self.params[0].grad.data_ptr() != self.views[0].data_ptr():
+            flat = self.adopted()
+            if flat is None:                      # gradients scattered over separate tensors: gather into the bucket
+                torch._foreach_copy_(self.views, [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params])
+                self.attach()
+                flat = self.flat
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.mul_(1.0 / dist.get_world_size())
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0):

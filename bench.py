@@ -177,6 +177,18 @@ def main():
                 'stage_ms_per_step': {k: round(v, 3) for k, v in stage_ms.items()},
                 'other_kernels_ms_per_step': round(other_ms, 3),
                 'step_flop_frac': round(3 * flop_per_launch / (elapsed / args.steps) / 1e12 / peak, 4)}
+    # HBM bytes of the dominant stage per step: PMC counters cannot be collected from inside this process; the value
+    # is the committed rocprofv3 --pmc measurement of this very command (profiles/r01_pmc_traffic.json), used only
+    # when the workload matches the one profiled
+    try:
+        tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+        if tr['workload']['rays_per_gpu'] == args.rays and tr['workload']['precision'] == args.precision:
+            roofline['traffic'] = tr['bytes_per_step'][dom]['total']
+            roofline['traffic_note'] = ('HBM bytes per step of this stage, FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 '
+                                        '--pmc passes (profiles/r01_pmc_*_bf16x6.txt); algorithmic: 10.75 KB/point of '
+                                        'activation stores + one 3.5 MB weight image per 128 points from L2')
+    except (OSError, KeyError, ValueError):
+        pass
 
     result = {
         'metric': 'train_rays_per_sec', 'value': round(value, 1), 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,

@@ -180,6 +180,46 @@ struct WStreamT {
         return ret;
     }
 };
+// group g of a stage (see gemm_stage_bf): reads of group g+D interleaved one by one behind the first MFMAs of group
+// g, then this group's share of the next stage's DMA
+template <int g, int NG, int NT, int NS, int G, int D, int NBUF, int NB, typename WS>
+__device__ __forceinline__ void gemm_groups_bf(const float *base, floatx16 (&acc)[NT], const bf16x8 (&B)[NB][NS], int ks0,
+                                               bf16x8 (&fr)[NBUF][G][NS], WS &ws) {
+    if constexpr (g < NG) {
+        constexpr int R = (g + D < NG) ? G * NS : 0;           // ds_read_b128 in this group
+        constexpr int M = G * NS * (NS + 1) / 2;               // MFMAs in this group
+        if (g + D < NG) {
+#pragma unroll
+            for (int tt = 0; tt < G; ++tt)
+#pragma unroll
+                for (int i = 0; i < NS; ++i)
+                    fr[(g + D) % NBUF][tt][i] = *(const bf16x8 *)(base + (((g + D) * G + tt) * NS + i) * CHUNK_F);
+        }
+#pragma unroll
+        for (int tt = 0; tt < G; ++tt) {
+            const int lin = g * G + tt, ks = lin / NT, t = lin % NT;
+            acc[t] = mfma_split<NS>(fr[g % NBUF][tt], B[ks0 + ks], acc[t]);
+        }
+#ifndef VN_INTERLEAVE
+#define VN_INTERLEAVE 1
+#endif
+#pragma unroll
+        for (int i = 0; i < (VN_INTERLEAVE ? R : 0); ++i) {    // MFMA, read, MFMA, read, ...: each read issues in the
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);   // shadow of the MFMA before it (measured +3 % over
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // reads-then-MFMAs)
+        }
+        if (VN_INTERLEAVE) __builtin_amdgcn_sched_group_barrier(0x8, M - R, 0);
+        else { __builtin_amdgcn_sched_group_barrier(0x100, R, 0); __builtin_amdgcn_sched_group_barrier(0x8, M, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        // the next stage's DMA goes out as ONE burst behind the first group: a global_load_lds costs its wave ~60
+        // cycles of issue time; spread over the groups (one piece per group) the same 16 pieces measured 6-10 %
+        // SLOWER than the burst, and before/after the first reads makes no difference
+        if (g == 0) ws.prefetch();
+        __builtin_amdgcn_sched_barrier(0);
+        gemm_groups_bf<g + 1, NG, NT, NS, G, D, NBUF>(base, acc, B, ks0, fr, ws);
+    }
+}
+
 // One stage of a layer, software-pipelined by hand: the stage's (k-step, tile) cells are walked in groups of two
 // tiles; the A fragments of the group D steps ahead are read from LDS while the MFMAs of the current group issue,
 // with scheduling barriers so the compiler keeps that order (left alone it sinks every read next to its MFMA and
@@ -207,25 +247,7 @@ __device__ __forceinline__ void gemm_stage_bf(const float *stage, int lane, floa
 #pragma unroll
             for (int i = 0; i < NS; ++i) fr[g][tt][i] = *(const bf16x8 *)(base + ((g * G + tt) * NS + i) * CHUNK_F);
     __builtin_amdgcn_sched_barrier(0);
-    ws.prefetch();
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        if (g + D < NG) {
-#pragma unroll
-            for (int tt = 0; tt < G; ++tt)
-#pragma unroll
-                for (int i = 0; i < NS; ++i)
-                    fr[(g + D) % NBUF][tt][i] = *(const bf16x8 *)(base + (((g + D) * G + tt) * NS + i) * CHUNK_F);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int tt = 0; tt < G; ++tt) {
-            const int lin = g * G + tt, ks = lin / NT, t = lin % NT;
-            acc[t] = mfma_split<NS>(fr[g % NBUF][tt], B[ks0 + ks], acc[t]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    gemm_groups_bf<0, NG, NT, NS, G, D, NBUF>(base, acc, B, ks0, fr, ws);
 }
 #endif
 

@@ -20,8 +20,9 @@ struct BfPlan {
     static constexpr int KSB = NS == 2 ? 4 : 2;              // k-steps (of 16) per stage for an 8-tile layer
     static constexpr int CH = KSB * 8 * NS;                  // chunks (1 KiB) per stage: 64 (NS=2) / 48 (NS=3)
     // LDS stage ring; the DMA runs NBUF-1 stages ahead.  Measured: a deeper ring of smaller stages (4 x 32 KiB /
-    // 5 x 24 KiB) is SLOWER than 2 x 64 / 2 x 48 KiB -- the stream is bound by the CU's LDS-DMA rate
-    // (~23-25 GB/s), not by its latency, and the extra barriers cost more than the smoothing gains.
+    // 5 x 24 KiB) is SLOWER than 2 x 64 / 2 x 48 KiB -- the stream's cost is the issue time of its
+    // global_load_lds instructions (~60 cycles per 1 KiB piece with no second wave to feed the MFMA pipe), not its
+    // latency or fill rate, and the extra barriers cost more than the smoothing gains.
     static constexpr int NBUF = 2;
     static constexpr int STAGE_F = CH * CHUNK_F;             // in float units
     static constexpr int ST_256 = 16 / KSB;                  // stages of a 256-deep contraction over 8 tiles

@@ -8,7 +8,9 @@
 #include <string>
 #include <vector>
 
-#include "vipnerf_bf16.h"
+#include <cstdlib>
+#include <cstring>
+#include "vipnerf_bf16n.h"
 #include "vipnerf_camera.h"
 #include "vipnerf_mlp.h"
 #include "vipnerf_prof.h"
@@ -75,10 +77,34 @@ static int check_cfg(const vipnerf_config *cfg) {
 
 int launch_mlp_fwd_bf16(const MlpFwdArgs &a, int precision, hipStream_t st);
 int launch_mlp_bwd_bf16(const MlpBwdArgs &a, int precision, hipStream_t st);
+int launch_mlp_fwd_bf16n(const MlpFwdArgs &a, int precision, hipStream_t st);
+int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st);
+
+// The split-bf16 kernels exist in two lane layouts: "wide" (32-point waves, one per SIMD; vipnerf_bf16.h) and
+// "narrow" (16-point waves, two per SIMD; vipnerf_bf16n.h).  The packed buffer carries both images
+// ([fp32][wide][narrow]); VIPNERF_BF16_LAYOUT=wide|narrow picks the kernels (forward and data-gradient kernels
+// must agree: the ReLU masks are stored in fragment order).
+#ifndef VN_BF16_NARROW_DEFAULT
+#define VN_BF16_NARROW_DEFAULT 0
+#endif
+static bool bf16_narrow() {
+    static const int v = [] {
+        const char *e = getenv("VIPNERF_BF16_LAYOUT");
+        if (e && !strcmp(e, "narrow")) return 1;
+        if (e && !strcmp(e, "wide")) return 0;
+        return VN_BF16_NARROW_DEFAULT;
+    }();
+    return v != 0;
+}
+static size_t packed_floats_all(int precision) { return packed_total_floats(precision) + packed_narrow_floats(precision); }
 
 static int launch_mlp_fwd_any(MlpFwdArgs &a, int precision, hipStream_t st) {
     if (precision == VIPNERF_PREC_FP32) return launch_mlp_fwd(a, st);
-    a.packed += PK_TOTAL_F;                       // the split-bf16 image follows the fp32 image
+    if (bf16_narrow()) {
+        a.packed += packed_total_floats(precision);   // [fp32][wide] precede the narrow image
+        return launch_mlp_fwd_bf16n(a, precision, st);
+    }
+    a.packed += PK_TOTAL_F;                       // the wide split-bf16 image follows the fp32 image
     return launch_mlp_fwd_bf16(a, precision, st);
 }
 
@@ -137,13 +163,14 @@ int32_t vipnerf_pack_weights(const vipnerf_mlp_params *params, void *packed, vip
     return launch_pack(params, packed, (hipStream_t)stream);
 }
 
-size_t vipnerf_packed_weights_bytes_p(int32_t precision) { return packed_total_floats(precision) * sizeof(float); }
+size_t vipnerf_packed_weights_bytes_p(int32_t precision) { return packed_floats_all(precision) * sizeof(float); }
 
 int32_t vipnerf_pack_weights_p(const vipnerf_mlp_params *params, int32_t precision, void *packed, vipnerf_stream_t stream) {
     if (precision < 0 || precision > VIPNERF_PREC_BF16X6) { set_error("pack_weights: precision=%d unsupported", precision); return VIPNERF_E_UNSUPPORTED; }
     int rc = vipnerf_pack_weights(params, packed, stream);
     if (rc || precision == VIPNERF_PREC_FP32) return rc;
-    return launch_pack_bf16(params, precision, (float *)packed + PK_TOTAL_F, (hipStream_t)stream);
+    if ((rc = launch_pack_bf16(params, precision, (float *)packed + PK_TOTAL_F, (hipStream_t)stream))) return rc;
+    return launch_pack_bf16n(params, precision, (float *)packed + packed_total_floats(precision), (hipStream_t)stream);
 }
 
 int32_t vipnerf_query_workspace(const vipnerf_config *cfg, int64_t n_rays, size_t *acts_bytes, size_t *bwd_bytes) {
@@ -344,6 +371,7 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
         {
             ProfScope ps(lv ? "mlp_dgrad_fine" : "mlp_dgrad_coarse", st);
             if (cfg->precision == VIPNERF_PREC_FP32) rc = launch_mlp_bwd(mb, st);
+            else if (bf16_narrow()) { mb.packed += packed_total_floats(cfg->precision); rc = launch_mlp_bwd_bf16n(mb, cfg->precision, st); }
             else { mb.packed += PK_TOTAL_F; rc = launch_mlp_bwd_bf16(mb, cfg->precision, st); }
             if (rc) return rc;
         }

@@ -87,13 +87,18 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&out)[NS]) {
     }
 }
 
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ floatx16 mfma_bf(bf16x8 a, bf16x8 b, floatx16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// 16x16x32: lane l supplies A[i = l&15][k = 8*(l>>4) + e] and B[k = 8*(l>>4) + e][j = l&15]; D[i = 4*(l>>4) + r][j = l&15]
+__device__ __forceinline__ floatx4 mfma_bf(bf16x8 a, bf16x8 b, floatx4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 
 // acc[t] += A(k-step, tile) * B(k-step) over the significant cross terms; smallest terms first
-template <int NS>
-__device__ __forceinline__ floatx16 mfma_split(const bf16x8 (&a)[NS], const bf16x8 (&b)[NS], floatx16 c) {
+template <int NS, typename ACC>
+__device__ __forceinline__ ACC mfma_split(const bf16x8 (&a)[NS], const bf16x8 (&b)[NS], ACC c) {
     if (NS == 3) {
         c = mfma_bf(a[1], b[1], c);
         c = mfma_bf(a[2], b[0], c);
@@ -105,24 +110,12 @@ __device__ __forceinline__ floatx16 mfma_split(const bf16x8 (&a)[NS], const bf16
     return c;
 }
 
-// `stage` holds NKS k-steps x NT tiles x NS parts, chunk index (ks * NT + t) * NS + part; B[s] = the NS parts of
-// k-step s (global k-step index KS0 + ks)
-#define VN_GEMM_STAGE_BF(stage, NT, NKS, KS0, NS, acc, BARR)                                             \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < (NKS); ++ks_) {                                            \
-        _Pragma("unroll") for (int t_ = 0; t_ < (NT); ++t_) {                                            \
-            bf16x8 a_[NS];                                                                               \
-            _Pragma("unroll") for (int i_ = 0; i_ < (NS); ++i_)                                          \
-                a_[i_] = *(const bf16x8 *)((stage) + ((ks_ * (NT) + t_) * (NS) + i_) * CHUNK_F + lane * 4); \
-            acc[t_] = mfma_split<NS>(a_, BARR[(KS0) + ks_], acc[t_]);                                    \
-        }                                                                                                \
-    }
-
 // Weight stream: a ring of NBUF LDS stage buffers filled by LDS-DMA NBUF-1 stages ahead of the consumer.
 //   wait():     counted s_waitcnt (this wave's DMA of the stage to consume has landed; with NBUF > 2 the younger
 //               stages' stay in flight: VM_CNT retires in issue order, stores included) + raw s_barrier (every
 //               wave's part has landed, and every wave is done reading the stage consumed before)
 //   prefetch(): DMA of stage (current + NBUF-1) into the buffer that barrier has just freed
-template <int CH, int NBUF>
+template <int CH, int NBUF, int WAVES = 4>
 struct WStreamT {
     const float *g;
     float *buf;
@@ -131,8 +124,8 @@ struct WStreamT {
     int cur, fill;         // ring slot to consume next / to fill next
     int lane, wave;
     static constexpr int SF = CH * CHUNK_F;
-    static constexpr int PER_WAVE = CH / 4;
-    static_assert(CH % 4 == 0 && PER_WAVE * (NBUF - 2) <= 63, "vmcnt is a 6-bit counter");
+    static constexpr int PER_WAVE = CH / WAVES;
+    static_assert(CH % WAVES == 0 && PER_WAVE * (NBUF - 2) <= 63, "vmcnt is a 6-bit counter");
     __device__ __forceinline__ void fetch() {
 #if defined(VN_EXP) && VN_EXP == 5
         if (n_left < -1000)                       // timing experiment only: no weight DMA
@@ -183,8 +176,8 @@ struct WStreamT {
 };
 // group g of a stage (see gemm_stage_bf): reads of group g+D interleaved one by one behind the first MFMAs of group
 // g, then this group's share of the next stage's DMA
-template <int g, int NG, int NT, int NS, int G, int D, int NBUF, int NB, typename WS>
-__device__ __forceinline__ void gemm_groups_bf(const float *base, floatx16 (&acc)[NT], const bf16x8 (&B)[NB][NS], int ks0,
+template <int g, int NG, int NT, int NS, int G, int D, int NBUF, int NB, typename WS, typename ACC>
+__device__ __forceinline__ void gemm_groups_bf(const float *base, ACC (&acc)[NT], const bf16x8 (&B)[NB][NS], int ks0,
                                                bf16x8 (&fr)[NBUF][G][NS], WS &ws) {
     if constexpr (g < NG) {
         constexpr int R = (g + D < NG) ? G * NS : 0;           // ds_read_b128 in this group
@@ -231,8 +224,8 @@ __device__ __forceinline__ void gemm_groups_bf(const float *base, floatx16 (&acc
 struct NoStream {
     __device__ __forceinline__ void prefetch() {}
 };
-template <int NT, int NKS, int NS, int NB, typename WS>
-__device__ __forceinline__ void gemm_stage_bf(const float *stage, int lane, floatx16 (&acc)[NT],
+template <int NT, int NKS, int NS, int NB, typename WS, typename ACC>
+__device__ __forceinline__ void gemm_stage_bf(const float *stage, int lane, ACC (&acc)[NT],
                                               const bf16x8 (&B)[NB][NS], int ks0, WS &ws) {
     constexpr int G = 2;
     constexpr int D = NS == 2 ? 2 : 1;

@@ -1,0 +1,99 @@
+// "Narrow-wave" variant of the split-precision bf16 path (vipnerf_bf16.h): 16 points per wave on
+// v_mfma_f32_16x16x32_bf16, 8 waves (two per SIMD) and still 128 points per workgroup.
+//
+// Why: with one 32-point wave per SIMD (the wide layout) nothing feeds a SIMD's MFMA pipe while its only wave issues
+// the weight DMA (~60 cycles per 1 KiB piece), runs a layer's epilogue (bias/ReLU/mask/operand split: VALU) or sits
+// at the stage barrier -- 50-55 % of the bf16 kernels' time.  A 16-point wave needs half the
+// registers (64 accumulators + 64/96 operand registers), so two fit on a SIMD and cover for each other.  The price:
+// a 16x16x32 MFMA consumes a 1 KiB A fragment every 16 cycles instead of every 32, i.e. twice the LDS read traffic
+// (171 B/clk of 256 in bf16x3, 128 in bf16x6).
+//
+// Fragments.  lane l = (j = l & 15: point, q = l >> 4).  A: row i = l & 15 of a 16-feature tile, k = 8q + e (e = 0..7)
+// of a 32-deep k-step.  C/D of tile T: features 16T + 4q + r (r = 0..3) of point j.  A k-step therefore takes its B
+// operand from two consecutive C/D tiles of the previous layer: contraction index (s, q, e) of k-step s is feature
+//     feat16(s, q, e) = 16 (2s + (e >> 2)) + 4q + (e & 3),
+// so layers chain in registers exactly as in the wide layout, and biases / heads are read in natural feature order.
+#pragma once
+#include "vipnerf_bf16.h"
+
+namespace vn {
+
+__host__ __device__ constexpr int feat16(int s, int q, int e) { return 16 * (2 * s + (e >> 2)) + 4 * q + (e & 3); }
+
+template <int NS>
+struct BnPlan {
+    static constexpr int WAVES = 8;
+    static constexpr int WG = 64 * WAVES;
+    static constexpr int NT = 16;                            // 16-feature tiles of a 256-wide layer
+    static constexpr int KSB = NS == 2 ? 2 : 1;              // k-steps (of 32) per stage for a 16-tile layer
+    static constexpr int CH = KSB * NT * NS;                 // chunks (1 KiB) per stage: 64 (NS=2) / 48 (NS=3)
+    static constexpr int STAGE_F = CH * CHUNK_F;
+    static constexpr int NBUF = 2;
+    static constexpr int ST_256 = 8 / KSB;                   // 256-deep contraction = 8 k-steps
+    static constexpr int ST_PE = 2 / KSB;                    // gamma(x): K = 64 -> 2 k-steps
+    static constexpr int KSV = 2 * KSB;                      // k-steps per stage when a stage spans 8 tiles
+    static constexpr int ST_VIEW_F = 8 / KSV;                // view layer forward: 8 tiles x 8 k-steps
+    static constexpr int ST_VIEW_B = 4 / KSB;                // view layer dgrad: 16 tiles x 4 k-steps (K = 128)
+    static constexpr int FS_L0PE = 0;
+    static constexpr int FS_L1 = FS_L0PE + ST_PE;
+    static constexpr int FS_L5PE = FS_L1 + 4 * ST_256;
+    static constexpr int FS_L5 = FS_L5PE + ST_PE;
+    static constexpr int FS_L6 = FS_L5 + ST_256;
+    static constexpr int FS_L7 = FS_L6 + ST_256;
+    static constexpr int FS_FEAT = FS_L7 + ST_256;
+    static constexpr int FS_VIEW = FS_FEAT + ST_256;
+    static constexpr int F_STAGES = FS_VIEW + ST_VIEW_F;
+    static constexpr int BS_VIEW = 0;
+    static constexpr int BS_FEAT = BS_VIEW + ST_VIEW_B;
+    static constexpr int BS_L7 = BS_FEAT + ST_256;
+    static constexpr int B_STAGES = BS_L7 + 7 * ST_256;
+    // LDS-resident block: direction columns of the view layer as A fragments (1 k-step x 8 tiles x NS chunks), then
+    // the fp32 biases / heads in natural feature order
+    static constexpr int R_DIRW = 0;
+    static constexpr int R_DIRW_F = 8 * NS * CHUNK_F;
+    static constexpr int R_F32 = R_DIRW_F;
+    static constexpr int N_BIAS = 0;                         // [8 layers][256]
+    static constexpr int N_BFEAT = N_BIAS + 8 * W;
+    static constexpr int N_BVIEW = N_BFEAT + W;
+    static constexpr int N_WSIG = N_BVIEW + WV;
+    static constexpr int N_WOUT = N_WSIG + W;                // [4][128]
+    static constexpr int N_BHEAD = N_WOUT + 4 * WV;          // sigma bias, 4 output biases, pad
+    static constexpr int N_TOTAL = N_BHEAD + 8;
+    static constexpr int R_TOTAL = R_F32 + N_TOTAL;
+    static constexpr int R_TOTAL_PAD = (R_TOTAL + 255) / 256 * 256;
+    static constexpr size_t PK_FWD = 0;
+    static constexpr size_t PK_BWD = PK_FWD + (size_t)F_STAGES * STAGE_F;
+    static constexpr size_t PK_RES = PK_BWD + (size_t)B_STAGES * STAGE_F;
+    static constexpr size_t PK_TOTAL_F = PK_RES + R_TOTAL_PAD;
+    static constexpr int LDS_F = R_TOTAL_PAD + NBUF * STAGE_F;
+    static_assert(LDS_F * 4 <= 160 * 1024, "LDS budget");
+};
+
+__host__ __device__ inline size_t packed_narrow_floats(int precision) {
+    return precision == 1 ? BnPlan<2>::PK_TOTAL_F : (precision == 2 ? BnPlan<3>::PK_TOTAL_F : 0);
+}
+
+#if defined(__HIPCC__)
+// C/D tile T of a narrow fragment <-> row-major [P][ld]: lane (j, q) owns features 16T + 4q .. +3
+__device__ __forceinline__ void store_tile16(float *base, int64_t p, int ld, int q, int T, const floatx4 &v, bool valid) {
+    if (!valid) return;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 val = {v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(val, (f4 *)(base + (size_t)p * ld + 16 * T + 4 * q));
+}
+__device__ __forceinline__ floatx4 load_tile16(const float *base, int64_t p, int ld, int q, int T) {
+    const float4 f = *(const float4 *)(base + (size_t)p * ld + 16 * T + 4 * q);
+    floatx4 v = {f.x, f.y, f.z, f.w};
+    return v;
+}
+// two C/D tiles (2s, 2s+1) -> the NS-part B fragment of k-step s
+template <int NS>
+__device__ __forceinline__ void split_pair(const floatx4 &lo, const floatx4 &hi, bf16x8 (&out)[NS]) {
+    const float xs[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    split8<NS>(xs, out);
+}
+#endif
+
+int launch_pack_bf16n(const vipnerf_mlp_params *p, int precision, void *packed_bn, hipStream_t st);
+
+}  // namespace vn

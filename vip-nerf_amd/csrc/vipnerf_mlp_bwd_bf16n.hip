@@ -1,0 +1,161 @@
+// Data-gradient pass, narrow-wave layout (vipnerf_bf16n.h): vipnerf_mlp_bwd_bf16.hip with 16-point waves on
+// v_mfma_f32_16x16x32_bf16, two waves per SIMD.  A = W^T from the narrow packed image, B = the NS-part split of the
+// current dY; ReLU masks are the 64 bits per lane and layer the narrow forward wrote.
+#include "vipnerf_bf16n.h"
+#include "vipnerf_mlp.h"
+
+namespace vn {
+
+__device__ __forceinline__ bool mask_bit16(unsigned m0, unsigned m1, int t, int r) {
+    return ((t < 8 ? m0 >> (4 * t) : m1 >> (4 * (t - 8))) >> r) & 1u;
+}
+
+template <int NS>
+__global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) {
+    typedef BnPlan<NS> PL;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *res = lds;
+    float *stage_buf = lds + PL::R_TOTAL_PAD;
+    const float *rf = res + PL::R_F32;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, j = lane & 15;
+    const int64_t p_raw = (int64_t)blockIdx.x * MLP_PTS_PER_WG + wave * 16 + j;
+    const bool valid = p_raw < a.src.P;
+    const int64_t p = valid ? p_raw : a.src.P - 1;
+    const int V = a.src.V;
+
+    WStreamT<PL::CH, PL::NBUF, PL::WAVES> ws;
+    ws.start(a.packed + PL::PK_BWD, PL::B_STAGES, stage_buf, lane, wave);
+    {
+        const float4 *g4 = (const float4 *)(a.packed + PL::PK_RES);
+        float4 *l4 = (float4 *)res;
+        for (int i = tid; i < PL::R_TOTAL_PAD / 4; i += PL::WG) l4[i] = g4[i];
+    }
+
+    const float *gb = a.bwd;
+    float dq0[4];
+    {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float y = a.rgb[3 * p + c];
+            dq0[c] = gb[a.bl.drgb + 3 * p + c] * ((1.f - y) * y);
+        }
+        const float y = a.vis[p];
+        dq0[3] = gb[a.bl.dvis + p] * ((1.f - y) * y);
+    }
+    const float dsig_raw = a.sigma[p] > 0.f ? gb[a.bl.dsig + p] : 0.f;
+    __syncthreads();
+
+    // ---------------------------------------------------------------- view branch, per direction
+    floatx4 vsum[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) vsum[t] = (floatx4)(0.f);
+#pragma unroll 1
+    for (int dsel = 0; dsel <= V; ++dsel) {
+        float dq[4];
+        if (dsel == 0) { dq[0] = dq0[0]; dq[1] = dq0[1]; dq[2] = dq0[2]; dq[3] = dq0[3]; }
+        else {
+            const float y = a.vis2[p * V + (dsel - 1)];
+            dq[0] = dq[1] = dq[2] = 0.f;
+            dq[3] = gb[a.bl.dvis2 + p * V + (dsel - 1)] * ((1.f - y) * y);
+        }
+        if (valid && q == 0) {
+            float *row = a.bwd + a.bl.dq[dsel] + (size_t)p * 8;
+            *(float4 *)row = make_float4(dq[0], dq[1], dq[2], dq[3]);
+            *(float4 *)(row + 4) = make_float4(dsel == 0 ? dsig_raw : 0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const floatx4 g = load_tile16(a.acts + a.al.g[dsel], p, WV, q, t);
+            float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 w4 = *(const float4 *)(rf + PL::N_WOUT + c * WV + 16 * t + 4 * q);
+                dg.x = fmaf(w4.x, dq[c], dg.x); dg.y = fmaf(w4.y, dq[c], dg.y);
+                dg.z = fmaf(w4.z, dq[c], dg.z); dg.w = fmaf(w4.w, dq[c], dg.w);
+            }
+            floatx4 d;
+            d[0] = g[0] > 0.f ? dg.x : 0.f;
+            d[1] = g[1] > 0.f ? dg.y : 0.f;
+            d[2] = g[2] > 0.f ? dg.z : 0.f;
+            d[3] = g[3] > 0.f ? dg.w : 0.f;
+            store_tile16(a.bwd + a.bl.dyv[dsel], p, WV, q, t, d, valid);
+            vsum[t] += d;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) store_tile16(a.bwd + a.bl.dyvsum, p, WV, q, t, vsum[t], valid);
+
+    // ---------------------------------------------------------------- d(feature) = W_vf^T sum_a dYv_a   (K = 128: 4 k-steps)
+    bf16x8 bin[8][NS];
+    floatx4 acc[16];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) split_pair<NS>(vsum[2 * s], vsum[2 * s + 1], bin[s]);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = (floatx4)(0.f);
+#pragma unroll
+    for (int jj = 0; jj < PL::ST_VIEW_B; ++jj) {
+        const float *st = ws.wait();
+        gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
+    }
+    // dY of the feature layer: store (fp32, for wgrad) and split
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        store_tile16(a.bwd + a.bl.dyf, p, W, q, 2 * s, acc[2 * s], valid);
+        store_tile16(a.bwd + a.bl.dyf, p, W, q, 2 * s + 1, acc[2 * s + 1], valid);
+        split_pair<NS>(acc[2 * s], acc[2 * s + 1], bin[s]);
+    }
+
+    // ---------------------------------------------------------------- feature layer, then layers 7..1
+#pragma unroll 1
+    for (int it = 0; it < 8; ++it) {
+        const int layer = 7 - it;
+        const uint2 mk = *(const uint2 *)(a.acts + a.al.hm[layer] + ((size_t)p * 4 + q) * 2);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = (floatx4)(0.f);
+#pragma unroll
+        for (int jj = 0; jj < PL::ST_256; ++jj) {
+            const float *st = ws.wait();
+            gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
+        }
+        float *dst = a.bwd + a.bl.dy[layer];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            floatx4 x[2] = {acc[2 * s], acc[2 * s + 1]};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = 2 * s + u;
+                if (it == 0) {                               // h_8 also feeds the sigma head
+                    const float4 w4 = *(const float4 *)(rf + PL::N_WSIG + 16 * t + 4 * q);
+                    x[u][0] = fmaf(w4.x, dsig_raw, x[u][0]); x[u][1] = fmaf(w4.y, dsig_raw, x[u][1]);
+                    x[u][2] = fmaf(w4.z, dsig_raw, x[u][2]); x[u][3] = fmaf(w4.w, dsig_raw, x[u][3]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[u][r] = mask_bit16(mk.x, mk.y, t, r) ? x[u][r] : 0.f;
+                store_tile16(dst, p, W, q, t, x[u], valid);
+            }
+            if (it < 7) split_pair<NS>(x[0], x[1], bin[s]);
+        }
+    }
+}
+
+template <int NS>
+static int launch_one_bwd_n(const MlpBwdArgs &a, unsigned grid, hipStream_t st) {
+    const size_t lds = (size_t)BnPlan<NS>::LDS_F * sizeof(float);
+    VN_HIP(hipFuncSetAttribute((const void *)k_mlp_bwd_bf16n<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_mlp_bwd_bf16n<NS>), dim3(grid), dim3(BnPlan<NS>::WG), lds, st, a);
+    VN_HIP(hipGetLastError());
+    return VIPNERF_OK;
+}
+
+int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
+    if (a.src.P <= 0) return VIPNERF_OK;
+    const unsigned grid = (unsigned)((a.src.P + MLP_PTS_PER_WG - 1) / MLP_PTS_PER_WG);
+    if (precision == 1) return launch_one_bwd_n<2>(a, grid, st);
+    if (precision == 2) return launch_one_bwd_n<3>(a, grid, st);
+    set_error("mlp_bwd_bf16n: precision %d", precision);
+    return VIPNERF_E_ARG;
+}
+
+}  // namespace vn

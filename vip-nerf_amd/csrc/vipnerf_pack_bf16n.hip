@@ -1,0 +1,124 @@
+// Packing for the narrow-wave split-precision path (layout in vipnerf_bf16n.h): each weight is split into NS bf16
+// parts and laid out as per-lane A fragments of v_mfma_f32_16x16x32_bf16 in consumption order.  One thread per
+// 32-bit cell (two bf16 of one lane's 8-element fragment).
+#include "vipnerf_bf16n.h"
+
+namespace vn {
+
+struct PackBnArgs {
+    vipnerf_mlp_params p;
+    uint32_t *out;
+};
+
+__device__ __forceinline__ uint32_t pack2n(float w0, float w1, int part) {
+    const __bf16 a = split_part(w0, part), b = split_part(w1, part);
+    const uint16_t ua = __builtin_bit_cast(uint16_t, a), ub = __builtin_bit_cast(uint16_t, b);
+    return (uint32_t)ua | ((uint32_t)ub << 16);
+}
+
+template <int NS>
+__global__ void k_pack_bf16n(PackBnArgs a) {
+    typedef BnPlan<NS> PL;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= PL::PK_TOTAL_F) return;
+    uint32_t cell = 0;
+    if (idx < PL::PK_RES) {
+        const bool bwd = idx >= PL::PK_BWD;
+        const size_t i0 = bwd ? idx - PL::PK_BWD : idx;
+        const int s = (int)(i0 / PL::STAGE_F);
+        const int w = (int)(i0 % PL::STAGE_F);
+        const int c = w / CHUNK_F, lane = (w % CHUNK_F) >> 2, e0 = 2 * (w & 3);
+        const int q = lane >> 4, i = lane & 15;
+        const int part = c % NS, cellno = c / NS;
+        float v[2] = {0.f, 0.f};
+        if (!bwd) {
+            if (s < PL::FS_L1 || (s >= PL::FS_L5PE && s < PL::FS_L5)) {            // gamma(x) columns of layer 0 / 5
+                const int layer = s < PL::FS_L1 ? 0 : SKIP_LAYER;
+                const int j = s < PL::FS_L1 ? s - PL::FS_L0PE : s - PL::FS_L5PE;
+                const int t = cellno % 16, ks = PL::KSB * j + cellno / 16;
+                for (int u = 0; u < 2; ++u) {
+                    const int k = 32 * ks + 8 * q + e0 + u;                        // natural gamma(x) index
+                    v[u] = k < DPE ? a.p.p[2 * layer][(size_t)(16 * t + i) * layer_in_dim(layer) + k] : 0.f;
+                }
+            } else if (s < PL::FS_VIEW) {                                          // 256-deep register-sourced layers
+                int layer, j, koff = 0;
+                if (s < PL::FS_L5PE) { layer = 1 + (s - PL::FS_L1) / PL::ST_256; j = (s - PL::FS_L1) % PL::ST_256; }
+                else if (s < PL::FS_L6) { layer = 5; j = s - PL::FS_L5; koff = DPE; }
+                else if (s < PL::FS_L7) { layer = 6; j = s - PL::FS_L6; }
+                else if (s < PL::FS_FEAT) { layer = 7; j = s - PL::FS_L7; }
+                else { layer = 8; j = s - PL::FS_FEAT; }
+                const float *wp = layer < 8 ? a.p.p[2 * layer] : a.p.p[P_FW];
+                const int ld = layer < 8 ? layer_in_dim(layer) : W;
+                const int t = cellno % 16, ks = PL::KSB * j + cellno / 16;
+                for (int u = 0; u < 2; ++u) v[u] = wp[(size_t)(16 * t + i) * ld + koff + feat16(ks, q, e0 + u)];
+            } else {                                                               // view layer, feature columns (8 tiles)
+                const int j = s - PL::FS_VIEW;
+                const int t = cellno % 8, ks = PL::KSV * j + cellno / 8;
+                for (int u = 0; u < 2; ++u) v[u] = a.p.p[P_VW][(size_t)(16 * t + i) * (W + DVE) + feat16(ks, q, e0 + u)];
+            }
+        } else {                                                                   // dgrad: A = W^T, 16 tiles of input features
+            const int t = cellno % 16, ksl = cellno / 16;
+            const int k = 16 * t + i;
+            for (int u = 0; u < 2; ++u) {
+                if (s < PL::BS_FEAT) {
+                    const int r = feat16(PL::KSB * s + ksl, q, e0 + u);            // < 128: output feature of the view layer
+                    v[u] = a.p.p[P_VW][(size_t)r * (W + DVE) + k];
+                } else if (s < PL::BS_L7) {
+                    const int r = feat16(PL::KSB * (s - PL::BS_FEAT) + ksl, q, e0 + u);
+                    v[u] = a.p.p[P_FW][(size_t)r * W + k];
+                } else {
+                    const int layer = 7 - (s - PL::BS_L7) / PL::ST_256;
+                    const int j = (s - PL::BS_L7) % PL::ST_256;
+                    const int r = feat16(PL::KSB * j + ksl, q, e0 + u);
+                    v[u] = a.p.p[2 * layer][(size_t)r * layer_in_dim(layer) + (layer == SKIP_LAYER ? DPE : 0) + k];
+                }
+            }
+        }
+        cell = pack2n(v[0], v[1], part);
+    } else {
+        const int i0 = (int)(idx - PL::PK_RES);
+        if (i0 < PL::R_DIRW_F) {                                                   // direction columns, chunk t * NS + part
+            const int c = i0 / CHUNK_F, lane = (i0 % CHUNK_F) >> 2, e0 = 2 * (i0 & 3);
+            const int part = c % NS, t = c / NS, q = lane >> 4, i = lane & 15;
+            float v[2];
+            for (int u = 0; u < 2; ++u) {
+                const int kk = 8 * q + e0 + u;
+                v[u] = kk < DVE ? a.p.p[P_VW][(size_t)(16 * t + i) * (W + DVE) + W + kk] : 0.f;
+            }
+            cell = pack2n(v[0], v[1], part);
+        } else if (i0 < PL::R_TOTAL) {                                             // fp32 biases / heads, natural order
+            const int f = i0 - PL::R_F32;
+            float v = 0.f;
+            if (f < PL::N_BFEAT) v = a.p.p[2 * (f / W) + 1][f % W];
+            else if (f < PL::N_BVIEW) v = a.p.p[P_FB][f - PL::N_BFEAT];
+            else if (f < PL::N_WSIG) v = a.p.p[P_VB][f - PL::N_BVIEW];
+            else if (f < PL::N_WOUT) v = a.p.p[P_SW][f - PL::N_WSIG];
+            else if (f < PL::N_BHEAD) v = a.p.p[P_OW][f - PL::N_WOUT];             // [4][128] row-major like nn.Linear
+            else {
+                const int rem = f - PL::N_BHEAD;
+                v = rem == 0 ? a.p.p[P_SB][0] : (rem <= 4 ? a.p.p[P_OB][rem - 1] : 0.f);
+            }
+            cell = __float_as_uint(v);
+        }
+    }
+    a.out[idx] = cell;
+}
+
+int launch_pack_bf16n(const vipnerf_mlp_params *p, int precision, void *packed_bn, hipStream_t st) {
+    PackBnArgs a;
+    a.p = *p;
+    a.out = (uint32_t *)packed_bn;
+    const int bs = 256;
+    if (precision == 1) {
+        hipLaunchKernelGGL(k_pack_bf16n<2>, dim3((unsigned)((BnPlan<2>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);
+    } else if (precision == 2) {
+        hipLaunchKernelGGL(k_pack_bf16n<3>, dim3((unsigned)((BnPlan<3>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);
+    } else {
+        set_error("pack_bf16n: precision %d", precision);
+        return VIPNERF_E_ARG;
+    }
+    VN_HIP(hipGetLastError());
+    return VIPNERF_OK;
+}
+
+}  // namespace vn

@@ -115,7 +115,11 @@ __device__ __forceinline__ ACC mfma_split(const bf16x8 (&a)[NS], const bf16x8 (&
 //               stages' stay in flight: VM_CNT retires in issue order, stores included) + raw s_barrier (every
 //               wave's part has landed, and every wave is done reading the stage consumed before)
 //   prefetch(): DMA of stage (current + NBUF-1) into the buffer that barrier has just freed
-template <int CH, int NBUF, int WAVES = 4>
+// ROTATE (narrow layout, two waves per SIMD): a stage's whole DMA is issued by ONE wave, a different one each stage.
+// The texture path takes a 1 KiB piece every ~16 cycles whoever issues it; when every wave issues its share at the
+// same time each of them is stuck ~60 cycles per piece and no MFMA issues meanwhile, whereas a single issuing wave
+// leaves the other seven (including its SIMD partner) computing.
+template <int CH, int NBUF, int WAVES = 4, bool ROTATE = false>
 struct WStreamT {
     const float *g;
     float *buf;
@@ -123,21 +127,27 @@ struct WStreamT {
     int in_flight;         // requested, not yet consumed
     int cur, fill;         // ring slot to consume next / to fill next
     int lane, wave;
+    int turn;              // ROTATE: the wave that issues the next stage's DMA
     static constexpr int SF = CH * CHUNK_F;
-    static constexpr int PER_WAVE = CH / WAVES;
-    static_assert(CH % WAVES == 0 && PER_WAVE * (NBUF - 2) <= 63, "vmcnt is a 6-bit counter");
+    static constexpr int PER_WAVE = ROTATE ? CH : CH / WAVES;
+    static_assert(CH % WAVES == 0 && (NBUF == 2 || PER_WAVE * (NBUF - 2) <= 63), "vmcnt is a 6-bit counter");
     __device__ __forceinline__ void fetch() {
 #if defined(VN_EXP) && VN_EXP == 5
         if (n_left < -1000)                       // timing experiment only: no weight DMA
 #endif
-        glds_run<PER_WAVE>(g + (wave * PER_WAVE) * CHUNK_F + lane * 4, buf + fill * SF + (wave * PER_WAVE) * CHUNK_F);
+        if (ROTATE) {
+            if (wave == turn) glds_run<PER_WAVE>(g + lane * 4, buf + fill * SF);
+            turn = turn + 1 == WAVES ? 0 : turn + 1;
+        } else {
+            glds_run<PER_WAVE>(g + (wave * PER_WAVE) * CHUNK_F + lane * 4, buf + fill * SF + (wave * PER_WAVE) * CHUNK_F);
+        }
         g += SF;
         --n_left;
         ++in_flight;
         fill = fill + 1 == NBUF ? 0 : fill + 1;
     }
     __device__ __forceinline__ void start(const float *stream, int n_stages, float *lds_buf, int lane_, int wave_) {
-        g = stream; buf = lds_buf; n_left = n_stages; in_flight = 0; cur = 0; fill = 0; lane = lane_; wave = wave_;
+        g = stream; buf = lds_buf; n_left = n_stages; in_flight = 0; cur = 0; fill = 0; lane = lane_; wave = wave_; turn = 0;
 #pragma unroll
         for (int i = 0; i < NBUF - 1; ++i)
             if (n_left > 0) fetch();
@@ -227,8 +237,10 @@ struct NoStream {
 template <int NT, int NKS, int NS, int NB, typename WS, typename ACC>
 __device__ __forceinline__ void gemm_stage_bf(const float *stage, int lane, ACC (&acc)[NT],
                                               const bf16x8 (&B)[NB][NS], int ks0, WS &ws) {
-    constexpr int G = 2;
-    constexpr int D = NS == 2 ? 2 : 1;
+    // narrow layout (floatx4 accumulators, 256 registers per wave) in bf16x6: one tile per group, two groups ahead
+    constexpr bool TIGHT = sizeof(ACC) == 16 && NS == 3;
+    constexpr int G = TIGHT ? 1 : 2;
+    constexpr int D = (NS == 2 || TIGHT) ? 2 : 1;
     constexpr int NBUF = D + 1;
     constexpr int NG = NKS * NT / G;
     static_assert(NT % G == 0 && NG >= D, "group shape");

@@ -20,6 +20,20 @@ namespace vn {
 
 __host__ __device__ constexpr int feat16(int s, int q, int e) { return 16 * (2 * s + (e >> 2)) + 4 * q + (e & 3); }
 
+// gamma(x) (63 features, 2 k-steps) and gamma(dir) (27 features, 1 k-step) enter as B operands whose contraction order
+// is free (the weights are packed to match), so each lane group q is given features it can compute from few sincos:
+//   gamma(x):   slot u = 8s + e of lane group q: u < 15 -> feature 3 + 15q + u  (5 consecutive (level, sin|cos) triples,
+//               levels (5q)>>1 .. +2: 9 sincosf per lane instead of 30);  u = 15 -> x[q] (q < 3), unused for q = 3
+//   gamma(dir): slot e of lane group q: e < 6 -> feature 3 + 6q + e (level q: 3 sincosf instead of 12);
+//               (q,e) = (0,6) -> d[0], (0,7) -> d[1], (1,6) -> d[2]; other slots unused
+// -1 = unused slot (zero weight column).
+__host__ __device__ constexpr int pe_feat16(int s, int q, int e) {
+    return 8 * s + e < 15 ? 3 + 15 * q + 8 * s + e : (q < 3 ? q : -1);
+}
+__host__ __device__ constexpr int dir_feat16(int q, int e) {
+    return e < 6 ? 3 + 6 * q + e : (q == 0 ? e - 6 : (q == 1 && e == 6 ? 2 : -1));
+}
+
 template <int NS>
 struct BnPlan {
     static constexpr int WAVES = 8;
@@ -36,9 +50,9 @@ struct BnPlan {
     static constexpr int ST_VIEW_B = 4 / KSB;                // view layer dgrad: 16 tiles x 4 k-steps (K = 128)
     static constexpr int FS_L0PE = 0;
     static constexpr int FS_L1 = FS_L0PE + ST_PE;
-    static constexpr int FS_L5PE = FS_L1 + 4 * ST_256;
-    static constexpr int FS_L5 = FS_L5PE + ST_PE;
-    static constexpr int FS_L6 = FS_L5 + ST_256;
+    static constexpr int FS_L5 = FS_L1 + 4 * ST_256;         // layer 5: the 256 h-columns first, then gamma(x) -- the
+    static constexpr int FS_L5PE = FS_L5 + ST_256;           // operand registers of h are dead by then and hold gamma(x)'s parts
+    static constexpr int FS_L6 = FS_L5PE + ST_PE;
     static constexpr int FS_L7 = FS_L6 + ST_256;
     static constexpr int FS_FEAT = FS_L7 + ST_256;
     static constexpr int FS_VIEW = FS_FEAT + ST_256;

@@ -4,6 +4,10 @@
 #include "vipnerf_bf16n.h"
 #include "vipnerf_mlp.h"
 
+#ifndef VN_ROTATE_DMA
+#define VN_ROTATE_DMA true
+#endif
+
 namespace vn {
 
 __device__ __forceinline__ bool mask_bit16(unsigned m0, unsigned m1, int t, int r) {
@@ -25,7 +29,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
     const int64_t p = valid ? p_raw : a.src.P - 1;
     const int V = a.src.V;
 
-    WStreamT<PL::CH, PL::NBUF, PL::WAVES> ws;
+    WStreamT<PL::CH, PL::NBUF, PL::WAVES, VN_ROTATE_DMA> ws;
     ws.start(a.packed + PL::PK_BWD, PL::B_STAGES, stage_buf, lane, wave);
     {
         const float4 *g4 = (const float4 *)(a.packed + PL::PK_RES);

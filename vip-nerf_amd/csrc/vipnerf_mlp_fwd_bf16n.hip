@@ -5,32 +5,68 @@
 #include "vipnerf_bf16n.h"
 #include "vipnerf_mlp.h"
 
+#ifndef VN_ROTATE_DMA
+#define VN_ROTATE_DMA true
+#endif
+
 namespace vn {
 
-// gamma_L(v) for the narrow fragment: k-step s, element e of lane group q is feature 32 s + 8 q + e (natural order)
-template <int L, int NKS>
-__device__ __forceinline__ void encode_bn(const float v[3], int q, float (&out)[NKS][8]) {
-    float val[32 * NKS];
+__device__ __forceinline__ float pow2f(int l) { return __uint_as_float((unsigned)(127 + l) << 23); }
+
+// gamma(x) in the slot order of pe_feat16 (vipnerf_bf16n.h): lane group q evaluates levels (5q)>>1 .. +2 only.
+// out[s][e], u = 8s + e: u = 3 gg + d < 15 -> triple gg of this lane group, component d; u = 15 -> x[q] / unused
+__device__ __forceinline__ void encode_x16(const float v[3], int q, float (&out)[2][8]) {
+    const int lb = (5 * q) >> 1;
+    float S[3][3], C[3][3];
 #pragma unroll
-    for (int f = 0; f < 32 * NKS; ++f) val[f] = 0.f;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) val[d] = v[d];
-#pragma unroll
-    for (int l = 0; l < L; ++l)
+    for (int li = 0; li < 3; ++li) {
+        const float f = pow2f(lb + li);
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            float s, c;
-            sincosf(v[d] * (float)(1 << l), &s, &c);
-            val[3 + 6 * l + d] = s;
-            val[3 + 6 * l + 3 + d] = c;
+#if defined(VN_EXP) && VN_EXP == 7
+            S[li][d] = v[d] * f; C[li][d] = S[li][d] + 1.f;   // timing experiment only: no sincos
+#else
+            sincosf(v[d] * f, &S[li][d], &C[li][d]);
+#endif
         }
+    }
+    const bool odd = q & 1;           // 5q even: triples are S0 C0 S1 C1 S2;  odd: C0 S1 C1 S2 C2
+    float val[16];
 #pragma unroll
-    for (int s = 0; s < NKS; ++s)
+    for (int d = 0; d < 3; ++d) {
+        val[0 + d] = odd ? C[0][d] : S[0][d];
+        val[3 + d] = odd ? S[1][d] : C[0][d];
+        val[6 + d] = odd ? C[1][d] : S[1][d];
+        val[9 + d] = odd ? S[2][d] : C[1][d];
+        val[12 + d] = odd ? C[2][d] : S[2][d];
+    }
+    val[15] = q == 0 ? v[0] : (q == 1 ? v[1] : (q == 2 ? v[2] : 0.f));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float a0 = val[32 * s + e], a1 = val[32 * s + 8 + e], a2 = val[32 * s + 16 + e], a3 = val[32 * s + 24 + e];
-            out[s][e] = q == 0 ? a0 : (q == 1 ? a1 : (q == 2 ? a2 : a3));
-        }
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[s][e] = val[8 * s + e];
+}
+// gamma(dir) in the slot order of dir_feat16: lane group q evaluates level q only
+__device__ __forceinline__ void encode_d16(const float v[3], int q, float (&out)[1][8]) {
+    const float f = pow2f(q);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) sincosf(v[d] * f, &out[0][d], &out[0][3 + d]);
+    out[0][6] = q == 0 ? v[0] : (q == 1 ? v[2] : 0.f);
+    out[0][7] = q == 0 ? v[1] : 0.f;
+}
+// natural-order rows of the activation store ([P][64] / [P][32], read by the weight-gradient GEMMs)
+__device__ __forceinline__ void store_x16(float *row, int q, const float (&pe)[2][8]) {
+#pragma unroll
+    for (int u = 0; u < 15; ++u) row[3 + 15 * q + u] = pe[u >> 3][u & 7];
+    row[q < 3 ? q : DPE] = pe[1][7];                       // x[q]; lane group 3 writes the zero pad column
+}
+__device__ __forceinline__ void store_d16(float *row, int q, const float (&pd)[1][8]) {
+#pragma unroll
+    for (int e = 0; e < 6; ++e) row[3 + 6 * q + e] = pd[0][e];
+    if (q == 0) { row[0] = pd[0][6]; row[1] = pd[0][7]; }
+    else if (q == 1) row[2] = pd[0][6];
+    else if (q == 2) { row[DVE] = 0.f; row[DVE + 1] = 0.f; }
+    else { row[DVE + 2] = 0.f; row[DVE + 3] = 0.f; row[DVE + 4] = 0.f; }
 }
 
 template <bool SAVE, int NS>
@@ -47,7 +83,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
     const bool valid = p_raw < a.src.P;
     const int64_t p = valid ? p_raw : a.src.P - 1;
 
-    WStreamT<PL::CH, PL::NBUF, PL::WAVES> ws;
+    WStreamT<PL::CH, PL::NBUF, PL::WAVES, VN_ROTATE_DMA> ws;
     ws.start(a.packed + PL::PK_FWD, PL::F_STAGES, stage_buf, lane, wave);
     {
         const float4 *g4 = (const float4 *)(a.packed + PL::PK_RES);
@@ -55,18 +91,13 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
         for (int i = tid; i < PL::R_TOTAL_PAD / 4; i += PL::WG) l4[i] = g4[i];
     }
 
-    PointCtx pc;
-    load_point(a.src, p, pc);
     float pe[2][8];
-    encode_bn<LP, 2>(pc.x, q, pe);
-    if (SAVE && valid) {
-        float *row = a.acts + a.al.pex + (size_t)p * DPE_PAD + 8 * q;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            *(float4 *)(row + 32 * s) = make_float4(pe[s][0], pe[s][1], pe[s][2], pe[s][3]);
-            *(float4 *)(row + 32 * s + 4) = make_float4(pe[s][4], pe[s][5], pe[s][6], pe[s][7]);
-        }
+    {
+        PointCtx pc0;                        // scoped: the ray / direction data is re-read for the view branch rather
+        load_point(a.src, p, pc0);           // than kept in 13 registers across the trunk
+        encode_x16(pc0.x, q, pe);
     }
+    if (SAVE && valid) store_x16(a.acts + a.al.pex + (size_t)p * DPE_PAD, q, pe);
 
     bf16x8 bin[8][NS];                       // the layer input as B fragments: k-step s <- C/D tiles 2s, 2s+1
     floatx4 acc[16];
@@ -83,7 +114,14 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             acc[t][0] = b4.x; acc[t][1] = b4.y; acc[t][2] = b4.z; acc[t][3] = b4.w;
         }
 
-        if (layer == 0 || layer == SKIP_LAYER) {
+        if (layer != 0) {
+#pragma unroll
+            for (int jj = 0; jj < PL::ST_256; ++jj) {
+                const float *st = ws.wait();
+                gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
+            }
+        }
+        if (layer == 0 || layer == SKIP_LAYER) {         // gamma(x) columns last: bin is dead, its registers hold bpe
             bf16x8 bpe[2][NS];
 #pragma unroll
             for (int s = 0; s < 2; ++s) split8<NS>(pe[s], bpe[s]);
@@ -91,13 +129,6 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             for (int jj = 0; jj < PL::ST_PE; ++jj) {
                 const float *st = ws.wait();
                 gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bpe, PL::KSB * jj, ws);
-            }
-        }
-        if (layer != 0) {
-#pragma unroll
-            for (int jj = 0; jj < PL::ST_256; ++jj) {
-                const float *st = ws.wait();
-                gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
             }
         }
         // epilogue: ReLU (trunk), activation store, mask, sigma head, split into the next layer's B fragments
@@ -147,6 +178,8 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
     }
 
     // ---------------------------------------------------------------- view branch
+    PointCtx pc;
+    load_point(a.src, p, pc);
     floatx4 vb[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -165,7 +198,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
         if (dsel == 0) { dir[0] = pc.dir[0]; dir[1] = pc.dir[1]; dir[2] = pc.dir[2]; }
         else secondary_dir(a.src, pc, dsel - 1, dir);
         float ped[1][8];
-        encode_bn<LV, 1>(dir, q, ped);
+        encode_d16(dir, q, ped);
         bf16x8 bpd[1][NS];
         split8<NS>(ped[0], bpd[0]);
         floatx4 g[8];
@@ -179,11 +212,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
         if (SAVE) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) store_tile16(a.acts + a.al.g[dsel], p, WV, q, t, g[t], valid);
-            if (valid) {
-                float *row = a.acts + a.al.ped[dsel] + (size_t)p * DVE_PAD + 8 * q;
-                *(float4 *)(row) = make_float4(ped[0][0], ped[0][1], ped[0][2], ped[0][3]);
-                *(float4 *)(row + 4) = make_float4(ped[0][4], ped[0][5], ped[0][6], ped[0][7]);
-            }
+            if (valid) store_d16(a.acts + a.al.ped[dsel] + (size_t)p * DVE_PAD, q, ped);
         }
         float qv[4];
 #pragma unroll

@@ -32,18 +32,18 @@ __global__ void k_pack_bf16n(PackBnArgs a) {
         const int part = c % NS, cellno = c / NS;
         float v[2] = {0.f, 0.f};
         if (!bwd) {
-            if (s < PL::FS_L1 || (s >= PL::FS_L5PE && s < PL::FS_L5)) {            // gamma(x) columns of layer 0 / 5
+            if (s < PL::FS_L1 || (s >= PL::FS_L5PE && s < PL::FS_L6)) {            // gamma(x) columns of layer 0 / 5
                 const int layer = s < PL::FS_L1 ? 0 : SKIP_LAYER;
                 const int j = s < PL::FS_L1 ? s - PL::FS_L0PE : s - PL::FS_L5PE;
                 const int t = cellno % 16, ks = PL::KSB * j + cellno / 16;
                 for (int u = 0; u < 2; ++u) {
-                    const int k = 32 * ks + 8 * q + e0 + u;                        // natural gamma(x) index
-                    v[u] = k < DPE ? a.p.p[2 * layer][(size_t)(16 * t + i) * layer_in_dim(layer) + k] : 0.f;
+                    const int k = pe_feat16(ks, q, e0 + u);
+                    v[u] = k >= 0 ? a.p.p[2 * layer][(size_t)(16 * t + i) * layer_in_dim(layer) + k] : 0.f;
                 }
             } else if (s < PL::FS_VIEW) {                                          // 256-deep register-sourced layers
                 int layer, j, koff = 0;
-                if (s < PL::FS_L5PE) { layer = 1 + (s - PL::FS_L1) / PL::ST_256; j = (s - PL::FS_L1) % PL::ST_256; }
-                else if (s < PL::FS_L6) { layer = 5; j = s - PL::FS_L5; koff = DPE; }
+                if (s < PL::FS_L5) { layer = 1 + (s - PL::FS_L1) / PL::ST_256; j = (s - PL::FS_L1) % PL::ST_256; }
+                else if (s < PL::FS_L5PE) { layer = 5; j = s - PL::FS_L5; koff = DPE; }
                 else if (s < PL::FS_L7) { layer = 6; j = s - PL::FS_L6; }
                 else if (s < PL::FS_FEAT) { layer = 7; j = s - PL::FS_L7; }
                 else { layer = 8; j = s - PL::FS_FEAT; }
@@ -82,8 +82,8 @@ __global__ void k_pack_bf16n(PackBnArgs a) {
             const int part = c % NS, t = c / NS, q = lane >> 4, i = lane & 15;
             float v[2];
             for (int u = 0; u < 2; ++u) {
-                const int kk = 8 * q + e0 + u;
-                v[u] = kk < DVE ? a.p.p[P_VW][(size_t)(16 * t + i) * (W + DVE) + W + kk] : 0.f;
+                const int kk = dir_feat16(q, e0 + u);
+                v[u] = kk >= 0 ? a.p.p[P_VW][(size_t)(16 * t + i) * (W + DVE) + W + kk] : 0.f;
             }
             cell = pack2n(v[0], v[1], part);
         } else if (i0 < PL::R_TOTAL) {                                             // fp32 biases / heads, natural order

@@ -45,6 +45,12 @@ extern "C" {
 #define VIPNERF_PREC_BF16X3 1
 #define VIPNERF_PREC_BF16X6 2
 
+/* Lane layout of the BF16X3 / BF16X6 kernels (same arithmetic, same stored activations):
+ * WIDE: 32-point waves on 32x32x16 MFMA, one wave per SIMD; NARROW: 16-point waves on 16x16x32, two waves per SIMD. */
+#define VIPNERF_LAYOUT_DEFAULT 0
+#define VIPNERF_LAYOUT_WIDE    1
+#define VIPNERF_LAYOUT_NARROW  2
+
 #define VIPNERF_MAX_SEC 3            /* secondary views V = nf-1 <= 3 (reference configs use nf in {2,3,4}) */
 #define VIPNERF_N_PARAMS 24          /* tensors of one MLP */
 
@@ -66,7 +72,9 @@ typedef struct vipnerf_config {
                              entry; importance sampling is skipped.  0 in production. */
     int32_t perturb;      /* configs['model']['perturb'] && training: stratified jitter + random inverse-CDF draws */
     int32_t precision;    /* VIPNERF_PREC_*: arithmetic of the MLP GEMMs */
-    int32_t reserved[4];
+    int32_t bf16_layout;  /* VIPNERF_LAYOUT_*: lane layout of the split-bf16 MLP kernels; 0 = library default
+                             (environment VIPNERF_BF16_LAYOUT=wide|narrow overrides the built-in default) */
+    int32_t reserved[3];
 } vipnerf_config;
 
 /* One ray batch (render_rays' input_dict, src/models/VipNeRF01.py:74-98).  N = n_rays. */

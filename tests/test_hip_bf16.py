@@ -17,6 +17,9 @@ from oracle import vipnerf_oracle as vo  # noqa: E402
 import test_hip_parity as tp  # noqa: E402
 
 PRECS = ['bf16x3', 'bf16x6']
+# the render-level tests run both lane layouts of the split-bf16 kernels (configs['model']['hip_bf16_layout']):
+# 'narrow' (16-point waves, the default) and 'wide' (32-point waves)
+MODES = ['bf16x3', 'bf16x6', 'bf16x3-wide', 'bf16x6-wide']
 # relative-L2 tolerance on parameter gradients.  bf16x6 is fp32 grade (same bar as the fp32 path).  bf16x3 perturbs
 # activations by ~5e-6 relative, i.e. ~20x more ReLU pre-activations land on the other side of 0 than in fp32, and
 # the error is carried through 8 chained dgrad layers: measured 2-3e-3 on the deepest layer's weights.
@@ -46,13 +49,19 @@ def test_mlp_forward_golden(dev, prec, V):
         tp.assert_close(o['visibility2'], g[f'vis2_{mode}'], what=f'{prec} vis2 {mode}')
 
 
-def make_model(dev, ndc, params, prec, sparse=False):
+def make_model(dev, ndc, params, mode, sparse=False):
     model, cfg = tp.make_model(dev, ndc, params, sparse=sparse)
+    prec, _, layout = mode.partition('-')
     model.configs['model']['hip_precision'] = prec
+    model.configs['model']['hip_bf16_layout'] = layout or 'narrow'
     return model, cfg
 
 
-@pytest.mark.parametrize('prec', PRECS)
+def grad_tol(mode):
+    return GRAD_TOL[mode.partition('-')[0]]
+
+
+@pytest.mark.parametrize('prec', MODES)
 def test_eval_render_golden(dev, prec):
     g = tp.load('f4_eval_fern')
     b = vo.synthetic_batch(int(g['n']), int(g['seed_batch']), scene='fern', nf=2)
@@ -69,7 +78,7 @@ def test_eval_render_golden(dev, prec):
                 tp.assert_close(out[f'{rk}_{lv}'], g[gk], what=f'{prec} {rk}_{lv}')
 
 
-@pytest.mark.parametrize('prec', PRECS)
+@pytest.mark.parametrize('prec', MODES)
 @pytest.mark.parametrize('tag', ['llff', 'dtu'])
 def test_train_step_golden(dev, prec, tag):
     from loss_functions.LossComputerHip01 import LossComputerHip
@@ -99,16 +108,16 @@ def test_train_step_golden(dev, prec, tag):
     worst = 0.0
     for k, p in model.named_parameters():
         gd, dg = g['gdig_' + k], digest(p.grad)
-        np.testing.assert_allclose(dg[1], gd[1], rtol=GRAD_TOL[prec], atol=1e-9, err_msg=f'{prec} {tag} |grad| of {k}')
+        np.testing.assert_allclose(dg[1], gd[1], rtol=grad_tol(prec), atol=1e-9, err_msg=f'{prec} {tag} |grad| of {k}')
         tp.grad_close(dg[2:], gd[2:], f'{prec} {tag} grad samples of {k}', scale=max(abs(gd[1]) / np.sqrt(p.numel()), 1e-12),
-                      l2_tol=GRAD_TOL[prec])
+                      l2_tol=grad_tol(prec))
         if 'grad_' + k in g:
-            tp.grad_close(p.grad.cpu().numpy(), g['grad_' + k], f'{prec} {tag} grad of {k}', l2_tol=GRAD_TOL[prec])
+            tp.grad_close(p.grad.cpu().numpy(), g['grad_' + k], f'{prec} {tag} grad of {k}', l2_tol=grad_tol(prec))
             worst = max(worst, float(np.linalg.norm(p.grad.cpu().numpy() - g['grad_' + k]) / max(np.linalg.norm(g['grad_' + k]), 1e-30)))
     print(f'{prec} {tag}: worst rel L2 error over the fully stored gradient tensors {worst:.2e}')
 
 
-@pytest.mark.parametrize('prec', PRECS)
+@pytest.mark.parametrize('prec', MODES)
 def test_backward_vs_oracle(dev, prec):
     n = 40
     b = vo.synthetic_batch(n, 77, scene='fern', nf=2)
@@ -133,6 +142,6 @@ def test_backward_vs_oracle(dev, prec):
     tot_h.backward()
     worst = 0.0
     for k, t in model.named_parameters():
-        tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{prec} {k}', l2_tol=GRAD_TOL[prec])
+        tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{prec} {k}', l2_tol=grad_tol(prec))
         worst = max(worst, float((t.grad.cpu() - p[k].grad).norm() / p[k].grad.norm()))
     print(f'{prec}: worst relative L2 gradient error over 48 tensors {worst:.3e}')

@@ -72,6 +72,8 @@ static int check_cfg(const vipnerf_config *cfg) {
         set_error("n_sec=%d unsupported (0..%d)", cfg->n_sec, VIPNERF_MAX_SEC); return VIPNERF_E_UNSUPPORTED; }
     if (cfg->precision < 0 || cfg->precision > VIPNERF_PREC_BF16X6) {
         set_error("precision=%d unsupported", cfg->precision); return VIPNERF_E_UNSUPPORTED; }
+    if (cfg->bf16_layout < VIPNERF_LAYOUT_DEFAULT || cfg->bf16_layout > VIPNERF_LAYOUT_NARROW) {
+        set_error("bf16_layout=%d unsupported", cfg->bf16_layout); return VIPNERF_E_UNSUPPORTED; }
     return VIPNERF_OK;
 }
 
@@ -85,9 +87,11 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st);
 // ([fp32][wide][narrow]); VIPNERF_BF16_LAYOUT=wide|narrow picks the kernels (forward and data-gradient kernels
 // must agree: the ReLU masks are stored in fragment order).
 #ifndef VN_BF16_NARROW_DEFAULT
-#define VN_BF16_NARROW_DEFAULT 0
+#define VN_BF16_NARROW_DEFAULT 1
 #endif
-static bool bf16_narrow() {
+static bool bf16_narrow(int layout = VIPNERF_LAYOUT_DEFAULT) {
+    if (layout == VIPNERF_LAYOUT_WIDE) return false;
+    if (layout == VIPNERF_LAYOUT_NARROW) return true;
     static const int v = [] {
         const char *e = getenv("VIPNERF_BF16_LAYOUT");
         if (e && !strcmp(e, "narrow")) return 1;
@@ -98,9 +102,9 @@ static bool bf16_narrow() {
 }
 static size_t packed_floats_all(int precision) { return packed_total_floats(precision) + packed_narrow_floats(precision); }
 
-static int launch_mlp_fwd_any(MlpFwdArgs &a, int precision, hipStream_t st) {
+static int launch_mlp_fwd_any(MlpFwdArgs &a, int precision, hipStream_t st, int layout = VIPNERF_LAYOUT_DEFAULT) {
     if (precision == VIPNERF_PREC_FP32) return launch_mlp_fwd(a, st);
-    if (bf16_narrow()) {
+    if (bf16_narrow(layout)) {
         a.packed += packed_total_floats(precision);   // [fp32][wide] precede the narrow image
         return launch_mlp_fwd_bf16n(a, precision, st);
     }
@@ -309,7 +313,7 @@ int32_t vipnerf_render_forward(const vipnerf_config *cfg, const vipnerf_rays *ra
         }
         {
             ProfScope ps(lv ? "mlp_fwd_fine" : "mlp_fwd_coarse", st);
-            if ((rc = launch_mlp_fwd_any(ma, cfg->precision, st))) return rc;
+            if ((rc = launch_mlp_fwd_any(ma, cfg->precision, st, cfg->bf16_layout))) return rc;
         }
         // 3./6. compositing
         CompositeArgs ca;
@@ -371,7 +375,7 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
         {
             ProfScope ps(lv ? "mlp_dgrad_fine" : "mlp_dgrad_coarse", st);
             if (cfg->precision == VIPNERF_PREC_FP32) rc = launch_mlp_bwd(mb, st);
-            else if (bf16_narrow()) { mb.packed += packed_total_floats(cfg->precision); rc = launch_mlp_bwd_bf16n(mb, cfg->precision, st); }
+            else if (bf16_narrow(cfg->bf16_layout)) { mb.packed += packed_total_floats(cfg->precision); rc = launch_mlp_bwd_bf16n(mb, cfg->precision, st); }
             else { mb.packed += PK_TOTAL_F; rc = launch_mlp_bwd_bf16(mb, cfg->precision, st); }
             if (rc) return rc;
         }

@@ -122,7 +122,8 @@ class VipNeRFHip(torch.nn.Module):
         noise_std = float(m.get('raw_noise_std', 0.0)) if train else 0.0
         cfg = ops.make_config(self.ndc, m['coarse_mlp']['num_samples'], n_fine, V, train=train, noise_std=noise_std,
                               lindisp=m.get('lindisp', False), white_bkgd=m.get('white_bkgd', False), perturb=perturb,
-                              precision=ops.PRECISIONS[m.get('hip_precision', 'fp32')])
+                              precision=ops.PRECISIONS[m.get('hip_precision', 'fp32')],
+                              bf16_layout=ops.LAYOUTS[m.get('hip_bf16_layout', 'default')])
         rng = None
         if train:
             rng = dict(self.injected_rng) if self.injected_rng is not None else {}

@@ -23,7 +23,8 @@ class VipNerfHipError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [('ndc', C.c_int32), ('n_coarse', C.c_int32), ('n_fine', C.c_int32), ('n_sec', C.c_int32),
                 ('train', C.c_int32), ('lindisp', C.c_int32), ('white_bkgd', C.c_int32), ('save_acts', C.c_int32),
-                ('noise_std', C.c_float), ('given_z_fine', C.c_int32), ('perturb', C.c_int32), ('precision', C.c_int32), ('reserved', C.c_int32 * 4)]
+                ('noise_std', C.c_float), ('given_z_fine', C.c_int32), ('perturb', C.c_int32), ('precision', C.c_int32), ('bf16_layout', C.c_int32),
+                ('reserved', C.c_int32 * 3)]
 
 
 class Rays(C.Structure):

@@ -36,9 +36,10 @@ def f32c(t: torch.Tensor) -> torch.Tensor:
 
 
 def make_config(ndc, n_coarse, n_fine, n_sec, train, noise_std=0.0, lindisp=False, white_bkgd=False,
-                save_acts=False, perturb=None, precision=0) -> L.Config:
+                save_acts=False, perturb=None, precision=0, bf16_layout=0) -> L.Config:
     c = L.Config()
     c.precision = int(precision)
+    c.bf16_layout = int(bf16_layout)
     c.perturb = int(bool(train if perturb is None else perturb))
     c.ndc, c.n_coarse, c.n_fine, c.n_sec = int(bool(ndc)), int(n_coarse), int(n_fine), int(n_sec)
     c.train, c.lindisp, c.white_bkgd, c.save_acts = int(bool(train)), int(bool(lindisp)), int(bool(white_bkgd)), int(bool(save_acts))
@@ -47,6 +48,7 @@ def make_config(ndc, n_coarse, n_fine, n_sec, train, noise_std=0.0, lindisp=Fals
 
 
 PRECISIONS = {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2}
+LAYOUTS = {'default': 0, 'wide': 1, 'narrow': 2}
 
 
 def packed_bytes(precision: int = 0) -> int:

@@ -141,25 +141,33 @@ __host__ __device__ inline int wgrad_chunks(size_t P) {
 // The eight 256x256 GEMMs use 4096-point chunks; the small GEMMs (few MFMAs per point) use chunks 4x shorter so
 // that their single-GEMM launches still fill the chip.
 constexpr int WGRAD_SMALL_SPLIT = 4;
-__host__ __device__ inline int wgrad_chunk_pts(size_t P) {            // multiple of 32 * WGRAD_SMALL_SPLIT
+__host__ __device__ inline int wgrad_chunk_pts(size_t P) {            // multiple of 32 * 2 * WGRAD_SMALL_SPLIT
     const int n = wgrad_chunks(P);
-    const size_t c = (P + n - 1) / n, q = 32 * WGRAD_SMALL_SPLIT;
+    const size_t c = (P + n - 1) / n, q = 32 * 2 * WGRAD_SMALL_SPLIT;
     return (int)((c + q - 1) / q * q);
 }
 __host__ __device__ inline int wgrad_chunks_small(size_t P) {
     const size_t c = wgrad_chunk_pts(P) / WGRAD_SMALL_SPLIT;
     return (int)((P + c - 1) / c);
 }
+// Small GEMMs that are alone in their launch (sigma head, view-layer feature columns) are cut twice as fine again:
+// with 4096 rays the other launches come to 256 / 768 workgroups (1 / 3 full rounds of the 256 CUs), these would
+// be 128 / 384.
+constexpr int WGRAD_SINGLE_SPLIT = 2 * WGRAD_SMALL_SPLIT;
+__host__ __device__ inline int wgrad_chunks_single(size_t P) {
+    const size_t c = wgrad_chunk_pts(P) / WGRAD_SINGLE_SPLIT;
+    return (int)((P + c - 1) / c);
+}
 // floats of partial output: sum over GEMMs of chunks * (Mp*Kp + Mp)   (Mp for the bias column sums)
 __host__ __device__ inline size_t wgrad_partial_total(size_t P, int V) {
     size_t big = 8 * (size_t)(256 * 256 + 256);     // layers 1-4, 5(h part), 6, 7, feature
-    size_t sm = 0;
+    size_t sm = 0, single = 0;
     sm += 2 * (size_t)(256 * 64 + 256);             // layer 0, layer 5 gamma(x) part
-    sm += (size_t)(32 * 256 + 32);                  // sigma head
-    sm += (size_t)(128 * 256 + 128);                // view layer, feature columns
+    single += (size_t)(32 * 256 + 32);              // sigma head
+    single += (size_t)(128 * 256 + 128);            // view layer, feature columns
     sm += (size_t)(1 + V) * (128 * 32 + 128);       // view layer, direction columns (per direction)
     sm += (size_t)(1 + V) * (32 * 128 + 32);        // output head (per direction)
-    return (size_t)wgrad_chunks(P) * big + (size_t)wgrad_chunks_small(P) * sm;
+    return (size_t)wgrad_chunks(P) * big + (size_t)wgrad_chunks_small(P) * sm + (size_t)wgrad_chunks_single(P) * single;
 }
 __host__ __device__ inline BwdLayout bwd_layout(size_t P, int V) {
     BwdLayout b; size_t o = 0;

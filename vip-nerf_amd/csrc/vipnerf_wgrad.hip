@@ -496,8 +496,8 @@ static int launch_class(const WgArgs &args, int n_desc, int n_chunks, hipStream_
 int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float *bwd, const BwdLayout &bl,
                  const vipnerf_mlp_grads *G, int precision, hipStream_t st) {
     if (P == 0) return VIPNERF_OK;
-    const int n_chunks = wgrad_chunks(P), n_small = wgrad_chunks_small(P);
-    const int chunk_pts = wgrad_chunk_pts(P), chunk_small = chunk_pts / WGRAD_SMALL_SPLIT;
+    const int n_chunks = wgrad_chunks(P), n_small = wgrad_chunks_small(P), n_single = wgrad_chunks_single(P);
+    const int chunk_pts = wgrad_chunk_pts(P), chunk_small = chunk_pts / WGRAD_SMALL_SPLIT, chunk_single = chunk_pts / WGRAD_SINGLE_SPLIT;
     float *partial = bwd + bl.partial;
 
     WgArgs c88, c82, c48, c41, c18, c14;       // classes by (M tiles, K tiles)
@@ -505,7 +505,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
     int n88 = 0, n82 = 0, n48 = 0, n41 = 0, n18 = 0, n14 = 0, ng = 0;
     size_t off = 0;
     auto init = [&](WgArgs &w, int cp) { w.P = (int64_t)P; w.chunk_pts = cp; w.partial = partial; };
-    init(c88, chunk_pts); init(c82, chunk_small); init(c48, chunk_small); init(c41, chunk_small); init(c18, chunk_small); init(c14, chunk_small);
+    init(c88, chunk_pts); init(c82, chunk_small); init(c48, chunk_single); init(c41, chunk_small); init(c18, chunk_single); init(c14, chunk_small);
     red.partial = partial;
 
     // adds one GEMM; returns its partial offset
@@ -513,15 +513,15 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
         WgDesc &d = w.d[n++];
         d.A = A; d.lda = lda; d.m_load = m_load; d.B = B; d.ldb = ldb; d.k_load = k_load;
         d.part_off = off; d.part_stride = (size_t)Mp * Kp + Mp;
-        d.n_chunks = (&w == &c88) ? n_chunks : n_small;
+        d.n_chunks = (&w == &c88) ? n_chunks : ((&w == &c48 || &w == &c18) ? n_single : n_small);
         const size_t o = off;
         off += (size_t)d.n_chunks * d.part_stride;
         return o;
     };
-    auto group = [&](bool big, size_t part_off, int n_desc, int Mp, int Kp, int m_valid, int k_valid, float *dW, int ldw, int col_off, float *dbias) {
+    auto group = [&](int chunks, size_t part_off, int n_desc, int Mp, int Kp, int m_valid, int k_valid, float *dW, int ldw, int col_off, float *dbias) {
         WgGroup &g = red.g[ng++];
         g.part_off = part_off; g.part_stride = (size_t)Mp * Kp + Mp; g.n_desc = n_desc;
-        g.n_chunks = big ? n_chunks : n_small;
+        g.n_chunks = chunks;
         g.desc_stride = (size_t)g.n_chunks * g.part_stride;
         g.Mp = Mp; g.Kp = Kp; g.m_valid = m_valid; g.k_valid = k_valid; g.dW = dW; g.ldw = ldw; g.col_off = col_off; g.dbias = dbias;
     };
@@ -532,28 +532,28 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
         float *dW = G->g[2 * i], *db = G->g[2 * i + 1];
         if (i == 0) {
             const size_t o = add(c82, n82, 256, 64, dy, W, W, pex, DPE_PAD, DPE_PAD);
-            group(false, o, 1, 256, 64, W, DPE, dW, DPE, 0, db);
+            group(n_small, o, 1, 256, 64, W, DPE, dW, DPE, 0, db);
         } else if (i == SKIP_LAYER) {
             const size_t o1 = add(c82, n82, 256, 64, dy, W, W, pex, DPE_PAD, DPE_PAD);
-            group(false, o1, 1, 256, 64, W, DPE, dW, W + DPE, 0, nullptr);
+            group(n_small, o1, 1, 256, 64, W, DPE, dW, W + DPE, 0, nullptr);
             const size_t o2 = add(c88, n88, 256, 256, dy, W, W, acts + al.h[i - 1], W, W);
-            group(true, o2, 1, 256, 256, W, W, dW, W + DPE, DPE, db);
+            group(n_chunks, o2, 1, 256, 256, W, W, dW, W + DPE, DPE, db);
         } else {
             const size_t o = add(c88, n88, 256, 256, dy, W, W, acts + al.h[i - 1], W, W);
-            group(true, o, 1, 256, 256, W, W, dW, W, 0, db);
+            group(n_chunks, o, 1, 256, 256, W, W, dW, W, 0, db);
         }
     }
     {   // feature_linear
         const size_t o = add(c88, n88, 256, 256, bwd + bl.dyf, W, W, acts + al.h[D - 1], W, W);
-        group(true, o, 1, 256, 256, W, W, G->g[P_FW], W, 0, G->g[P_FB]);
+        group(n_chunks, o, 1, 256, 256, W, W, G->g[P_FW], W, 0, G->g[P_FB]);
     }
     {   // sigma head: A = column 4 of DQ[0]
         const size_t o = add(c18, n18, 32, 256, bwd + bl.dq[0] + 4, 8, 4, acts + al.h[D - 1], W, W);
-        group(false, o, 1, 32, 256, 1, W, G->g[P_SW], W, 0, G->g[P_SB]);
+        group(n_single, o, 1, 32, 256, 1, W, G->g[P_SW], W, 0, G->g[P_SB]);
     }
     {   // view layer, feature columns: A = sum over directions
         const size_t o = add(c48, n48, 128, 256, bwd + bl.dyvsum, WV, WV, acts + al.feat, W, W);
-        group(false, o, 1, 128, 256, WV, W, G->g[P_VW], W + DVE, 0, G->g[P_VB]);
+        group(n_single, o, 1, 128, 256, WV, W, G->g[P_VW], W + DVE, 0, G->g[P_VB]);
     }
     {   // view layer, direction columns: one GEMM per direction, summed in order
         size_t first = 0;
@@ -561,7 +561,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
             const size_t o = add(c41, n41, 128, 32, bwd + bl.dyv[k], WV, WV, acts + al.ped[k], DVE_PAD, DVE_PAD);
             if (k == 0) first = o;
         }
-        group(false, first, 1 + V, 128, 32, WV, DVE, G->g[P_VW], W + DVE, W, nullptr);
+        group(n_small, first, 1 + V, 128, 32, WV, DVE, G->g[P_VW], W + DVE, W, nullptr);
     }
     {   // output head: A = DQ[k][:, 0:4], B = view hidden of direction k
         size_t first = 0;
@@ -569,7 +569,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
             const size_t o = add(c14, n14, 32, 128, bwd + bl.dq[k], 8, 4, acts + al.g[k], WV, WV);
             if (k == 0) first = o;
         }
-        group(false, first, 1 + V, 32, 128, 4, WV, G->g[P_OW], WV, 0, G->g[P_OB]);
+        group(n_small, first, 1 + V, 32, 128, 4, WV, G->g[P_OW], WV, 0, G->g[P_OB]);
     }
     if (off != wgrad_partial_total(P, V)) { set_error("wgrad: partial buffer plan mismatch"); return VIPNERF_E_ARG; }
 
@@ -587,14 +587,14 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
     }
     ProfScope ps("wgrad_small", st);
     if (precision == VIPNERF_PREC_FP32) {
-        if ((rc = launch_class<1, 8, 4>(c48, n48, n_small, st))) return rc;
+        if ((rc = launch_class<1, 8, 4>(c48, n48, n_single, st))) return rc;
         if ((rc = launch_class<2, 2, 4>(c82, n82, n_small, st))) return rc;
     } else {
-        if ((rc = launch_bf16x3<4, 8>(c48, n48, n_small, st))) return rc;
+        if ((rc = launch_bf16x3<4, 8>(c48, n48, n_single, st))) return rc;
         if ((rc = launch_bf16x3<8, 2>(c82, n82, n_small, st))) return rc;
     }
     if ((rc = launch_class<1, 1, 4>(c41, n41, n_small, st))) return rc;
-    if ((rc = launch_class<1, 2, 1>(c18, n18, n_small, st))) return rc;
+    if ((rc = launch_class<1, 2, 1>(c18, n18, n_single, st))) return rc;
     if ((rc = launch_class<1, 1, 1>(c14, n14, n_small, st))) return rc;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(512, ng), dim3(256), 0, st, red);
     VN_HIP(hipGetLastError());

@@ -99,7 +99,8 @@ def main():
     rank, world, local = vdist.init_from_env()
     if args.gpus != world and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-    dev = torch.device(f'cuda:{local}')
+    dev = torch.device(f'cuda:{local % torch.cuda.device_count()}')   # (one GPU per rank; the modulo only serves the
+                                                                      # 2-ranks-on-1-GPU gloo smoke run of the N>1 code path)
     torch.cuda.set_device(dev)
 
     from oracle import vipnerf_oracle as vo       # synthetic-data generator + cpu_baseline leg only
@@ -154,6 +155,8 @@ def main():
         elapsed = float(t.item())
 
     if rank != 0:
+        torch.distributed.barrier()              # rank 0 finishes its report, then everybody leaves together
+        torch.distributed.destroy_process_group()
         return
     rays_total = args.rays * world * args.steps
     value = rays_total / elapsed
@@ -247,6 +250,9 @@ def main():
                                   'sample': '%d training steps of %d rays (same synthetic workload, CPU oracle, fp32, '
                                             'os.cpu_count=%d)' % (args.cpu_steps, args.cpu_rays, os.cpu_count())}
     print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -131,9 +131,24 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
                 gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bpe, PL::KSB * jj, ws);
             }
         }
-        // epilogue: ReLU (trunk), activation store, mask, sigma head, split into the next layer's B fragments
+        // epilogue: ReLU (trunk), activation store, mask, sigma head, split into the next layer's B fragments.
+        // Kept free of per-tile branches on `layer`: ReLU is a max with a per-layer bound (0, or -inf for the feature
+        // layer), the sigma head is one block for layer 7.
+        const float lo = layer < 8 ? 0.f : -INFINITY;
+        if (layer == 7) {
+            float sg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float4 w4 = *(const float4 *)(rf + PL::N_WSIG + 16 * t + 4 * q);
+                sg[0] = fmaf(w4.x, fmaxf(acc[t][0], 0.f), sg[0]); sg[1] = fmaf(w4.y, fmaxf(acc[t][1], 0.f), sg[1]);
+                sg[2] = fmaf(w4.z, fmaxf(acc[t][2], 0.f), sg[2]); sg[3] = fmaf(w4.w, fmaxf(acc[t][3], 0.f), sg[3]);
+            }
+            float s = (sg[0] + sg[1]) + (sg[2] + sg[3]);
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            sigma_raw = s + rf[PL::N_BHEAD];
+        }
         unsigned mk0 = 0u, mk1 = 0u;
-        float sg[4] = {0.f, 0.f, 0.f, 0.f};
         float *dst = SAVE ? a.acts + (layer < 8 ? a.al.h[layer] : a.al.feat) : nullptr;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
@@ -141,32 +156,19 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int t = 2 * s + u;
-                if (layer < 8) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) x[u][r] = fmaxf(x[u][r], 0.f);
-                }
-                if (SAVE) store_tile16(dst, p, W, q, t, x[u], valid);
-                if (layer < 8) {
+                for (int r = 0; r < 4; ++r) x[u][r] = fmaxf(x[u][r], lo);
+                if (SAVE) {
+                    store_tile16(dst, p, W, q, t, x[u], valid);
                     unsigned m = 0;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) m |= (x[u][r] > 0.f ? 1u : 0u) << r;
                     if (t < 8) mk0 |= m << (4 * t); else mk1 |= m << (4 * (t - 8));
                 }
-                if (layer == 7) {
-                    const float4 w4 = *(const float4 *)(rf + PL::N_WSIG + 16 * t + 4 * q);
-                    sg[0] = fmaf(w4.x, x[u][0], sg[0]); sg[1] = fmaf(w4.y, x[u][1], sg[1]);
-                    sg[2] = fmaf(w4.z, x[u][2], sg[2]); sg[3] = fmaf(w4.w, x[u][3], sg[3]);
-                }
             }
             split_pair<NS>(x[0], x[1], bin[s]);
         }
         if (SAVE && valid && layer < 8) *(uint2 *)(a.acts + a.al.hm[layer] + ((size_t)p * 4 + q) * 2) = make_uint2(mk0, mk1);
-        if (layer == 7) {
-            float s = (sg[0] + sg[1]) + (sg[2] + sg[3]);
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            sigma_raw = s + rf[PL::N_BHEAD];
-        }
     }
 
     {

@@ -44,6 +44,10 @@ extern "C" {
 #define VIPNERF_PREC_FP32   0
 #define VIPNERF_PREC_BF16X3 1
 #define VIPNERF_PREC_BF16X6 2
+/* FP16X3: operands split into 2 fp16 parts (11 bits each), 3 cross terms on v_mfma_f32_16x16x32_f16 with fp32
+ * accumulation, power-of-two operand scaling (vip-nerf_amd/csrc/vipnerf_bf16n.h): ~2^-21 relative error per product
+ * at the cost of BF16X3.  Narrow lane layout only. */
+#define VIPNERF_PREC_FP16X3 3
 
 /* Lane layout of the BF16X3 / BF16X6 kernels (same arithmetic, same stored activations):
  * WIDE: 32-point waves on 32x32x16 MFMA, one wave per SIMD; NARROW: 16-point waves on 16x16x32, two waves per SIMD. */

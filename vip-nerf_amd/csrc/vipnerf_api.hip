@@ -70,7 +70,7 @@ static int check_cfg(const vipnerf_config *cfg) {
         set_error("n_fine=%d unsupported (n_coarse+n_fine multiple of 32, <= 256)", cfg->n_fine); return VIPNERF_E_UNSUPPORTED; }
     if (cfg->n_sec < 0 || cfg->n_sec > VIPNERF_MAX_SEC) {
         set_error("n_sec=%d unsupported (0..%d)", cfg->n_sec, VIPNERF_MAX_SEC); return VIPNERF_E_UNSUPPORTED; }
-    if (cfg->precision < 0 || cfg->precision > VIPNERF_PREC_BF16X6) {
+    if (cfg->precision < 0 || cfg->precision > VIPNERF_PREC_FP16X3) {
         set_error("precision=%d unsupported", cfg->precision); return VIPNERF_E_UNSUPPORTED; }
     if (cfg->bf16_layout < VIPNERF_LAYOUT_DEFAULT || cfg->bf16_layout > VIPNERF_LAYOUT_NARROW) {
         set_error("bf16_layout=%d unsupported", cfg->bf16_layout); return VIPNERF_E_UNSUPPORTED; }
@@ -89,7 +89,8 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st);
 #ifndef VN_BF16_NARROW_DEFAULT
 #define VN_BF16_NARROW_DEFAULT 1
 #endif
-static bool bf16_narrow(int layout = VIPNERF_LAYOUT_DEFAULT) {
+static bool bf16_narrow(int layout = VIPNERF_LAYOUT_DEFAULT, int precision = 0) {
+    if (precision == VIPNERF_PREC_FP16X3) return true;      // fp16 fragments exist in the narrow layout only
     if (layout == VIPNERF_LAYOUT_WIDE) return false;
     if (layout == VIPNERF_LAYOUT_NARROW) return true;
     static const int v = [] {
@@ -104,7 +105,7 @@ static size_t packed_floats_all(int precision) { return packed_total_floats(prec
 
 static int launch_mlp_fwd_any(MlpFwdArgs &a, int precision, hipStream_t st, int layout = VIPNERF_LAYOUT_DEFAULT) {
     if (precision == VIPNERF_PREC_FP32) return launch_mlp_fwd(a, st);
-    if (bf16_narrow(layout)) {
+    if (bf16_narrow(layout, precision)) {
         a.packed += packed_total_floats(precision);   // [fp32][wide] precede the narrow image
         return launch_mlp_fwd_bf16n(a, precision, st);
     }
@@ -170,10 +171,11 @@ int32_t vipnerf_pack_weights(const vipnerf_mlp_params *params, void *packed, vip
 size_t vipnerf_packed_weights_bytes_p(int32_t precision) { return packed_floats_all(precision) * sizeof(float); }
 
 int32_t vipnerf_pack_weights_p(const vipnerf_mlp_params *params, int32_t precision, void *packed, vipnerf_stream_t stream) {
-    if (precision < 0 || precision > VIPNERF_PREC_BF16X6) { set_error("pack_weights: precision=%d unsupported", precision); return VIPNERF_E_UNSUPPORTED; }
+    if (precision < 0 || precision > VIPNERF_PREC_FP16X3) { set_error("pack_weights: precision=%d unsupported", precision); return VIPNERF_E_UNSUPPORTED; }
     int rc = vipnerf_pack_weights(params, packed, stream);
     if (rc || precision == VIPNERF_PREC_FP32) return rc;
-    if ((rc = launch_pack_bf16(params, precision, (float *)packed + PK_TOTAL_F, (hipStream_t)stream))) return rc;
+    if (precision != VIPNERF_PREC_FP16X3 &&
+        (rc = launch_pack_bf16(params, precision, (float *)packed + PK_TOTAL_F, (hipStream_t)stream))) return rc;
     return launch_pack_bf16n(params, precision, (float *)packed + packed_total_floats(precision), (hipStream_t)stream);
 }
 
@@ -225,7 +227,7 @@ int32_t vipnerf_mlp_forward_p(int64_t n_points, int32_t n_sec, const float *pts,
                               const void *packed, float *sigma, float *rgb, float *vis, float *vis2,
                               vipnerf_stream_t stream) {
     clear_stale_hip_error();
-    if (precision < 0 || precision > VIPNERF_PREC_BF16X6) { set_error("mlp_forward: precision=%d unsupported", precision); return VIPNERF_E_UNSUPPORTED; }
+    if (precision < 0 || precision > VIPNERF_PREC_FP16X3) { set_error("mlp_forward: precision=%d unsupported", precision); return VIPNERF_E_UNSUPPORTED; }
     if (n_points == 0) return VIPNERF_OK;
     if (!pts || !view_dirs || !packed || !sigma || !rgb || !vis || (n_sec > 0 && (!view_dirs2 || !vis2))) {
         set_error("mlp_forward: NULL argument"); return VIPNERF_E_ARG; }
@@ -375,7 +377,7 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
         {
             ProfScope ps(lv ? "mlp_dgrad_fine" : "mlp_dgrad_coarse", st);
             if (cfg->precision == VIPNERF_PREC_FP32) rc = launch_mlp_bwd(mb, st);
-            else if (bf16_narrow(cfg->bf16_layout)) { mb.packed += packed_total_floats(cfg->precision); rc = launch_mlp_bwd_bf16n(mb, cfg->precision, st); }
+            else if (bf16_narrow(cfg->bf16_layout, cfg->precision)) { mb.packed += packed_total_floats(cfg->precision); rc = launch_mlp_bwd_bf16n(mb, cfg->precision, st); }
             else { mb.packed += PK_TOTAL_F; rc = launch_mlp_bwd_bf16(mb, cfg->precision, st); }
             if (rc) return rc;
         }

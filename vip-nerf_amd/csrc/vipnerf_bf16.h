@@ -88,6 +88,24 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&out)[NS]) {
 }
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+// fp16 fragments ("fp16x3", narrow layout only): same fragment shapes, 11-bit parts instead of 8-bit ones
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+template <int NS>
+__device__ __forceinline__ void split8(const float (&x)[8], half8 (&out)[NS]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float r = x[e];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const _Float16 p = (_Float16)r;
+            out[i][e] = p;
+            r = r - (float)p;
+        }
+    }
+}
+__device__ __forceinline__ floatx4 mfma_bf(half8 a, half8 b, floatx4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 __device__ __forceinline__ floatx16 mfma_bf(bf16x8 a, bf16x8 b, floatx16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
@@ -97,8 +115,8 @@ __device__ __forceinline__ floatx4 mfma_bf(bf16x8 a, bf16x8 b, floatx4 c) {
 }
 
 // acc[t] += A(k-step, tile) * B(k-step) over the significant cross terms; smallest terms first
-template <int NS, typename ACC>
-__device__ __forceinline__ ACC mfma_split(const bf16x8 (&a)[NS], const bf16x8 (&b)[NS], ACC c) {
+template <int NS, typename ACC, typename FR>
+__device__ __forceinline__ ACC mfma_split(const FR (&a)[NS], const FR (&b)[NS], ACC c) {
     if (NS == 3) {
         c = mfma_bf(a[1], b[1], c);
         c = mfma_bf(a[2], b[0], c);
@@ -186,9 +204,9 @@ struct WStreamT {
 };
 // group g of a stage (see gemm_stage_bf): reads of group g+D interleaved one by one behind the first MFMAs of group
 // g, then this group's share of the next stage's DMA
-template <int g, int NG, int NT, int NS, int G, int D, int NBUF, int NB, typename WS, typename ACC>
-__device__ __forceinline__ void gemm_groups_bf(const float *base, ACC (&acc)[NT], const bf16x8 (&B)[NB][NS], int ks0,
-                                               bf16x8 (&fr)[NBUF][G][NS], WS &ws) {
+template <int g, int NG, int NT, int NS, int G, int D, int NBUF, int NB, typename WS, typename ACC, typename FR>
+__device__ __forceinline__ void gemm_groups_bf(const float *base, ACC (&acc)[NT], const FR (&B)[NB][NS], int ks0,
+                                               FR (&fr)[NBUF][G][NS], WS &ws) {
     if constexpr (g < NG) {
         constexpr int R = (g + D < NG) ? G * NS : 0;           // ds_read_b128 in this group
         constexpr int M = G * NS * (NS + 1) / 2;               // MFMAs in this group
@@ -197,7 +215,7 @@ __device__ __forceinline__ void gemm_groups_bf(const float *base, ACC (&acc)[NT]
             for (int tt = 0; tt < G; ++tt)
 #pragma unroll
                 for (int i = 0; i < NS; ++i)
-                    fr[(g + D) % NBUF][tt][i] = *(const bf16x8 *)(base + (((g + D) * G + tt) * NS + i) * CHUNK_F);
+                    fr[(g + D) % NBUF][tt][i] = *(const FR *)(base + (((g + D) * G + tt) * NS + i) * CHUNK_F);
         }
 #pragma unroll
         for (int tt = 0; tt < G; ++tt) {
@@ -234,9 +252,9 @@ __device__ __forceinline__ void gemm_groups_bf(const float *base, ACC (&acc)[NT]
 struct NoStream {
     __device__ __forceinline__ void prefetch() {}
 };
-template <int NT, int NKS, int NS, int NB, typename WS, typename ACC>
+template <int NT, int NKS, int NS, int NB, typename WS, typename ACC, typename FR>
 __device__ __forceinline__ void gemm_stage_bf(const float *stage, int lane, ACC (&acc)[NT],
-                                              const bf16x8 (&B)[NB][NS], int ks0, WS &ws) {
+                                              const FR (&B)[NB][NS], int ks0, WS &ws) {
     // narrow layout (floatx4 accumulators, 256 registers per wave) in bf16x6: one tile per group, two groups ahead
     constexpr bool TIGHT = sizeof(ACC) == 16 && NS == 3;
     constexpr int G = TIGHT ? 1 : 2;
@@ -244,14 +262,14 @@ __device__ __forceinline__ void gemm_stage_bf(const float *stage, int lane, ACC 
     constexpr int NBUF = D + 1;
     constexpr int NG = NKS * NT / G;
     static_assert(NT % G == 0 && NG >= D, "group shape");
-    bf16x8 fr[NBUF][G][NS];
+    FR fr[NBUF][G][NS];
     const float *base = stage + lane * 4;
 #pragma unroll
     for (int g = 0; g < D; ++g)
 #pragma unroll
         for (int tt = 0; tt < G; ++tt)
 #pragma unroll
-            for (int i = 0; i < NS; ++i) fr[g][tt][i] = *(const bf16x8 *)(base + ((g * G + tt) * NS + i) * CHUNK_F);
+            for (int i = 0; i < NS; ++i) fr[g][tt][i] = *(const FR *)(base + ((g * G + tt) * NS + i) * CHUNK_F);
     __builtin_amdgcn_sched_barrier(0);
     gemm_groups_bf<0, NG, NT, NS, G, D, NBUF>(base, acc, B, ks0, fr, ws);
 }

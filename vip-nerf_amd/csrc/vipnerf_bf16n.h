@@ -84,8 +84,25 @@ struct BnPlan {
 };
 
 __host__ __device__ inline size_t packed_narrow_floats(int precision) {
-    return precision == 1 ? BnPlan<2>::PK_TOTAL_F : (precision == 2 ? BnPlan<3>::PK_TOTAL_F : 0);
+    return (precision == 1 || precision == 3) ? BnPlan<2>::PK_TOTAL_F : (precision == 2 ? BnPlan<3>::PK_TOTAL_F : 0);
 }
+
+// "fp16x3" (VIPNERF_PREC_FP16X3): the narrow kernels with fp16 fragments, x = x0 + x1 with 11-bit parts, three cross
+// terms a0b0 + a0b1 + a1b0 on v_mfma_f32_16x16x32_f16: per-product error <= ~3 * 2^-22 (the dropped a1b1 and the two
+// residuals), i.e. close to fp32, at the MFMA count and weight-stream size of bf16x3.  fp16 has 5 exponent bits, so
+// operands are moved into its comfortable range by exact powers of two: weights are packed as 2^8 w (|w| ~ 0.06 ->
+// ~16: the low part 2^-11 * 16 is a normal fp16 number, and 2^8 |w| < 65504 up to |w| = 255), the B operands
+// (activations, encodings) are split as 2^4 x (|x| < 4094), accumulators start at 2^12 bias and the epilogue takes
+// 2^-12 off again -- all exact in fp32.  What falls below fp16's normal range is at most 2^-14-ish of an operand whose
+// partner is O(10): an absolute error far below the 2^-22 of the large terms, whether or not the MFMA flushes it.
+#if defined(VN_F16_WS)
+constexpr float F16_WSCALE = VN_F16_WS, F16_XSCALE = VN_F16_XS;    // diagnostic build
+#else
+constexpr float F16_WSCALE = 256.f;           // weights
+constexpr float F16_XSCALE = 16.f;            // B operands of the forward pass
+#endif
+constexpr float F16_ACC_SCALE = F16_WSCALE * F16_XSCALE;
+constexpr float F16_ACC_UNSCALE = 1.f / F16_ACC_SCALE;
 
 #if defined(__HIPCC__)
 // C/D tile T of a narrow fragment <-> row-major [P][ld]: lane (j, q) owns features 16T + 4q .. +3
@@ -101,13 +118,15 @@ __device__ __forceinline__ floatx4 load_tile16(const float *base, int64_t p, int
     return v;
 }
 // two C/D tiles (2s, 2s+1) -> the NS-part B fragment of k-step s
-template <int NS>
-__device__ __forceinline__ void split_pair(const floatx4 &lo, const floatx4 &hi, bf16x8 (&out)[NS]) {
+template <int NS, typename FR>
+__device__ __forceinline__ void split_pair(const floatx4 &lo, const floatx4 &hi, FR (&out)[NS]) {
     const float xs[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     split8<NS>(xs, out);
 }
+template <bool F16> struct FragOf { typedef bf16x8 type; };
+template <> struct FragOf<true> { typedef half8 type; };
 #endif
 
-int launch_pack_bf16n(const vipnerf_mlp_params *p, int precision, void *packed_bn, hipStream_t st);
+int launch_pack_bf16n(const vipnerf_mlp_params *p, int precision, void *packed_bn, hipStream_t st);   // precision 1, 2 or 3
 
 }  // namespace vn

@@ -69,9 +69,14 @@ __device__ __forceinline__ void store_d16(float *row, int q, const float (&pd)[1
     else { row[DVE + 2] = 0.f; row[DVE + 3] = 0.f; row[DVE + 4] = 0.f; }
 }
 
-template <bool SAVE, int NS>
+// F16: fp16 fragments with power-of-two operand scaling (vipnerf_bf16n.h); otherwise bf16 fragments
+template <bool SAVE, int NS, bool F16>
 __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) {
     typedef BnPlan<NS> PL;
+    typedef typename FragOf<F16>::type FR;
+    constexpr float XS = F16 ? F16_XSCALE : 1.f;           // B operands are split as XS * x
+    constexpr float AS = F16 ? F16_ACC_SCALE : 1.f;        // accumulators hold AS * (pre-activation)
+    constexpr float AU = F16 ? F16_ACC_UNSCALE : 1.f;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *res = lds;
     float *stage_buf = lds + PL::R_TOTAL_PAD;
@@ -98,8 +103,14 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
         encode_x16(pc0.x, q, pe);
     }
     if (SAVE && valid) store_x16(a.acts + a.al.pex + (size_t)p * DPE_PAD, q, pe);
+    if (F16) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pe[s][e] *= XS;
+    }
 
-    bf16x8 bin[8][NS];                       // the layer input as B fragments: k-step s <- C/D tiles 2s, 2s+1
+    FR bin[8][NS];                           // the layer input as B fragments: k-step s <- C/D tiles 2s, 2s+1
     floatx4 acc[16];
     float sigma_raw = 0.f;
 
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const float4 b4 = *(const float4 *)(bias + 16 * t);
-            acc[t][0] = b4.x; acc[t][1] = b4.y; acc[t][2] = b4.z; acc[t][3] = b4.w;
+            acc[t][0] = b4.x * AS; acc[t][1] = b4.y * AS; acc[t][2] = b4.z * AS; acc[t][3] = b4.w * AS;
         }
 
         if (layer != 0) {
@@ -122,7 +133,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             }
         }
         if (layer == 0 || layer == SKIP_LAYER) {         // gamma(x) columns last: bin is dead, its registers hold bpe
-            bf16x8 bpe[2][NS];
+            FR bpe[2][NS];
 #pragma unroll
             for (int s = 0; s < 2; ++s) split8<NS>(pe[s], bpe[s]);
 #pragma unroll
@@ -140,8 +151,8 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const float4 w4 = *(const float4 *)(rf + PL::N_WSIG + 16 * t + 4 * q);
-                sg[0] = fmaf(w4.x, fmaxf(acc[t][0], 0.f), sg[0]); sg[1] = fmaf(w4.y, fmaxf(acc[t][1], 0.f), sg[1]);
-                sg[2] = fmaf(w4.z, fmaxf(acc[t][2], 0.f), sg[2]); sg[3] = fmaf(w4.w, fmaxf(acc[t][3], 0.f), sg[3]);
+                sg[0] = fmaf(w4.x, fmaxf(acc[t][0] * AU, 0.f), sg[0]); sg[1] = fmaf(w4.y, fmaxf(acc[t][1] * AU, 0.f), sg[1]);
+                sg[2] = fmaf(w4.z, fmaxf(acc[t][2] * AU, 0.f), sg[2]); sg[3] = fmaf(w4.w, fmaxf(acc[t][3] * AU, 0.f), sg[3]);
             }
             float s = (sg[0] + sg[1]) + (sg[2] + sg[3]);
             s += __shfl_xor(s, 16, 64);
@@ -157,7 +168,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             for (int u = 0; u < 2; ++u) {
                 const int t = 2 * s + u;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) x[u][r] = fmaxf(x[u][r], lo);
+                for (int r = 0; r < 4; ++r) x[u][r] = fmaxf(x[u][r] * AU, lo);
                 if (SAVE) {
                     store_tile16(dst, p, W, q, t, x[u], valid);
                     unsigned m = 0;
@@ -166,6 +177,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
                     if (t < 8) mk0 |= m << (4 * t); else mk1 |= m << (4 * (t - 8));
                 }
             }
+            if (F16) { x[0] *= XS; x[1] *= XS; }
             split_pair<NS>(x[0], x[1], bin[s]);
         }
         if (SAVE && valid && layer < 8) *(uint2 *)(a.acts + a.al.hm[layer] + ((size_t)p * 4 + q) * 2) = make_uint2(mk0, mk1);
@@ -186,7 +198,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const float4 b4 = *(const float4 *)(rf + PL::N_BVIEW + 16 * t + 4 * q);
-        vb[t][0] = b4.x; vb[t][1] = b4.y; vb[t][2] = b4.z; vb[t][3] = b4.w;
+        vb[t][0] = b4.x * AS; vb[t][1] = b4.y * AS; vb[t][2] = b4.z * AS; vb[t][3] = b4.w * AS;
     }
 #pragma unroll
     for (int jj = 0; jj < PL::ST_VIEW_F; ++jj) {
@@ -201,8 +213,13 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
         else secondary_dir(a.src, pc, dsel - 1, dir);
         float ped[1][8];
         encode_d16(dir, q, ped);
-        bf16x8 bpd[1][NS];
-        split8<NS>(ped[0], bpd[0]);
+        FR bpd[1][NS];
+        {
+            float sc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sc[e] = ped[0][e] * XS;
+            split8<NS>(sc, bpd[0]);
+        }
         floatx4 g[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) g[t] = vb[t];
@@ -210,7 +227,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) g[t][r] = fmaxf(g[t][r], 0.f);
+            for (int r = 0; r < 4; ++r) g[t][r] = fmaxf(g[t][r] * AU, 0.f);
         if (SAVE) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) store_tile16(a.acts + a.al.g[dsel], p, WV, q, t, g[t], valid);
@@ -245,11 +262,11 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
     }
 }
 
-template <bool SAVE, int NS>
+template <bool SAVE, int NS, bool F16 = false>
 static int launch_one_n(const MlpFwdArgs &a, unsigned grid, hipStream_t st) {
     const size_t lds = (size_t)BnPlan<NS>::LDS_F * sizeof(float);
-    VN_HIP(hipFuncSetAttribute((const void *)k_mlp_fwd_bf16n<SAVE, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_mlp_fwd_bf16n<SAVE, NS>), dim3(grid), dim3(BnPlan<NS>::WG), lds, st, a);
+    VN_HIP(hipFuncSetAttribute((const void *)k_mlp_fwd_bf16n<SAVE, NS, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_mlp_fwd_bf16n<SAVE, NS, F16>), dim3(grid), dim3(BnPlan<NS>::WG), lds, st, a);
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;
 }
@@ -260,6 +277,7 @@ int launch_mlp_fwd_bf16n(const MlpFwdArgs &a, int precision, hipStream_t st) {
     const unsigned grid = (unsigned)((a.src.P + MLP_PTS_PER_WG - 1) / MLP_PTS_PER_WG);
     if (precision == 1) return a.acts ? launch_one_n<true, 2>(a, grid, st) : launch_one_n<false, 2>(a, grid, st);
     if (precision == 2) return a.acts ? launch_one_n<true, 3>(a, grid, st) : launch_one_n<false, 3>(a, grid, st);
+    if (precision == 3) return a.acts ? launch_one_n<true, 2, true>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);
     set_error("mlp_fwd_bf16n: precision %d", precision);
     return VIPNERF_E_ARG;
 }

@@ -10,13 +10,25 @@ struct PackBnArgs {
     uint32_t *out;
 };
 
+__device__ __forceinline__ _Float16 split_part_h(float x, int i) {
+    _Float16 p = (_Float16)x;
+    for (int k = 0; k < i; ++k) { x = x - (float)p; p = (_Float16)x; }
+    return p;
+}
+template <bool F16>
 __device__ __forceinline__ uint32_t pack2n(float w0, float w1, int part) {
-    const __bf16 a = split_part(w0, part), b = split_part(w1, part);
-    const uint16_t ua = __builtin_bit_cast(uint16_t, a), ub = __builtin_bit_cast(uint16_t, b);
+    uint16_t ua, ub;
+    if (F16) {
+        ua = __builtin_bit_cast(uint16_t, split_part_h(w0 * F16_WSCALE, part));
+        ub = __builtin_bit_cast(uint16_t, split_part_h(w1 * F16_WSCALE, part));
+    } else {
+        ua = __builtin_bit_cast(uint16_t, split_part(w0, part));
+        ub = __builtin_bit_cast(uint16_t, split_part(w1, part));
+    }
     return (uint32_t)ua | ((uint32_t)ub << 16);
 }
 
-template <int NS>
+template <int NS, bool F16>
 __global__ void k_pack_bf16n(PackBnArgs a) {
     typedef BnPlan<NS> PL;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,7 +86,7 @@ __global__ void k_pack_bf16n(PackBnArgs a) {
                 }
             }
         }
-        cell = pack2n(v[0], v[1], part);
+        cell = pack2n<F16>(v[0], v[1], part);
     } else {
         const int i0 = (int)(idx - PL::PK_RES);
         if (i0 < PL::R_DIRW_F) {                                                   // direction columns, chunk t * NS + part
@@ -85,7 +97,7 @@ __global__ void k_pack_bf16n(PackBnArgs a) {
                 const int kk = dir_feat16(q, e0 + u);
                 v[u] = kk >= 0 ? a.p.p[P_VW][(size_t)(16 * t + i) * (W + DVE) + W + kk] : 0.f;
             }
-            cell = pack2n(v[0], v[1], part);
+            cell = pack2n<F16>(v[0], v[1], part);
         } else if (i0 < PL::R_TOTAL) {                                             // fp32 biases / heads, natural order
             const int f = i0 - PL::R_F32;
             float v = 0.f;
@@ -110,9 +122,11 @@ int launch_pack_bf16n(const vipnerf_mlp_params *p, int precision, void *packed_b
     a.out = (uint32_t *)packed_bn;
     const int bs = 256;
     if (precision == 1) {
-        hipLaunchKernelGGL(k_pack_bf16n<2>, dim3((unsigned)((BnPlan<2>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);
+        hipLaunchKernelGGL((k_pack_bf16n<2, false>), dim3((unsigned)((BnPlan<2>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);
     } else if (precision == 2) {
-        hipLaunchKernelGGL(k_pack_bf16n<3>, dim3((unsigned)((BnPlan<3>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);
+        hipLaunchKernelGGL((k_pack_bf16n<3, false>), dim3((unsigned)((BnPlan<3>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);
+    } else if (precision == 3) {
+        hipLaunchKernelGGL((k_pack_bf16n<2, true>), dim3((unsigned)((BnPlan<2>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);
     } else {
         set_error("pack_bf16n: precision %d", precision);
         return VIPNERF_E_ARG;

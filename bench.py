@@ -28,12 +28,20 @@ MAC_PER_POINT = 630272          # trunk+sigma+feature 556,800 + 
 POINTS_PER_RAY = 64 + 192
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak (about 6300 GB/s achievable)
+# Weight-gradient stage: bytes the 14 GEMMs of a level must read per point (fp32 operands as stored, each GEMM reading its
+# two operands once; V = 1): 8 x (256+256) + 2 x (256+64) [gamma(x)] + (128+256) [view, feature cols] + (8+256) [sigma head]
+# + 2 x (128+32) [view, direction cols] + 2 x (8+128) [output head] floats = 5880 floats = 23,520 B   
+WGRAD_BYTES_PER_POINT = 4 * (8 * 512 + 2 * 320 + 384 + 264 + 2 * 160 + 2 * 136)
 # fp32-equivalent peak of each arithmetic: the split modes spend 6 / 3 bf16 MFMAs per fp32 multiply-add
 PEAK = {'fp32': (FP32_MFMA_PEAK_TFLOPS, 'fp32 MFMA peak (v_mfma_f32_32x32x2_f32)'),
         'bf16x6': (BF16_MFMA_PEAK_TFLOPS / 6, 'dense bf16 MFMA peak 2500 TFLOP/s / 6 cross terms per fp32-grade product'),
-        'bf16x3': (BF16_MFMA_PEAK_TFLOPS / 3, 'dense bf16 MFMA peak 2500 TFLOP/s / 3 cross terms per product')}
+        'bf16x3': (BF16_MFMA_PEAK_TFLOPS / 3, 'dense bf16 MFMA peak 2500 TFLOP/s / 3 cross terms per product'),
+        'fp16x3': (BF16_MFMA_PEAK_TFLOPS / 3, 'dense fp16 MFMA peak 2500 TFLOP/s / 3 cross terms per fp32-grade product')}
 DTYPE = {'fp32': 'f32', 'bf16x6': 'f32 via 3-way bf16 split (6 bf16 MFMAs per product, fp32 accumulate; fp32-grade error)',
-         'bf16x3': 'f32 via 2-way bf16 split (3 bf16 MFMAs per product, fp32 accumulate; ~5e-6 relative error)'}
+         'bf16x3': 'f32 via 2-way bf16 split (3 bf16 MFMAs per product, fp32 accumulate; ~5e-6 relative error)',
+         'fp16x3': 'f32 via 2-way fp16 split (3 fp16 MFMAs per product, fp32 accumulate, power-of-two operand scaling; '
+                   'fp32-grade error)'}
 
 
 def model_configs(n_views=2):
@@ -89,7 +97,7 @@ def main():
     ap.add_argument('--cpu-rays', type=int, default=1024)
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--no-render', action='store_true')
-    ap.add_argument('--precision', default='bf16x6', choices=['fp32', 'bf16x6', 'bf16x3'],
+    ap.add_argument('--precision', default='fp16x3', choices=['fp32', 'bf16x6', 'bf16x3', 'fp16x3'],
                     help='MLP GEMM arithmetic of the headline number (all three are parity-tested; see DESIGN.md)')
     ap.add_argument('--no-other-precisions', action='store_true')
     args = ap.parse_args()
@@ -174,12 +182,25 @@ def main():
     flop_per_launch = MAC_PER_POINT * 2.0 * POINTS_PER_RAY * args.rays
     achieved = flop_per_launch / (stage_ms[dom] * 1e-3) / 1e12 if stage_ms[dom] > 0 else 0.0
     peak, peak_note = PEAK[args.precision]
-    roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': round(peak, 1),
-                'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': None, 'peak_note': peak_note,
-                'frac_of_fp32_mfma_peak': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                'stage_ms_per_step': {k: round(v, 3) for k, v in stage_ms.items()},
-                'other_kernels_ms_per_step': round(other_ms, 3),
-                'step_flop_frac': round(3 * flop_per_launch / (elapsed / args.steps) / 1e12 / peak, 4)}
+    if dom == 'wgrad':
+        # the weight-gradient GEMMs stream both fp32 operands from HBM once per GEMM and are bound by that, not by MFMA
+        bytes_per_step = WGRAD_BYTES_PER_POINT * POINTS_PER_RAY * args.rays
+        gbs = bytes_per_step / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'peak_note': 'HBM3E peak; algorithmic bytes = %d B/point x %d points per step (operands of the 14 GEMMs of '
+                                 'each level, read once per GEMM)' % (WGRAD_BYTES_PER_POINT, POINTS_PER_RAY * args.rays)}
+    else:
+        roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': round(peak, 1),
+                    'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': None, 'peak_note': peak_note,
+                    'frac_of_fp32_mfma_peak': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4)}
+    # the MFMA-bound stages, always reported next to the dominant one
+    roofline['mfma_stages'] = {k: {'achieved_tflops': round(flop_per_launch / (stage_ms[k] * 1e-3) / 1e12, 1),
+                                   'frac': round(flop_per_launch / (stage_ms[k] * 1e-3) / 1e12 / peak, 4)}
+                               for k in ('mlp_fwd', 'mlp_dgrad') if stage_ms[k] > 0}
+    roofline.update({'stage_ms_per_step': {k: round(v, 3) for k, v in stage_ms.items()},
+                     'other_kernels_ms_per_step': round(other_ms, 3),
+                     'step_flop_frac': round(3 * flop_per_launch / (elapsed / args.steps) / 1e12 / peak, 4)})
     # HBM bytes of the dominant stage per step: PMC counters cannot be collected from inside this process; the value
     # is the committed rocprofv3 --pmc measurement of this very command (profiles/r01_pmc_traffic.json), used only
     # when the workload matches the one profiled
@@ -188,8 +209,7 @@ def main():
         if tr['workload']['rays_per_gpu'] == args.rays and tr['workload']['precision'] == args.precision:
             roofline['traffic'] = tr['bytes_per_step'][dom]['total']
             roofline['traffic_note'] = ('HBM bytes per step of this stage, FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 '
-                                        '--pmc passes (profiles/r01_pmc_*_bf16x6.txt); algorithmic: 10.75 KB/point of '
-                                        'activation stores + one 3.5 MB weight image per 128 points from L2')
+                                        '--pmc passes (profiles/r01_pmc_*_fp16x3.txt, profiles/r01_pmc_traffic.json)')
     except (OSError, KeyError, ValueError):
         pass
 
@@ -206,7 +226,7 @@ def main():
     if world == 1 and not args.no_other_precisions:
         # the same step in the other two arithmetics (10 steps each, same process, same batches)
         others = {}
-        for prec in ('fp32', 'bf16x6', 'bf16x3'):
+        for prec in ('fp32', 'bf16x6', 'bf16x3', 'fp16x3'):
             if prec == args.precision:
                 continue
             model.configs['model']['hip_precision'] = prec

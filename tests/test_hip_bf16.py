@@ -1,4 +1,4 @@
-"""The split-precision bf16 MFMA modes (cfg.precision / configs['model']['hip_precision'] = 'bf16x3' | 'bf16x6') against
+"""The split-precision MFMA modes (cfg.precision / configs['model']['hip_precision'] = 'bf16x3' | 'bf16x6' | 'fp16x3') against
 the same golden vectors and the same tolerances as the fp32 path (tests/test_hip_parity.py): outputs within 1e-4
 relative (+1e-5 of the tensor's max), gradients within 2e-3 relative L2."""
 import os
@@ -16,14 +16,14 @@ sys.path.insert(0, os.path.join(ROOT, 'vip-nerf_amd', 'src'))
 from oracle import vipnerf_oracle as vo  # noqa: E402
 import test_hip_parity as tp  # noqa: E402
 
-PRECS = ['bf16x3', 'bf16x6']
+PRECS = ['bf16x3', 'bf16x6', 'fp16x3']
 # the render-level tests run both lane layouts of the split-bf16 kernels (configs['model']['hip_bf16_layout']):
 # 'narrow' (16-point waves, the default) and 'wide' (32-point waves)
-MODES = ['bf16x3', 'bf16x6', 'bf16x3-wide', 'bf16x6-wide']
+MODES = ['bf16x3', 'bf16x6', 'fp16x3', 'bf16x3-wide', 'bf16x6-wide']
 # relative-L2 tolerance on parameter gradients.  bf16x6 is fp32 grade (same bar as the fp32 path).  bf16x3 perturbs
 # activations by ~5e-6 relative, i.e. ~20x more ReLU pre-activations land on the other side of 0 than in fp32, and
 # the error is carried through 8 chained dgrad layers: measured 2-3e-3 on the deepest layer's weights.
-GRAD_TOL = {'bf16x3': 6e-3, 'bf16x6': 2e-3}
+GRAD_TOL = {'bf16x3': 6e-3, 'bf16x6': 2e-3, 'fp16x3': 2e-3}
 
 
 @pytest.fixture(scope='module')

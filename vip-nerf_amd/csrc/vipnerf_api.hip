@@ -382,7 +382,8 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
             if (rc) return rc;
         }
         // 3. weight gradients: dW = dY^T H as MFMA GEMMs over the point axis
-        if ((rc = launch_wgrad(P, V, mb.acts, mb.al, bw, bl, G, cfg->precision, st))) return rc;
+        if ((rc = launch_wgrad(P, V, mb.acts, mb.al, bw, bl, G, cfg->precision, st,
+                               cfg->precision == VIPNERF_PREC_FP16X3 ? (const unsigned *)(bw + bl.gmax) : nullptr))) return rc;
     }
     return VIPNERF_OK;
 }

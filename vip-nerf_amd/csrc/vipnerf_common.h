@@ -127,6 +127,7 @@ struct BwdLayout {
     size_t dyvsum;    // [P][128]
     size_t dq[1 + VIPNERF_MAX_SEC];   // [P][8]: a=0: d(pre-sigmoid rgb,vis), d(sigma_raw); a>=1: (0,0,0,d pre-sigmoid vis2_a)
     size_t dsig, drgb, dvis, dvis2;   // [P], [P][3], [P], [P][V]: dLoss/d(raw network outputs)
+    size_t gmax;      // [64] slot; word 0 = bit pattern of max |d raw output| of the level (FP16X3 gradient scaling)
     size_t partial;   // wgrad partial sums
     size_t total;
 };
@@ -181,6 +182,7 @@ __host__ __device__ inline BwdLayout bwd_layout(size_t P, int V) {
     b.dvis = o; o += P;
     b.dvis2 = o; o += P * (V > 0 ? V : 1);
     o = (o + 63) & ~(size_t)63;
+    b.gmax = o; o += 64;
     b.partial = o; o += wgrad_partial_total(P, V);
     b.total = o;
     return b;
@@ -208,6 +210,21 @@ __device__ __forceinline__ float wave_rscan_add(float v, int lane) {   // inclus
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { float t = __shfl_down(v, o, 64); if (lane + o < 64) v += t; }
     return v;
+}
+
+// FP16X3 gradient scaling.  fp16 operands have 5 exponent bits, and dLoss/d(pre-activation) is ~1e-5 and smaller:
+// the data-gradient pass of that mode works on 2^S * dY, S chosen from the level's largest |d raw output| m so that
+// 2^S m lies in [32, 64) (1000x headroom to fp16's 65504 for growth through the layers; values 2^-19 of the largest
+// still have normal low parts).  Everything in the backward workspace is then 2^S times the true value and the
+// weight-gradient reduction multiplies by 2^-S -- all exact.  m is the bit pattern written by k_seed_absmax.
+__device__ __forceinline__ float grad_scale_from_max(unsigned m_bits) {
+    const float m = __uint_as_float(m_bits);
+    if (!(m > 0.f) || !(m < 3.0e38f)) return 1.f;
+    int e;
+    (void)frexpf(m, &e);                                   // m = f * 2^e, f in [0.5, 1)
+    int S = 6 - e;
+    S = S < -100 ? -100 : (S > 100 ? 100 : S);
+    return ldexpf(1.f, S);
 }
 
 // LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = one 1 KiB chunk per instruction), N consecutive chunks.

@@ -44,6 +44,7 @@ struct MlpBwdArgs {
     ActLayout al;
     float *bwd;                                  // backward scratch base
     BwdLayout bl;
+    const unsigned *gmax;                        // FP16X3: max |seed| slot (grad_scale_from_max); else nullptr
 };
 
 constexpr int MLP_WG = 256;                 // 4 waves, one per SIMD

@@ -14,9 +14,33 @@ __device__ __forceinline__ bool mask_bit16(unsigned m0, unsigned m1, int t, int 
     return ((t < 8 ? m0 >> (4 * t) : m1 >> (4 * (t - 8))) >> r) & 1u;
 }
 
-template <int NS>
+// max over the level of the seeds the data-gradient pass actually starts from -- d(pre-sigmoid rgb, vis, vis2) and
+// d(sigma) where sigma > 0, exactly as k_mlp_bwd_bf16n forms them; non-finite entries are skipped -- written to *slot
+// as the bit pattern of a non-negative float (an unsigned atomicMax orders those; order-independent, deterministic)
+__global__ void k_seed_absmax(MlpBwdArgs a, unsigned *slot) {
+    const float *gb = a.bwd;
+    const int V = a.src.V;
+    float m = 0.f;
+    auto take = [&](float v) { v = fabsf(v); if (v < 3.0e38f) m = fmaxf(m, v); };
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.src.P; p += (int64_t)gridDim.x * blockDim.x) {
+        for (int c = 0; c < 3; ++c) { const float y = a.rgb[3 * p + c]; take(gb[a.bl.drgb + 3 * p + c] * ((1.f - y) * y)); }
+        { const float y = a.vis[p]; take(gb[a.bl.dvis + p] * ((1.f - y) * y)); }
+        for (int v = 0; v < V; ++v) { const float y = a.vis2[p * V + v]; take(gb[a.bl.dvis2 + p * V + v] * ((1.f - y) * y)); }
+        if (a.sigma[p] > 0.f) take(gb[a.bl.dsig + p]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slot, __float_as_uint(m));
+}
+
+// F16: fp16 fragments (VIPNERF_PREC_FP16X3): W^T is packed as 2^8 W^T, every gradient in the workspace is 2^S times its
+// true value (grad_scale_from_max), accumulators are taken back by 2^-8
+template <int NS, bool F16>
 __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) {
     typedef BnPlan<NS> PL;
+    typedef typename FragOf<F16>::type FR;
+    constexpr float AU = F16 ? 1.f / F16_WSCALE : 1.f;
+    const float gs = (F16 && a.gmax) ? grad_scale_from_max(*a.gmax) : 1.f;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *res = lds;
     float *stage_buf = lds + PL::R_TOTAL_PAD;
@@ -43,12 +67,12 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float y = a.rgb[3 * p + c];
-            dq0[c] = gb[a.bl.drgb + 3 * p + c] * ((1.f - y) * y);
+            dq0[c] = gb[a.bl.drgb + 3 * p + c] * gs * ((1.f - y) * y);
         }
         const float y = a.vis[p];
-        dq0[3] = gb[a.bl.dvis + p] * ((1.f - y) * y);
+        dq0[3] = gb[a.bl.dvis + p] * gs * ((1.f - y) * y);
     }
-    const float dsig_raw = a.sigma[p] > 0.f ? gb[a.bl.dsig + p] : 0.f;
+    const float dsig_raw = a.sigma[p] > 0.f ? gb[a.bl.dsig + p] * gs : 0.f;
     __syncthreads();
 
     // ---------------------------------------------------------------- view branch, per direction
@@ -62,7 +86,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
         else {
             const float y = a.vis2[p * V + (dsel - 1)];
             dq[0] = dq[1] = dq[2] = 0.f;
-            dq[3] = gb[a.bl.dvis2 + p * V + (dsel - 1)] * ((1.f - y) * y);
+            dq[3] = gb[a.bl.dvis2 + p * V + (dsel - 1)] * gs * ((1.f - y) * y);
         }
         if (valid && q == 0) {
             float *row = a.bwd + a.bl.dq[dsel] + (size_t)p * 8;
@@ -92,7 +116,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
     for (int t = 0; t < 8; ++t) store_tile16(a.bwd + a.bl.dyvsum, p, WV, q, t, vsum[t], valid);
 
     // ---------------------------------------------------------------- d(feature) = W_vf^T sum_a dYv_a   (K = 128: 4 k-steps)
-    bf16x8 bin[8][NS];
+    FR bin[8][NS];
     floatx4 acc[16];
 #pragma unroll
     for (int s = 0; s < 4; ++s) split_pair<NS>(vsum[2 * s], vsum[2 * s + 1], bin[s]);
@@ -106,9 +130,10 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
     // dY of the feature layer: store (fp32, for wgrad) and split
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        store_tile16(a.bwd + a.bl.dyf, p, W, q, 2 * s, acc[2 * s], valid);
-        store_tile16(a.bwd + a.bl.dyf, p, W, q, 2 * s + 1, acc[2 * s + 1], valid);
-        split_pair<NS>(acc[2 * s], acc[2 * s + 1], bin[s]);
+        const floatx4 x0 = acc[2 * s] * AU, x1 = acc[2 * s + 1] * AU;
+        store_tile16(a.bwd + a.bl.dyf, p, W, q, 2 * s, x0, valid);
+        store_tile16(a.bwd + a.bl.dyf, p, W, q, 2 * s + 1, x1, valid);
+        split_pair<NS>(x0, x1, bin[s]);
     }
 
     // ---------------------------------------------------------------- feature layer, then layers 7..1
@@ -126,7 +151,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
         float *dst = a.bwd + a.bl.dy[layer];
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            floatx4 x[2] = {acc[2 * s], acc[2 * s + 1]};
+            floatx4 x[2] = {acc[2 * s] * AU, acc[2 * s + 1] * AU};
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int t = 2 * s + u;
@@ -144,11 +169,11 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
     }
 }
 
-template <int NS>
+template <int NS, bool F16 = false>
 static int launch_one_bwd_n(const MlpBwdArgs &a, unsigned grid, hipStream_t st) {
     const size_t lds = (size_t)BnPlan<NS>::LDS_F * sizeof(float);
-    VN_HIP(hipFuncSetAttribute((const void *)k_mlp_bwd_bf16n<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_mlp_bwd_bf16n<NS>), dim3(grid), dim3(BnPlan<NS>::WG), lds, st, a);
+    VN_HIP(hipFuncSetAttribute((const void *)k_mlp_bwd_bf16n<NS, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_mlp_bwd_bf16n<NS, F16>), dim3(grid), dim3(BnPlan<NS>::WG), lds, st, a);
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;
 }
@@ -158,6 +183,16 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
     const unsigned grid = (unsigned)((a.src.P + MLP_PTS_PER_WG - 1) / MLP_PTS_PER_WG);
     if (precision == 1) return launch_one_bwd_n<2>(a, grid, st);
     if (precision == 2) return launch_one_bwd_n<3>(a, grid, st);
+    if (precision == 3) {
+        // the level's largest seed first (one pass over 5+V floats per point)
+        unsigned *slot = (unsigned *)(a.bwd + a.bl.gmax);
+        VN_HIP(hipMemsetAsync(slot, 0, sizeof(unsigned), st));
+        hipLaunchKernelGGL(k_seed_absmax, dim3(1024), dim3(256), 0, st, a, slot);
+        VN_HIP(hipGetLastError());
+        MlpBwdArgs b = a;
+        b.gmax = slot;
+        return launch_one_bwd_n<2, true>(b, grid, st);
+    }
     set_error("mlp_bwd_bf16n: precision %d", precision);
     return VIPNERF_E_ARG;
 }

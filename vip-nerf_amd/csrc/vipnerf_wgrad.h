@@ -4,5 +4,5 @@
 
 namespace vn {
 int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float *bwd, const BwdLayout &bl,
-                 const vipnerf_mlp_grads *G, int precision, hipStream_t st);
+                 const vipnerf_mlp_grads *G, int precision, hipStream_t st, const unsigned *gmax = nullptr);
 }

@@ -42,6 +42,7 @@ constexpr int WG_MAX_GROUP = 24;
 struct WgReduceArgs {
     WgGroup g[WG_MAX_GROUP];
     const float *partial;
+    const unsigned *gmax;                     // FP16X3: the partials are 2^S times the gradients (grad_scale_from_max)
 };
 
 __device__ __forceinline__ floatx16 mfma32(float a, float b, floatx16 c) {
@@ -455,6 +456,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgReduceArgs a) {
     const int n_w = g.m_valid * g.k_valid;
     const int n_all = n_w + (g.dbias ? g.m_valid : 0);
     const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const float unscale = a.gmax ? 1.f / grad_scale_from_max(*a.gmax) : 1.f;
     for (int e0 = blockIdx.x * 64; e0 < n_all; e0 += gridDim.x * 64) {
         const int e = e0 + el;
         float s = 0.f;
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgReduceArgs a) {
         }
         sh[q][el] = s;
         __syncthreads();
-        if (q == 0 && e < n_all) *dst = (sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el]);
+        if (q == 0 && e < n_all) *dst = ((sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el])) * unscale;
         __syncthreads();
     }
 }
@@ -494,7 +496,7 @@ static int launch_class(const WgArgs &args, int n_desc, int n_chunks, hipStream_
 }
 
 int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float *bwd, const BwdLayout &bl,
-                 const vipnerf_mlp_grads *G, int precision, hipStream_t st) {
+                 const vipnerf_mlp_grads *G, int precision, hipStream_t st, const unsigned *gmax) {
     if (P == 0) return VIPNERF_OK;
     const int n_chunks = wgrad_chunks(P), n_small = wgrad_chunks_small(P), n_single = wgrad_chunks_single(P);
     const int chunk_pts = wgrad_chunk_pts(P), chunk_small = chunk_pts / WGRAD_SMALL_SPLIT, chunk_single = chunk_pts / WGRAD_SINGLE_SPLIT;
@@ -507,6 +509,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
     auto init = [&](WgArgs &w, int cp) { w.P = (int64_t)P; w.chunk_pts = cp; w.partial = partial; };
     init(c88, chunk_pts); init(c82, chunk_small); init(c48, chunk_single); init(c41, chunk_small); init(c18, chunk_single); init(c14, chunk_small);
     red.partial = partial;
+    red.gmax = gmax;
 
     // adds one GEMM; returns its partial offset
     auto add = [&](WgArgs &w, int &n, int Mp, int Kp, const float *A, int lda, int m_load, const float *B, int ldb, int k_load) {

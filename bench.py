@@ -31,7 +31,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak (about 6300 GB/s achievable)
 # Weight-gradient stage: bytes the 14 GEMMs of a level must read per point (fp32 operands as stored, each GEMM reading its
 # two operands once; V = 1): 8 x (256+256) + 2 x (256+64) [gamma(x)] + (128+256) [view, feature cols] + (8+256) [sigma head]
-# + 2 x (128+32) [view, direction cols] + 2 x (8+128) [output head] floats = 5880 floats = 23,520 B   
+# + 2 x (128+32) [view, direction cols] + 2 x (8+128) [output head] floats = 5976 floats = 23,904 B   
 WGRAD_BYTES_PER_POINT = 4 * (8 * 512 + 2 * 320 + 384 + 264 + 2 * 160 + 2 * 136)
 # fp32-equivalent peak of each arithmetic: the split modes spend 6 / 3 bf16 MFMAs per fp32 multiply-add
 PEAK = {'fp32': (FP32_MFMA_PEAK_TFLOPS, 'fp32 MFMA peak (v_mfma_f32_32x32x2_f32)'),

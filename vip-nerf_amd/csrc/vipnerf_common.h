@@ -161,7 +161,7 @@ __host__ __device__ inline int wgrad_chunks_single(size_t P) {
 }
 // floats of partial output: sum over GEMMs of chunks * (Mp*Kp + Mp)   (Mp for the bias column sums)
 __host__ __device__ inline size_t wgrad_partial_total(size_t P, int V) {
-    size_t big = 8 * (size_t)(256 * 256 + 256);     // layers 1-4, 5(h part), 6, 7, feature
+    size_t big = 8 * (size_t)(256 * 256 + 256) + 320;   // layers 1-4, 5(h part), 6, 7, feature (+ the sigma head's column sums)
     size_t sm = 0, single = 0;
     sm += 2 * (size_t)(256 * 64 + 256);             // layer 0, layer 5 gamma(x) part
     single += (size_t)(32 * 256 + 32);              // sigma head

@@ -19,8 +19,13 @@ struct WgDesc {
     const float *B; int ldb; int k_load;
     size_t part_off;                          // float offset of this GEMM's partials (chunk 0)
     int n_chunks;                             // chunks of this GEMM (workgroups beyond it exit)
-    size_t part_stride;                       // floats per chunk: Mp*Kp + Mp
+    size_t part_stride;                       // floats per chunk: Mp*Kp + Mp (+ WCOL_EXTRA with wcol)
+    // 256x256 split-precision kernel only: a per-point weight column w[p] = wcol[p * wcol_stride].  The workgroup also
+    // accumulates sum_p w[p] * B[p][0..256) and sum_p w[p] into its partial (after the bias sums) -- the weight and
+    // bias gradient of a 1-output head fed by B (the sigma head reads the same h_8 as the feature layer's GEMM)
+    const float *wcol; int wcol_stride;
 };
+constexpr int WCOL_EXTRA = 256 + 64;          // 256 weighted column sums, the weight sum, pad
 constexpr int WG_MAX_DESC = 12;
 struct WgArgs {
     WgDesc d[WG_MAX_DESC];
@@ -322,7 +327,8 @@ static int launch_bf16x3(const WgArgs &args, int n_desc, int n_chunks, hipStream
 // that write.  LDS plane layout: [feature][4 slots of 8 points], slot XOR-swizzled by (feature >> 2) & 3 so that
 // the 16-lane groups of ds_read_b128 hit 16 distinct slots.  The order of the 32 points inside a block is a fixed
 // permutation (slot = loading wave), identical for A and B, which a contraction index may be.
-__global__ __launch_bounds__(256) void k_wgrad_bf16x3_256(WgArgs a) {
+template <bool HAS_W>
+__device__ __forceinline__ void wgrad_bf16x3_256_body(const WgArgs &a) {
     constexpr int MTW = 2, KTW = 8, Mp = 256, Kp = 256;
     constexpr int PLANE = 256 * 64;                       // bytes: one operand, one part, 256 features x 32 points
     constexpr int BUF = 4 * PLANE;                        // A hi, A lo, B hi, B lo
@@ -344,10 +350,20 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16x3_256(WgArgs a) {
 #pragma unroll
         for (int j = 0; j < KTW; ++j) acc[i][j] = (floatx16)(0.f);
     float bs[4] = {0.f, 0.f, 0.f, 0.f};                   // column sums of A for this thread's 4 features (its 8 points per block)
+    float ws[4] = {0.f, 0.f, 0.f, 0.f}, wsum = 0.f;       // wcol: weighted column sums of B, sum of the weights
+    float wv[8];
+    constexpr bool has_w = HAS_W;
 
     float4 ra[8], rb[8];                                  // rows wave + 4 i, features 4 (tid & 63) .. + 3
     auto gload = [&](int blk) {
         const int64_t pb = p0 + (int64_t)blk * 32;
+        if (has_w) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t row = pb + wave + 4 * i;
+                wv[i] = row < p1 ? d.wcol[(size_t)row * d.wcol_stride] : 0.f;
+            }
+        }
         if (pb + 32 <= p1) {
             const float4 *ta = (const float4 *)(d.A + (size_t)pb * Mp) + tid;
             const float4 *tb = (const float4 *)(d.B + (size_t)pb * Kp) + tid;
@@ -381,9 +397,14 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16x3_256(WgArgs a) {
                 xa[i] = c == 0 ? ra[i].x : (c == 1 ? ra[i].y : (c == 2 ? ra[i].z : ra[i].w));
                 xb[i] = c == 0 ? rb[i].x : (c == 1 ? rb[i].y : (c == 2 ? rb[i].z : rb[i].w));
                 bs[c] += xa[i];
+                if (has_w) ws[c] = fmaf(wv[i], xb[i], ws[c]);
             }
             put(base, 4 * lane + c, xa);
             put(base + 2 * PLANE, 4 * lane + c, xb);
+        }
+        if (has_w) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wsum += wv[i];
         }
     };
 
@@ -445,6 +466,21 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16x3_256(WgArgs a) {
     for (int c = 0; c < 4; ++c) red[wave * 256 + 4 * lane + c] = bs[c];
     __syncthreads();
     part[(size_t)Mp * Kp + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+    if (has_w) {                                           // weighted column sums of B and the weight sum, same folding
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[wave * 256 + 4 * lane + c] = ws[c];
+        if (lane == 0) red[1024 + wave] = wsum;            // every lane of a wave saw the same 8 rows per block
+        __syncthreads();
+        part[(size_t)Mp * Kp + Mp + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+        if (tid == 0) part[(size_t)Mp * Kp + Mp + 256] = (red[1024] + red[1025]) + (red[1026] + red[1027]);
+    }
+}
+// one launch for the eight 256x256 GEMMs; the one that carries a weight column (sigma head) takes the second body, so the
+// other seven run exactly the plain code
+__global__ __launch_bounds__(256) void k_wgrad_bf16x3_256(WgArgs a) {
+    if (a.d[blockIdx.y].wcol) wgrad_bf16x3_256_body<true>(a);
+    else wgrad_bf16x3_256_body<false>(a);
 }
 
 // Ordered sum over chunks.  A workgroup of 256 threads handles 64 consecutive output elements: thread (e, q) sums
@@ -515,6 +551,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
     auto add = [&](WgArgs &w, int &n, int Mp, int Kp, const float *A, int lda, int m_load, const float *B, int ldb, int k_load) {
         WgDesc &d = w.d[n++];
         d.A = A; d.lda = lda; d.m_load = m_load; d.B = B; d.ldb = ldb; d.k_load = k_load;
+        d.wcol = nullptr; d.wcol_stride = 0;
         d.part_off = off; d.part_stride = (size_t)Mp * Kp + Mp;
         d.n_chunks = (&w == &c88) ? n_chunks : ((&w == &c48 || &w == &c18) ? n_single : n_small);
         const size_t o = off;
@@ -546,11 +583,25 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
             group(n_chunks, o, 1, 256, 256, W, W, dW, W, 0, db);
         }
     }
+    const bool fuse_sigma = precision != VIPNERF_PREC_FP32;   // the split-precision 256x256 kernel carries the sigma head
     {   // feature_linear
         const size_t o = add(c88, n88, 256, 256, bwd + bl.dyf, W, W, acts + al.h[D - 1], W, W);
         group(n_chunks, o, 1, 256, 256, W, W, G->g[P_FW], W, 0, G->g[P_FB]);
+        if (fuse_sigma) {
+            // sigma head: dW = sum_p dsigma_raw[p] h_8[p][:], db = sum_p dsigma_raw[p] -- weighted column sums of this
+            // GEMM's B operand, taken while it is staged (no second pass over h_8, no extra launch)
+            WgDesc &d = c88.d[n88 - 1];
+            d.wcol = bwd + bl.dq[0] + 4; d.wcol_stride = 8;
+            d.part_stride += WCOL_EXTRA;
+            off += (size_t)d.n_chunks * WCOL_EXTRA;
+            group(n_chunks, o + (size_t)256 * 256 + 256, 1, 1, 256, 1, W, G->g[P_SW], W, 0, G->g[P_SB]);
+            red.g[ng - 1].part_stride = d.part_stride;
+            red.g[ng - 1].desc_stride = (size_t)n_chunks * d.part_stride;
+            red.g[ng - 2].part_stride = d.part_stride;
+            red.g[ng - 2].desc_stride = (size_t)n_chunks * d.part_stride;
+        }
     }
-    {   // sigma head: A = column 4 of DQ[0]
+    if (!fuse_sigma) {   // sigma head: A = column 4 of DQ[0]
         const size_t o = add(c18, n18, 32, 256, bwd + bl.dq[0] + 4, 8, 4, acts + al.h[D - 1], W, W);
         group(n_single, o, 1, 32, 256, 1, W, G->g[P_SW], W, 0, G->g[P_SB]);
     }
@@ -574,7 +625,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
         }
         group(n_small, first, 1 + V, 32, 128, 4, WV, G->g[P_OW], WV, 0, G->g[P_OB]);
     }
-    if (off != wgrad_partial_total(P, V)) { set_error("wgrad: partial buffer plan mismatch"); return VIPNERF_E_ARG; }
+    if (off > wgrad_partial_total(P, V)) { set_error("wgrad: partial buffer plan mismatch"); return VIPNERF_E_ARG; }
 
     int rc;
     {

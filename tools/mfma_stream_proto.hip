@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void k32(const char *w, int reps, float *out) 
 }
 
 // ---- 8 waves x 16 points, 16x16x32: stage = 2 k-steps x 16 tiles x 2 parts
+template <int ORDER>
 __global__ __launch_bounds__(512) void k16(const char *w, int reps, float *out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -107,12 +108,23 @@ __global__ __launch_bounds__(512) void k16(const char *w, int reps, float *out) 
 #pragma unroll
                         for (int i = 0; i < 2; ++i) fr[(g + 2) % 3][tt][i] = *(const bf16x8 *)(st + (((g + 2) * 2 + tt) * 2 + i) * 1024);
                 }
+                {
+                    const int lin = g * 2, ks = lin / 16, t = lin % 16;
+                    if (ORDER == 0) {
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int lin = g * 2 + tt, ks = lin / 16, t = lin % 16;
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][tt][1], b[ks][0], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][tt][0], b[ks][1], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][tt][0], b[ks][0], acc[t], 0, 0, 0);
+                        for (int tt = 0; tt < 2; ++tt) {
+                            acc[t + tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][tt][1], b[ks][0], acc[t + tt], 0, 0, 0);
+                            acc[t + tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][tt][0], b[ks][1], acc[t + tt], 0, 0, 0);
+                            acc[t + tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][tt][0], b[ks][0], acc[t + tt], 0, 0, 0);
+                        }
+                    } else {
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][0][1], b[ks][0], acc[t], 0, 0, 0);
+                        acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][1][1], b[ks][0], acc[t + 1], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][0][0], b[ks][1], acc[t], 0, 0, 0);
+                        acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][1][0], b[ks][1], acc[t + 1], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][0][0], b[ks][0], acc[t], 0, 0, 0);
+                        acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][1][0], b[ks][0], acc[t + 1], 0, 0, 0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -131,23 +143,25 @@ int main() {
     CK(hipMalloc(&out, 4096 * 512 * 4));
     const size_t lds = 2 * STAGE_BYTES;
     CK(hipFuncSetAttribute((const void *)k32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    CK(hipFuncSetAttribute((const void *)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void *)k16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void *)k16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int reps = 20;
     // MFMA cycles per task per SIMD: 36 stages x 96 MFMAs x 32 cycles (k32: one wave) = 36 x 2 waves x 96 x 16 (k16)
     const double mfma_cycles = 36.0 * 96 * 32;
     for (int grid : {8, 256, 1024}) {
-        for (int which = 0; which < 2; ++which) {
+        for (int which = 0; which < 3; ++which) {
             for (int pass = 0; pass < 2; ++pass) {
                 CK(hipEventRecord(e0));
                 if (which == 0) hipLaunchKernelGGL(k32, dim3(grid), dim3(256), lds, 0, w, pass ? reps : 2, out);
-                else hipLaunchKernelGGL(k16, dim3(grid), dim3(512), lds, 0, w, pass ? reps : 2, out);
+                else if (which == 1) hipLaunchKernelGGL(k16<0>, dim3(grid), dim3(512), lds, 0, w, pass ? reps : 2, out);
+                else hipLaunchKernelGGL(k16<1>, dim3(grid), dim3(512), lds, 0, w, pass ? reps : 2, out);
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             }
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             const double rounds = grid <= 256 ? 1.0 : grid / 256.0;
             const double us_task = ms * 1e3 / reps / rounds;
-            printf("%s grid=%4d  %7.1f us per task   MFMA utilisation at 2.4 GHz: %.2f\n", which ? "16-pt x 8 waves (16x16x32)" : "32-pt x 4 waves (32x32x16)",
+            printf("%s grid=%4d  %7.1f us per task   MFMA utilisation at 2.4 GHz: %.2f\n", which == 2 ? "16-pt x 8 waves, term-major MFMA order" : (which ? "16-pt x 8 waves (16x16x32)            " : "32-pt x 4 waves (32x32x16)            "),
                    grid, us_task, mfma_cycles / 2400.0 / us_task);
         }
     }

@@ -29,10 +29,11 @@ POINTS_PER_RAY = 64 + 192
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak (about 6300 GB/s achievable)
-# Weight-gradient stage: bytes the 14 GEMMs of a level must read per point (fp32 operands as stored, each GEMM reading its
-# two operands once; V = 1): 8 x (256+256) + 2 x (256+64) [gamma(x)] + (128+256) [view, feature cols] + (8+256) [sigma head]
-# + 2 x (128+32) [view, direction cols] + 2 x (8+128) [output head] floats = 5976 floats = 23,904 B   
-WGRAD_BYTES_PER_POINT = 4 * (8 * 512 + 2 * 320 + 384 + 264 + 2 * 160 + 2 * 136)
+# Weight-gradient stage: bytes the GEMMs of a level must read per point (fp32 operands as stored, each GEMM reading its two
+# operands once; V = 1): 8 x (256+256) + 2 x (256+64) [gamma(x)] + (128+256) [view, feature cols] + 1 [sigma head: rides in
+# the feature layer's GEMM, only d(sigma) is extra] + 2 x (128+32) [view, direction cols] + 2 x (8+128) [output head] floats
+# = 5713 floats = 22,852 B   
+WGRAD_BYTES_PER_POINT = 4 * (8 * 512 + 2 * 320 + 384 + 1 + 2 * 160 + 2 * 136)
 # fp32-equivalent peak of each arithmetic: the split modes spend 6 / 3 bf16 MFMAs per fp32 multiply-add
 PEAK = {'fp32': (FP32_MFMA_PEAK_TFLOPS, 'fp32 MFMA peak (v_mfma_f32_32x32x2_f32)'),
         'bf16x6': (BF16_MFMA_PEAK_TFLOPS / 6, 'dense bf16 MFMA peak 2500 TFLOP/s / 6 cross terms per fp32-grade product'),
@@ -188,7 +189,7 @@ def main():
         gbs = bytes_per_step / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None,
-                    'peak_note': 'HBM3E peak; algorithmic bytes = %d B/point x %d points per step (operands of the 14 GEMMs of '
+                    'peak_note': 'HBM3E peak; algorithmic bytes = %d B/point x %d points per step (operands of the GEMMs of '
                                  'each level, read once per GEMM)' % (WGRAD_BYTES_PER_POINT, POINTS_PER_RAY * args.rays)}
     else:
         roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': round(peak, 1),

@@ -34,15 +34,24 @@ __host__ __device__ constexpr int dir_feat16(int q, int e) {
     return e < 6 ? 3 + 6 * q + e : (q == 0 ? e - 6 : (q == 1 && e == 6 ? 2 : -1));
 }
 
+// VN_SKEW (two-part modes only): waves 4..7 -- the second wave of every SIMD -- run one weight stage behind waves 0..3,
+// so that one wave's layer epilogue (VALU, stores) falls under the other's MFMAs instead of both doing it at once.
+// Needs three resident stages, hence half-size ones (32 KiB); WStreamSkew below.  Built, correct (all tests pass with
+// -DVN_SKEW=1) and measured on the same box: forward 4.63 vs 4.35 ms per step, data gradients 5.05 vs 5.01 -- what the
+// overlap gains, twice as many workgroup barriers take back.  Off by default.
+#ifndef VN_SKEW
+#define VN_SKEW 0
+#endif
 template <int NS>
 struct BnPlan {
     static constexpr int WAVES = 8;
     static constexpr int WG = 64 * WAVES;
     static constexpr int NT = 16;                            // 16-feature tiles of a 256-wide layer
-    static constexpr int KSB = NS == 2 ? 2 : 1;              // k-steps (of 32) per stage for a 16-tile layer
-    static constexpr int CH = KSB * NT * NS;                 // chunks (1 KiB) per stage: 64 (NS=2) / 48 (NS=3)
+    static constexpr bool SKEW = NS == 2 && VN_SKEW;
+    static constexpr int KSB = SKEW ? 1 : (NS == 2 ? 2 : 1); // k-steps (of 32) per stage for a 16-tile layer
+    static constexpr int CH = KSB * NT * NS;                 // chunks (1 KiB) per stage: 64 (NS=2) / 48 (NS=3) / 32 (skew)
     static constexpr int STAGE_F = CH * CHUNK_F;
-    static constexpr int NBUF = 2;
+    static constexpr int NBUF = SKEW ? 3 : 2;
     static constexpr int ST_256 = 8 / KSB;                   // 256-deep contraction = 8 k-steps
     static constexpr int ST_PE = 2 / KSB;                    // gamma(x): K = 64 -> 2 k-steps
     static constexpr int KSV = 2 * KSB;                      // k-steps per stage when a stage spans 8 tiles
@@ -105,6 +114,50 @@ constexpr float F16_ACC_SCALE = F16_WSCALE * F16_XSCALE;
 constexpr float F16_ACC_UNSCALE = 1.f / F16_ACC_SCALE;
 
 #if defined(__HIPCC__)
+// Skewed weight stream (VN_SKEW): a ring of three stages.  Time is cut into intervals by one workgroup barrier each
+// (tick); in interval k waves 0..3 consume stage k, waves 4..7 stage k-1, and wave (k+1) mod 8 issues the DMA of stage
+// k+1 into the slot of stage k-2, which the lagging group finished reading before the barrier.  Every wave executes
+// the same number of ticks: the lagging group one idle tick first (begin), the leading group one after its last stage
+// (end).
+template <int CH>
+struct WStreamSkew {
+    const float *g0;
+    float *buf;
+    int n_total, tickno, lag, slot, lane, wave;
+    static constexpr int SF = CH * CHUNK_F;
+    __device__ __forceinline__ void issue(int s) {
+        if (s < n_total && (s & 7) == wave) {
+            const int sl = s % 3;
+            glds_run<CH>(g0 + (size_t)s * SF + lane * 4, buf + sl * SF);
+        }
+    }
+    __device__ __forceinline__ void start(const float *stream, int n_stages, float *lds_buf, int lane_, int wave_) {
+        g0 = stream; buf = lds_buf; n_total = n_stages; tickno = 0; lane = lane_; wave = wave_; lag = wave_ >> 2; slot = 0;
+        issue(0);
+    }
+    __device__ __forceinline__ void tick() {
+        glds_drain();
+        __syncthreads();
+        issue(tickno + 1);
+        ++tickno;
+    }
+    __device__ __forceinline__ void begin() { if (lag) tick(); }
+    __device__ __forceinline__ void end() { if (!lag) tick(); }
+    __device__ __forceinline__ const float *wait() {
+        tick();
+        const float *ret = buf + slot * SF;
+        slot = slot == 2 ? 0 : slot + 1;
+        return ret;
+    }
+    __device__ __forceinline__ void prefetch() {}
+};
+template <typename PL, bool SK> struct StreamOf { typedef WStreamT<PL::CH, PL::NBUF, PL::WAVES, true> type; };
+template <typename PL> struct StreamOf<PL, true> { typedef WStreamSkew<PL::CH> type; };
+__device__ __forceinline__ void stream_begin(...) {}
+__device__ __forceinline__ void stream_end(...) {}
+template <int CH> __device__ __forceinline__ void stream_begin(WStreamSkew<CH> &w) { w.begin(); }
+template <int CH> __device__ __forceinline__ void stream_end(WStreamSkew<CH> &w) { w.end(); }
+
 // C/D tile T of a narrow fragment <-> row-major [P][ld]: lane (j, q) owns features 16T + 4q .. +3
 __device__ __forceinline__ void store_tile16(float *base, int64_t p, int ld, int q, int T, const floatx4 &v, bool valid) {
     if (!valid) return;

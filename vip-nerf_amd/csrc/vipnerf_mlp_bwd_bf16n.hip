@@ -53,7 +53,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
     const int64_t p = valid ? p_raw : a.src.P - 1;
     const int V = a.src.V;
 
-    WStreamT<PL::CH, PL::NBUF, PL::WAVES, VN_ROTATE_DMA> ws;
+    typename StreamOf<PL, PL::SKEW>::type ws;
     ws.start(a.packed + PL::PK_BWD, PL::B_STAGES, stage_buf, lane, wave);
     {
         const float4 *g4 = (const float4 *)(a.packed + PL::PK_RES);
@@ -122,6 +122,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
     for (int s = 0; s < 4; ++s) split_pair<NS>(vsum[2 * s], vsum[2 * s + 1], bin[s]);
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[t] = (floatx4)(0.f);
+    stream_begin(ws);
 #pragma unroll
     for (int jj = 0; jj < PL::ST_VIEW_B; ++jj) {
         const float *st = ws.wait();
@@ -167,6 +168,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
             if (it < 7) split_pair<NS>(x[0], x[1], bin[s]);
         }
     }
+    stream_end(ws);
 }
 
 template <int NS, bool F16 = false>

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
     const bool valid = p_raw < a.src.P;
     const int64_t p = valid ? p_raw : a.src.P - 1;
 
-    WStreamT<PL::CH, PL::NBUF, PL::WAVES, VN_ROTATE_DMA> ws;
+    typename StreamOf<PL, PL::SKEW>::type ws;
     ws.start(a.packed + PL::PK_FWD, PL::F_STAGES, stage_buf, lane, wave);
     {
         const float4 *g4 = (const float4 *)(a.packed + PL::PK_RES);
@@ -115,9 +115,10 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
     float sigma_raw = 0.f;
 
     // ---------------------------------------------------------------- trunk (layers 0..7) + feature layer (8)
+    __syncthreads();                         // resident block visible
+    stream_begin(ws);
 #pragma unroll 1
     for (int layer = 0; layer < 9; ++layer) {
-        if (layer == 0) __syncthreads();
         const float *bias = rf + (layer < 8 ? PL::N_BIAS + layer * W : PL::N_BFEAT) + 4 * q;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
         const float *st = ws.wait();
         gemm_stage_bf<8, PL::KSV, NS>(st, lane, vb, bin, PL::KSV * jj, ws);
     }
+    stream_end(ws);
 
 #pragma unroll 1
     for (int dsel = 0; dsel <= a.src.V; ++dsel) {

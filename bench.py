@@ -240,6 +240,8 @@ def main():
             others[prec] = {'rays_per_sec': round(args.rays / dt, 1), 'ms_per_step': round(dt * 1e3, 3)}
         model.configs['model']['hip_precision'] = args.precision
         result['other_precisions'] = others
+        if 'fp32' in others:      # the exact-fp32 MFMA path (BASELINE configs[1] says fp32), next to the headline arithmetic
+            result['value_fp32_mfma'] = others['fp32']['rays_per_sec']
 
     if world == 1 and not args.no_render:
         # full-frame eval render, camera -> uint8 image on the GPU (756 x 1008 rays, no secondary views):

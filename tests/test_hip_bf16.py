@@ -212,3 +212,28 @@ def test_full_size_step_properties(dev, prec):
             halves.append(m1(hb, retraw=True, sec_views_vis=True))
     for k in whole:
         assert torch.equal(whole[k], torch.cat([halves[0][k], halves[1][k]], 0)), f'{prec}: ray independence {k}'
+
+
+def test_fp16x3_range(dev):
+    """fp16 fragments have 5 exponent bits.  Inside the range (activations < 65504: here a 6x over-scaled network whose
+    raw sigma reaches ~7e3) fp16x3 agrees with the exact fp32 path to fp32 rounding; beyond it (10x: activations ~1e5)
+    the outputs are NaN -- a loud failure, never finite garbage."""
+    ops = tp.hip_ops()
+    rs = np.random.default_rng(0)
+    P = 2048
+    pts = tp.cu(rs.uniform(-1, 1, size=(P, 3)).astype(np.float32), dev)
+    vd = torch.nn.functional.normalize(tp.cu(rs.standard_normal((P, 3)).astype(np.float32), dev), dim=-1)
+
+    def run(scale, prec):
+        params = vo.init_params(3, levels=('coarse',), scale=scale)
+        pr = ops.PRECISIONS[prec]
+        pk = ops.pack_weights([tp.cu(params[f'coarse_model.{n}'], dev) for n in ops.PARAM_ORDER], precision=pr)
+        return ops.mlp_forward(pk, pts, vd, precision=pr)
+
+    ref, o = run(6.0, 'fp32'), run(6.0, 'fp16x3')
+    assert float(ref['sigma'].max()) > 1e3
+    assert float((o['sigma'] - ref['sigma']).abs().max() / ref['sigma'].abs().max()) < 1e-5
+    assert float((o['rgb'] - ref['rgb']).abs().max()) < 1e-4
+    big = run(10.0, 'fp16x3')
+    assert torch.isfinite(run(10.0, 'fp32')['sigma']).all()
+    assert not torch.isfinite(big['sigma']).all() and not torch.isfinite(big['rgb']).all()

@@ -98,17 +98,20 @@ __host__ __device__ inline size_t packed_narrow_floats(int precision) {
 
 // "fp16x3" (VIPNERF_PREC_FP16X3): the narrow kernels with fp16 fragments, x = x0 + x1 with 11-bit parts, three cross
 // terms a0b0 + a0b1 + a1b0 on v_mfma_f32_16x16x32_f16: per-product error <= ~3 * 2^-22 (the dropped a1b1 and the two
-// residuals), i.e. close to fp32, at the MFMA count and weight-stream size of bf16x3.  fp16 has 5 exponent bits, so
-// operands are moved into its comfortable range by exact powers of two: weights are packed as 2^8 w (|w| ~ 0.06 ->
-// ~16: the low part 2^-11 * 16 is a normal fp16 number, and 2^8 |w| < 65504 up to |w| = 255), the B operands
-// (activations, encodings) are split as 2^4 x (|x| < 4094), accumulators start at 2^12 bias and the epilogue takes
-// 2^-12 off again -- all exact in fp32.  What falls below fp16's normal range is at most 2^-14-ish of an operand whose
-// partner is O(10): an absolute error far below the 2^-22 of the large terms, whether or not the MFMA flushes it.
+// residuals), i.e. close to fp32, at the MFMA count and weight-stream size of bf16x3.  fp16 has 5 exponent bits:
+//   * weights are packed as 2^8 w (exact): |w| ~ 0.06 -> ~16, so the low part 2^-11 * 16 is a normal fp16 number;
+//     2^8 |w| < 65504 up to |w| = 255.  Accumulators start at 2^8 bias and the epilogue takes 2^-8 off again.
+//   * the B operands (activations, encodings) are split as they are: |x| < 65504, all of fp16's range.  (A scale of
+//     2^4 was measured: no accuracy difference on the goldens -- the MFMA does not flush fp16 subnormals, and what sits
+//     below the normal range is <= 2^-14 of an operand whose partner is O(10) -- but it cost a factor 16 of range.)
+//   * beyond that range the conversion gives inf, inf - inf in the low part gives NaN, and the F16 kernels' ReLU
+//     passes NaN on (x < 0 ? 0 : x instead of max), so the outputs and the loss are NaN: out-of-range inputs fail
+//     loudly instead of being squashed to finite garbage (tools/range_diag.py).
 #if defined(VN_F16_WS)
 constexpr float F16_WSCALE = VN_F16_WS, F16_XSCALE = VN_F16_XS;    // diagnostic build
 #else
 constexpr float F16_WSCALE = 256.f;           // weights
-constexpr float F16_XSCALE = 16.f;            // B operands of the forward pass
+constexpr float F16_XSCALE = 1.f;             // B operands of the forward pass
 #endif
 constexpr float F16_ACC_SCALE = F16_WSCALE * F16_XSCALE;
 constexpr float F16_ACC_UNSCALE = 1.f / F16_ACC_SCALE;
@@ -157,6 +160,10 @@ __device__ __forceinline__ void stream_begin(...) {}
 __device__ __forceinline__ void stream_end(...) {}
 template <int CH> __device__ __forceinline__ void stream_begin(WStreamSkew<CH> &w) { w.begin(); }
 template <int CH> __device__ __forceinline__ void stream_end(WStreamSkew<CH> &w) { w.end(); }
+
+// max(x, lo); the NaN-propagating form for the fp16 kernels (v_max_f32 returns the non-NaN operand)
+template <bool NAN_THROUGH>
+__device__ __forceinline__ float relu_lo(float x, float lo) { return NAN_THROUGH ? (x < lo ? lo : x) : fmaxf(x, lo); }
 
 // C/D tile T of a narrow fragment <-> row-major [P][ld]: lane (j, q) owns features 16T + 4q .. +3
 __device__ __forceinline__ void store_tile16(float *base, int64_t p, int ld, int q, int T, const floatx4 &v, bool valid) {

@@ -152,8 +152,8 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const float4 w4 = *(const float4 *)(rf + PL::N_WSIG + 16 * t + 4 * q);
-                sg[0] = fmaf(w4.x, fmaxf(acc[t][0] * AU, 0.f), sg[0]); sg[1] = fmaf(w4.y, fmaxf(acc[t][1] * AU, 0.f), sg[1]);
-                sg[2] = fmaf(w4.z, fmaxf(acc[t][2] * AU, 0.f), sg[2]); sg[3] = fmaf(w4.w, fmaxf(acc[t][3] * AU, 0.f), sg[3]);
+                sg[0] = fmaf(w4.x, relu_lo<F16>(acc[t][0] * AU, 0.f), sg[0]); sg[1] = fmaf(w4.y, relu_lo<F16>(acc[t][1] * AU, 0.f), sg[1]);
+                sg[2] = fmaf(w4.z, relu_lo<F16>(acc[t][2] * AU, 0.f), sg[2]); sg[3] = fmaf(w4.w, relu_lo<F16>(acc[t][3] * AU, 0.f), sg[3]);
             }
             float s = (sg[0] + sg[1]) + (sg[2] + sg[3]);
             s += __shfl_xor(s, 16, 64);
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             for (int u = 0; u < 2; ++u) {
                 const int t = 2 * s + u;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) x[u][r] = fmaxf(x[u][r] * AU, lo);
+                for (int r = 0; r < 4; ++r) x[u][r] = relu_lo<F16>(x[u][r] * AU, lo);
                 if (SAVE) {
                     store_tile16(dst, p, W, q, t, x[u], valid);
                     unsigned m = 0;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
         float nz = 0.f;
         if (a.ns.noise) nz = a.ns.noise[p];
         else if (a.ns.device_rng) nz = rng_normal(a.ns.seed, a.ns.offset, a.ns.stream, (uint64_t)p);
-        const float sgm = fmaxf(__fadd_rn(sigma_raw, __fmul_rn(nz, a.ns.std)), 0.f);
+        const float sgm = relu_lo<F16>(__fadd_rn(sigma_raw, __fmul_rn(nz, a.ns.std)), 0.f);
         if (valid && q == 0) a.sigma[p] = sgm;
     }
 
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) g[t][r] = fmaxf(g[t][r] * AU, 0.f);
+            for (int r = 0; r < 4; ++r) g[t][r] = relu_lo<F16>(g[t][r] * AU, 0.f);
         if (SAVE) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) store_tile16(a.acts + a.al.g[dsel], p, WV, q, t, g[t], valid);

@@ -30,7 +30,13 @@ __global__ void k_seed_absmax(MlpBwdArgs a, unsigned *slot) {
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slot, __float_as_uint(m));
+    __shared__ float wm[4];                                // one atomic per workgroup: thousands on one address serialise
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        if (m > 0.f) atomicMax(slot, __float_as_uint(m));
+    }
 }
 
 // F16: fp16 fragments (VIPNERF_PREC_FP16X3): W^T is packed as 2^8 W^T, every gradient in the workspace is 2^S times its
@@ -189,7 +195,7 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
         // the level's largest seed first (one pass over 5+V floats per point)
         unsigned *slot = (unsigned *)(a.bwd + a.bl.gmax);
         VN_HIP(hipMemsetAsync(slot, 0, sizeof(unsigned), st));
-        hipLaunchKernelGGL(k_seed_absmax, dim3(1024), dim3(256), 0, st, a, slot);
+        hipLaunchKernelGGL(k_seed_absmax, dim3((unsigned)((a.src.P + 255) / 256)), dim3(256), 0, st, a, slot);   // one point per thread
         VN_HIP(hipGetLastError());
         MlpBwdArgs b = a;
         b.gmax = slot;

@@ -510,7 +510,17 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgReduceArgs a) {
             }
             for (int dd = 0; dd < g.n_desc; ++dd) {
                 const float *pp = a.partial + g.part_off + (size_t)dd * g.desc_stride + off;
-                for (int c = q; c < g.n_chunks; c += 4) s += pp[(size_t)c * g.part_stride];
+                // four loads in flight per thread (the sum is latency-bound otherwise); fixed order -> deterministic
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                int c = q;
+                for (; c + 12 < g.n_chunks; c += 16) {
+                    s0 += pp[(size_t)c * g.part_stride];
+                    s1 += pp[(size_t)(c + 4) * g.part_stride];
+                    s2 += pp[(size_t)(c + 8) * g.part_stride];
+                    s3 += pp[(size_t)(c + 12) * g.part_stride];
+                }
+                for (; c < g.n_chunks; c += 4) s0 += pp[(size_t)c * g.part_stride];
+                s += (s0 + s1) + (s2 + s3);
             }
         }
         sh[q][el] = s;

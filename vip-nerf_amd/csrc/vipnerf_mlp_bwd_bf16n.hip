@@ -10,8 +10,11 @@
 
 namespace vn {
 
-__device__ __forceinline__ bool mask_bit16(unsigned m0, unsigned m1, int t, int r) {
-    return ((t < 8 ? m0 >> (4 * t) : m1 >> (4 * (t - 8))) >> r) & 1u;
+// x where bit (4t + r) of the lane's 64-bit ReLU mask is set, +0 elsewhere: a signed 1-bit field extract gives 0 / -1,
+// which ANDs the value (2 VALU; compare + select would be 3)
+__device__ __forceinline__ float mask_apply16(float x, unsigned m0, unsigned m1, int t, int r) {
+    const int sel = __builtin_amdgcn_sbfe((int)(t < 8 ? m0 : m1), (unsigned)(4 * (t & 7) + r), 1u);
+    return __uint_as_float(__float_as_uint(x) & (unsigned)sel);
 }
 
 // max over the level of the seeds the data-gradient pass actually starts from -- d(pre-sigmoid rgb, vis, vis2) and
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
                     x[u][2] = fmaf(w4.z, dsig_raw, x[u][2]); x[u][3] = fmaf(w4.w, dsig_raw, x[u][3]);
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) x[u][r] = mask_bit16(mk.x, mk.y, t, r) ? x[u][r] : 0.f;
+                for (int r = 0; r < 4; ++r) x[u][r] = mask_apply16(x[u][r], mk.x, mk.y, t, r);
                 store_tile16(dst, p, W, q, t, x[u], valid);
             }
             if (it < 7) split_pair<NS>(x[0], x[1], bin[s]);

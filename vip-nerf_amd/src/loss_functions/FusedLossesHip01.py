@@ -20,8 +20,10 @@ from vipnerf_hip.autograd import FusedLossFunction
 CACHE_KEY = '_vipnerf_hip_fused_losses'
 
 
-def fused_loss_values(configs: dict, input_dict: dict, output_dict: dict) -> torch.Tensor:
-    """-> tensor (8,): [mse_c, mse_f, vis_c, vis_f, prior_c, prior_f, sparse_depth, 0] (unweighted)."""
+def fused_loss_values(configs: dict, input_dict: dict, output_dict: dict):
+    """-> 8 scalar tensors: [mse_c, mse_f, vis_c, vis_f, prior_c, prior_f, sparse_depth, 0] (unweighted).  They are
+    the unbind() of the kernel's result vector, so that autograd sees one Unbind node instead of one Select node (a
+    zeros + a copy kernel) per value a loss class picks."""
     if CACHE_KEY in output_dict:
         return output_dict[CACHE_KEY]
     m = configs['model']
@@ -46,5 +48,6 @@ def fused_loss_values(configs: dict, input_dict: dict, output_dict: dict) -> tor
                 output_dict.get(f'visibility2_{lv}'), output_dict[f'depth_{lv}'])
     vals = FusedLossFunction.apply(cfg, n, input_dict['target_rgb'], input_dict['indices_mask_nerf'], prior, mask_sd, sd,
                                    *level('coarse'), *(level('fine') if fine else (None,) * 5))
+    vals = vals.unbind(0)
     output_dict[CACHE_KEY] = vals
     return vals

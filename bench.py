@@ -38,11 +38,14 @@ WGRAD_BYTES_PER_POINT = 4 * (8 * 512 + 2 * 320 + 384 + 1 + 2 * 160 + 2 * 136)
 PEAK = {'fp32': (FP32_MFMA_PEAK_TFLOPS, 'fp32 MFMA peak (v_mfma_f32_32x32x2_f32)'),
         'bf16x6': (BF16_MFMA_PEAK_TFLOPS / 6, 'dense bf16 MFMA peak 2500 TFLOP/s / 6 cross terms per fp32-grade product'),
         'bf16x3': (BF16_MFMA_PEAK_TFLOPS / 3, 'dense bf16 MFMA peak 2500 TFLOP/s / 3 cross terms per product'),
-        'fp16x3': (BF16_MFMA_PEAK_TFLOPS / 3, 'dense fp16 MFMA peak 2500 TFLOP/s / 3 cross terms per fp32-grade product')}
+        'fp16x3': (BF16_MFMA_PEAK_TFLOPS / 3, 'dense fp16 MFMA peak 2500 TFLOP/s / 3 cross terms per fp32-grade product'),
+        'fp16x3h': (BF16_MFMA_PEAK_TFLOPS / 3, 'dense fp16 MFMA peak 2500 TFLOP/s / 3 cross terms per product (forward / data gradients)')}
 DTYPE = {'fp32': 'f32', 'bf16x6': 'f32 via 3-way bf16 split (6 bf16 MFMAs per product, fp32 accumulate; fp32-grade error)',
          'bf16x3': 'f32 via 2-way bf16 split (3 bf16 MFMAs per product, fp32 accumulate; ~5e-6 relative error)',
          'fp16x3': 'f32 via 2-way fp16 split (3 fp16 MFMAs per product, fp32 accumulate, power-of-two operand scaling; '
-                   'fp32-grade error)'}
+                   'fp32-grade error)',
+         'fp16x3h': 'mixed: fp16x3 forward / data gradients, trunk activations and gradients stored as fp16 for the weight '
+                    'gradients (single fp16 MFMA, ~2e-4 relative gradient error)'}
 
 
 def model_configs(n_views=2):
@@ -98,7 +101,7 @@ def main():
     ap.add_argument('--cpu-rays', type=int, default=1024)
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--no-render', action='store_true')
-    ap.add_argument('--precision', default='fp16x3', choices=['fp32', 'bf16x6', 'bf16x3', 'fp16x3'],
+    ap.add_argument('--precision', default='fp16x3', choices=['fp32', 'bf16x6', 'bf16x3', 'fp16x3', 'fp16x3h'],
                     help='MLP GEMM arithmetic of the headline number (all three are parity-tested; see DESIGN.md)')
     ap.add_argument('--no-other-precisions', action='store_true')
     args = ap.parse_args()
@@ -227,7 +230,7 @@ def main():
     if world == 1 and not args.no_other_precisions:
         # the same step in the other two arithmetics (10 steps each, same process, same batches)
         others = {}
-        for prec in ('fp32', 'bf16x6', 'bf16x3', 'fp16x3'):
+        for prec in ('fp32', 'bf16x6', 'bf16x3', 'fp16x3', 'fp16x3h'):
             if prec == args.precision:
                 continue
             model.configs['model']['hip_precision'] = prec

@@ -48,6 +48,11 @@ extern "C" {
  * accumulation, power-of-two operand scaling (vip-nerf_amd/csrc/vipnerf_bf16n.h): ~2^-21 relative error per product
  * at the cost of BF16X3.  Narrow lane layout only. */
 #define VIPNERF_PREC_FP16X3 3
+/* FP16X3H ("mixed"): FP16X3 in the forward and data-gradient GEMMs (so outputs and losses are the FP16X3 ones), but the
+ * 256-wide activations and gradients that only the weight-gradient GEMMs read back are stored as fp16 (2 bytes instead
+ * of 4) and those GEMMs run single fp16 MFMAs: 8 GB less HBM traffic per 4096-ray step, parameter gradients at ~2e-4
+ * relative error instead of fp32 grade.  A separate accuracy class (BASELINE configs[4] style mixed precision). */
+#define VIPNERF_PREC_FP16X3H 4
 
 /* Lane layout of the BF16X3 / BF16X6 kernels (same arithmetic, same stored activations):
  * WIDE: 32-point waves on 32x32x16 MFMA, one wave per SIMD; NARROW: 16-point waves on 16x16x32, two waves per SIMD. */

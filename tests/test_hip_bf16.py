@@ -19,11 +19,11 @@ import test_hip_parity as tp  # noqa: E402
 PRECS = ['bf16x3', 'bf16x6', 'fp16x3']
 # the render-level tests run both lane layouts of the split-bf16 kernels (configs['model']['hip_bf16_layout']):
 # 'narrow' (16-point waves, the default) and 'wide' (32-point waves)
-MODES = ['bf16x3', 'bf16x6', 'fp16x3', 'bf16x3-wide', 'bf16x6-wide']
+MODES = ['bf16x3', 'bf16x6', 'fp16x3', 'fp16x3h', 'bf16x3-wide', 'bf16x6-wide']
 # relative-L2 tolerance on parameter gradients.  bf16x6 is fp32 grade (same bar as the fp32 path).  bf16x3 perturbs
 # activations by ~5e-6 relative, i.e. ~20x more ReLU pre-activations land on the other side of 0 than in fp32, and
 # the error is carried through 8 chained dgrad layers: measured 2-3e-3 on the deepest layer's weights.
-GRAD_TOL = {'bf16x3': 6e-3, 'bf16x6': 2e-3, 'fp16x3': 2e-3}
+GRAD_TOL = {'bf16x3': 6e-3, 'bf16x6': 2e-3, 'fp16x3': 2e-3, 'fp16x3h': 2e-3}
 
 
 @pytest.fixture(scope='module')
@@ -168,7 +168,7 @@ def test_mlp_forward_ragged_and_empty(dev, prec):
     assert o['rgb'].shape == (0, 3)
 
 
-@pytest.mark.parametrize('prec', ['fp16x3', 'bf16x6'])
+@pytest.mark.parametrize('prec', ['fp16x3', 'fp16x3h', 'bf16x6'])
 def test_full_size_step_properties(dev, prec):
     """BASELINE config 2 sizes (4096 rays x 64+128) in the bench arithmetics: determinism of a whole training step
     (outputs and all 48 gradients bit-identical run to run), ray independence of the eval render, finite values, and

@@ -70,7 +70,7 @@ static int check_cfg(const vipnerf_config *cfg) {
         set_error("n_fine=%d unsupported (n_coarse+n_fine multiple of 32, <= 256)", cfg->n_fine); return VIPNERF_E_UNSUPPORTED; }
     if (cfg->n_sec < 0 || cfg->n_sec > VIPNERF_MAX_SEC) {
         set_error("n_sec=%d unsupported (0..%d)", cfg->n_sec, VIPNERF_MAX_SEC); return VIPNERF_E_UNSUPPORTED; }
-    if (cfg->precision < 0 || cfg->precision > VIPNERF_PREC_FP16X3) {
+    if (cfg->precision < 0 || cfg->precision > VIPNERF_PREC_FP16X3H) {
         set_error("precision=%d unsupported", cfg->precision); return VIPNERF_E_UNSUPPORTED; }
     if (cfg->bf16_layout < VIPNERF_LAYOUT_DEFAULT || cfg->bf16_layout > VIPNERF_LAYOUT_NARROW) {
         set_error("bf16_layout=%d unsupported", cfg->bf16_layout); return VIPNERF_E_UNSUPPORTED; }
@@ -90,7 +90,7 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st);
 #define VN_BF16_NARROW_DEFAULT 1
 #endif
 static bool bf16_narrow(int layout = VIPNERF_LAYOUT_DEFAULT, int precision = 0) {
-    if (precision == VIPNERF_PREC_FP16X3) return true;      // fp16 fragments exist in the narrow layout only
+    if (precision >= VIPNERF_PREC_FP16X3) return true;      // fp16 fragments exist in the narrow layout only
     if (layout == VIPNERF_LAYOUT_WIDE) return false;
     if (layout == VIPNERF_LAYOUT_NARROW) return true;
     static const int v = [] {
@@ -141,7 +141,7 @@ static PointSrc ray_points(const vipnerf_config *cfg, const vipnerf_rays *r, int
 
 struct LevelWs { size_t acts_off, bwd_off; };   // float offsets of the fine level inside the workspaces
 
-static size_t bwd_total(size_t P, int V) { return bwd_layout(P, V).total; }
+static size_t bwd_total(size_t P, int V, bool h16) { return bwd_layout(P, V, h16).total; }
 
 }  // namespace vn
 
@@ -171,10 +171,10 @@ int32_t vipnerf_pack_weights(const vipnerf_mlp_params *params, void *packed, vip
 size_t vipnerf_packed_weights_bytes_p(int32_t precision) { return packed_floats_all(precision) * sizeof(float); }
 
 int32_t vipnerf_pack_weights_p(const vipnerf_mlp_params *params, int32_t precision, void *packed, vipnerf_stream_t stream) {
-    if (precision < 0 || precision > VIPNERF_PREC_FP16X3) { set_error("pack_weights: precision=%d unsupported", precision); return VIPNERF_E_UNSUPPORTED; }
+    if (precision < 0 || precision > VIPNERF_PREC_FP16X3H) { set_error("pack_weights: precision=%d unsupported", precision); return VIPNERF_E_UNSUPPORTED; }
     int rc = vipnerf_pack_weights(params, packed, stream);
     if (rc || precision == VIPNERF_PREC_FP32) return rc;
-    if (precision != VIPNERF_PREC_FP16X3 &&
+    if (precision < VIPNERF_PREC_FP16X3 &&
         (rc = launch_pack_bf16(params, precision, (float *)packed + PK_TOTAL_F, (hipStream_t)stream))) return rc;
     return launch_pack_bf16n(params, precision, (float *)packed + packed_total_floats(precision), (hipStream_t)stream);
 }
@@ -188,7 +188,8 @@ int32_t vipnerf_query_workspace(const vipnerf_config *cfg, int64_t n_rays, size_
     if (acts_bytes)
         *acts_bytes = cfg->save_acts ? (act_layout(Pc, cfg->n_sec).total + (Pf ? act_layout(Pf, cfg->n_sec).total : 0)) * sizeof(float) : 0;
     if (bwd_bytes) {
-        const size_t a = bwd_total(Pc, cfg->n_sec), b = Pf ? bwd_total(Pf, cfg->n_sec) : 0;
+        const bool h16 = cfg->precision == VIPNERF_PREC_FP16X3H;
+        const size_t a = bwd_total(Pc, cfg->n_sec, h16), b = Pf ? bwd_total(Pf, cfg->n_sec, h16) : 0;
         *bwd_bytes = (a > b ? a : b) * sizeof(float);       // levels run one after the other
     }
     return VIPNERF_OK;
@@ -227,7 +228,7 @@ int32_t vipnerf_mlp_forward_p(int64_t n_points, int32_t n_sec, const float *pts,
                               const void *packed, float *sigma, float *rgb, float *vis, float *vis2,
                               vipnerf_stream_t stream) {
     clear_stale_hip_error();
-    if (precision < 0 || precision > VIPNERF_PREC_FP16X3) { set_error("mlp_forward: precision=%d unsupported", precision); return VIPNERF_E_UNSUPPORTED; }
+    if (precision < 0 || precision > VIPNERF_PREC_FP16X3H) { set_error("mlp_forward: precision=%d unsupported", precision); return VIPNERF_E_UNSUPPORTED; }
     if (n_points == 0) return VIPNERF_OK;
     if (!pts || !view_dirs || !packed || !sigma || !rgb || !vis || (n_sec > 0 && (!view_dirs2 || !vis2))) {
         set_error("mlp_forward: NULL argument"); return VIPNERF_E_ARG; }
@@ -352,7 +353,7 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
         }
         const int S = lv ? Sc + Sf : Sc;
         const size_t P = (size_t)N * S;
-        const BwdLayout bl = bwd_layout(P, V);
+        const BwdLayout bl = bwd_layout(P, V, cfg->precision == VIPNERF_PREC_FP16X3H);
         float *bw = (float *)bwd_ws;
         // 1. compositing backward -> dLoss/d(raw network outputs)
         CompositeBwdArgs cb;
@@ -383,7 +384,7 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
         }
         // 3. weight gradients: dW = dY^T H as MFMA GEMMs over the point axis
         if ((rc = launch_wgrad(P, V, mb.acts, mb.al, bw, bl, G, cfg->precision, st,
-                               cfg->precision == VIPNERF_PREC_FP16X3 ? (const unsigned *)(bw + bl.gmax) : nullptr))) return rc;
+                               cfg->precision >= VIPNERF_PREC_FP16X3 ? (const unsigned *)(bw + bl.gmax) : nullptr))) return rc;
     }
     return VIPNERF_OK;
 }

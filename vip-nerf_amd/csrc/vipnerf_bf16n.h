@@ -93,7 +93,7 @@ struct BnPlan {
 };
 
 __host__ __device__ inline size_t packed_narrow_floats(int precision) {
-    return (precision == 1 || precision == 3) ? BnPlan<2>::PK_TOTAL_F : (precision == 2 ? BnPlan<3>::PK_TOTAL_F : 0);
+    return (precision == 1 || precision >= 3) ? BnPlan<2>::PK_TOTAL_F : (precision == 2 ? BnPlan<3>::PK_TOTAL_F : 0);
 }
 
 // "fp16x3" (VIPNERF_PREC_FP16X3): the narrow kernels with fp16 fragments, x = x0 + x1 with 11-bit parts, three cross
@@ -177,6 +177,18 @@ __device__ __forceinline__ floatx4 load_tile16(const float *base, int64_t p, int
     floatx4 v = {f.x, f.y, f.z, f.w};
     return v;
 }
+// FP16X3H: the fp16 high parts of a B fragment (k-step s <- tiles 2s, 2s+1) ARE the fp16 image of those two tiles:
+// elements 4u .. 4u+3 of part 0 are features 16 (2s+u) + 4q .. +3.  Stored as [P][ld] halves (8 bytes per lane, tile).
+__device__ __forceinline__ void store_pair16h(float *base, int64_t p, int ld, int q, int s, const half8 &hi, bool valid) {
+    if (!valid) return;
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    _Float16 *row = (_Float16 *)base + (size_t)p * ld + 4 * q;
+    const half4 a = {hi[0], hi[1], hi[2], hi[3]}, b = {hi[4], hi[5], hi[6], hi[7]};
+    __builtin_nontemporal_store(a, (half4 *)(row + 16 * (2 * s)));
+    __builtin_nontemporal_store(b, (half4 *)(row + 16 * (2 * s + 1)));
+}
+__device__ __forceinline__ void store_pair16h(float *, int64_t, int, int, int, const bf16x8 &, bool) {}   // never used
+
 // two C/D tiles (2s, 2s+1) -> the NS-part B fragment of k-step s
 template <int NS, typename FR>
 __device__ __forceinline__ void split_pair(const floatx4 &lo, const floatx4 &hi, FR (&out)[NS]) {

@@ -128,6 +128,7 @@ struct BwdLayout {
     size_t dq[1 + VIPNERF_MAX_SEC];   // [P][8]: a=0: d(pre-sigmoid rgb,vis), d(sigma_raw); a>=1: (0,0,0,d pre-sigmoid vis2_a)
     size_t dsig, drgb, dvis, dvis2;   // [P], [P][3], [P], [P][V]: dLoss/d(raw network outputs)
     size_t gmax;      // [64] slot; word 0 = bit pattern of max |d raw output| of the level (FP16X3 gradient scaling)
+    size_t dy5f;      // FP16X3H only: fp32 copy of dy[5] for the gamma(x) weight-gradient GEMM of layer 5 ([P][256])
     size_t partial;   // wgrad partial sums
     size_t total;
 };
@@ -170,7 +171,7 @@ __host__ __device__ inline size_t wgrad_partial_total(size_t P, int V) {
     sm += (size_t)(1 + V) * (32 * 128 + 32);        // output head (per direction)
     return (size_t)wgrad_chunks(P) * big + (size_t)wgrad_chunks_small(P) * sm + (size_t)wgrad_chunks_single(P) * single;
 }
-__host__ __device__ inline BwdLayout bwd_layout(size_t P, int V) {
+__host__ __device__ inline BwdLayout bwd_layout(size_t P, int V, bool h16 = false) {
     BwdLayout b; size_t o = 0;
     for (int i = 0; i < D; ++i) { b.dy[i] = o; o += P * W; }
     b.dyf = o; o += P * W;
@@ -183,6 +184,7 @@ __host__ __device__ inline BwdLayout bwd_layout(size_t P, int V) {
     b.dvis2 = o; o += P * (V > 0 ? V : 1);
     o = (o + 63) & ~(size_t)63;
     b.gmax = o; o += 64;
+    b.dy5f = o; if (h16) o += P * W;
     b.partial = o; o += wgrad_partial_total(P, V);
     b.total = o;
     return b;

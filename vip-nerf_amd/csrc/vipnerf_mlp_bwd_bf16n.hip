@@ -44,7 +44,10 @@ __global__ void k_seed_absmax(MlpBwdArgs a, unsigned *slot) {
 
 // F16: fp16 fragments (VIPNERF_PREC_FP16X3): W^T is packed as 2^8 W^T, every gradient in the workspace is 2^S times its
 // true value (grad_scale_from_max), accumulators are taken back by 2^-8
-template <int NS, bool F16>
+// H16 (with F16, FP16X3H): dY of the feature layer and of layers 1..7 -- read back only by the 256x256 weight-gradient
+// GEMMs -- are stored as fp16 (the high parts of the split that is made for the next GEMM anyway); dY_5 additionally
+// in fp32 for layer 5's gamma(x) GEMM; dY_0 stays fp32.
+template <int NS, bool F16, bool H16 = false>
 __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) {
     typedef BnPlan<NS> PL;
     typedef typename FragOf<F16>::type FR;
@@ -141,9 +144,12 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const floatx4 x0 = acc[2 * s] * AU, x1 = acc[2 * s + 1] * AU;
-        store_tile16(a.bwd + a.bl.dyf, p, W, q, 2 * s, x0, valid);
-        store_tile16(a.bwd + a.bl.dyf, p, W, q, 2 * s + 1, x1, valid);
+        if (!H16) {
+            store_tile16(a.bwd + a.bl.dyf, p, W, q, 2 * s, x0, valid);
+            store_tile16(a.bwd + a.bl.dyf, p, W, q, 2 * s + 1, x1, valid);
+        }
         split_pair<NS>(x0, x1, bin[s]);
+        if (H16) store_pair16h(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0], valid);
     }
 
     // ---------------------------------------------------------------- feature layer, then layers 7..1
@@ -172,19 +178,23 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[u][r] = mask_apply16(x[u][r], mk.x, mk.y, t, r);
-                store_tile16(dst, p, W, q, t, x[u], valid);
+                if (!H16 || it == 7) store_tile16(dst, p, W, q, t, x[u], valid);
+                if (H16 && layer == SKIP_LAYER) store_tile16(a.bwd + a.bl.dy5f, p, W, q, t, x[u], valid);
             }
-            if (it < 7) split_pair<NS>(x[0], x[1], bin[s]);
+            if (it < 7) {
+                split_pair<NS>(x[0], x[1], bin[s]);
+                if (H16) store_pair16h(dst, p, W, q, s, bin[s][0], valid);
+            }
         }
     }
     stream_end(ws);
 }
 
-template <int NS, bool F16 = false>
+template <int NS, bool F16 = false, bool H16 = false>
 static int launch_one_bwd_n(const MlpBwdArgs &a, unsigned grid, hipStream_t st) {
     const size_t lds = (size_t)BnPlan<NS>::LDS_F * sizeof(float);
-    VN_HIP(hipFuncSetAttribute((const void *)k_mlp_bwd_bf16n<NS, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_mlp_bwd_bf16n<NS, F16>), dim3(grid), dim3(BnPlan<NS>::WG), lds, st, a);
+    VN_HIP(hipFuncSetAttribute((const void *)k_mlp_bwd_bf16n<NS, F16, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_mlp_bwd_bf16n<NS, F16, H16>), dim3(grid), dim3(BnPlan<NS>::WG), lds, st, a);
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;
 }
@@ -194,7 +204,7 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
     const unsigned grid = (unsigned)((a.src.P + MLP_PTS_PER_WG - 1) / MLP_PTS_PER_WG);
     if (precision == 1) return launch_one_bwd_n<2>(a, grid, st);
     if (precision == 2) return launch_one_bwd_n<3>(a, grid, st);
-    if (precision == 3) {
+    if (precision == 3 || precision == 4) {
         // the level's largest seed first (one pass over 5+V floats per point)
         unsigned *slot = (unsigned *)(a.bwd + a.bl.gmax);
         VN_HIP(hipMemsetAsync(slot, 0, sizeof(unsigned), st));
@@ -202,7 +212,7 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
         VN_HIP(hipGetLastError());
         MlpBwdArgs b = a;
         b.gmax = slot;
-        return launch_one_bwd_n<2, true>(b, grid, st);
+        return precision == 4 ? launch_one_bwd_n<2, true, true>(b, grid, st) : launch_one_bwd_n<2, true>(b, grid, st);
     }
     set_error("mlp_bwd_bf16n: precision %d", precision);
     return VIPNERF_E_ARG;

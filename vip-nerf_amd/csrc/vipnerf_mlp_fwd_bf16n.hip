@@ -69,8 +69,9 @@ __device__ __forceinline__ void store_d16(float *row, int q, const float (&pd)[1
     else { row[DVE + 2] = 0.f; row[DVE + 3] = 0.f; row[DVE + 4] = 0.f; }
 }
 
-// F16: fp16 fragments with power-of-two operand scaling (vipnerf_bf16n.h); otherwise bf16 fragments
-template <bool SAVE, int NS, bool F16>
+// F16: fp16 fragments with power-of-two operand scaling (vipnerf_bf16n.h); otherwise bf16 fragments.
+// H16 (with F16 and SAVE): the trunk activations h_1..h_8 are stored as fp16 (FP16X3H); everything else stays fp32.
+template <bool SAVE, int NS, bool F16, bool H16 = false>
 __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) {
     typedef BnPlan<NS> PL;
     typedef typename FragOf<F16>::type FR;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[u][r] = relu_lo<F16>(x[u][r] * AU, lo);
                 if (SAVE) {
-                    store_tile16(dst, p, W, q, t, x[u], valid);
+                    if (!(H16 && layer < 8)) store_tile16(dst, p, W, q, t, x[u], valid);
                     unsigned m = 0;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) m |= (x[u][r] > 0.f ? 1u : 0u) << r;
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             }
             if (F16) { x[0] *= XS; x[1] *= XS; }
             split_pair<NS>(x[0], x[1], bin[s]);
+            if (SAVE && H16 && layer < 8) store_pair16h(dst, p, W, q, s, bin[s][0], valid);
         }
         if (SAVE && valid && layer < 8) *(uint2 *)(a.acts + a.al.hm[layer] + ((size_t)p * 4 + q) * 2) = make_uint2(mk0, mk1);
     }
@@ -264,11 +266,11 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
     }
 }
 
-template <bool SAVE, int NS, bool F16 = false>
+template <bool SAVE, int NS, bool F16 = false, bool H16 = false>
 static int launch_one_n(const MlpFwdArgs &a, unsigned grid, hipStream_t st) {
     const size_t lds = (size_t)BnPlan<NS>::LDS_F * sizeof(float);
-    VN_HIP(hipFuncSetAttribute((const void *)k_mlp_fwd_bf16n<SAVE, NS, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_mlp_fwd_bf16n<SAVE, NS, F16>), dim3(grid), dim3(BnPlan<NS>::WG), lds, st, a);
+    VN_HIP(hipFuncSetAttribute((const void *)k_mlp_fwd_bf16n<SAVE, NS, F16, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_mlp_fwd_bf16n<SAVE, NS, F16, H16>), dim3(grid), dim3(BnPlan<NS>::WG), lds, st, a);
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;
 }
@@ -280,6 +282,7 @@ int launch_mlp_fwd_bf16n(const MlpFwdArgs &a, int precision, hipStream_t st) {
     if (precision == 1) return a.acts ? launch_one_n<true, 2>(a, grid, st) : launch_one_n<false, 2>(a, grid, st);
     if (precision == 2) return a.acts ? launch_one_n<true, 3>(a, grid, st) : launch_one_n<false, 3>(a, grid, st);
     if (precision == 3) return a.acts ? launch_one_n<true, 2, true>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);
+    if (precision == 4) return a.acts ? launch_one_n<true, 2, true, true>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);
     set_error("mlp_fwd_bf16n: precision %d", precision);
     return VIPNERF_E_ARG;
 }

@@ -483,6 +483,151 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16x3_256(WgArgs a) {
     else wgrad_bf16x3_256_body<false>(a);
 }
 
+// FP16X3H: the 256x256 class when both operands were STORED as fp16 ([P][256] halves: the trunk activations h_1..h_8 and
+// the gradients dY_1..dY_7, dY_feature).  No split and no conversion while staging -- a thread gathers the 8 points of
+// a feature from its 8 row registers with v_perm and writes them as one 16-byte LDS store (same [feature][4 slots of 8
+// points] plane, same swizzle, one plane per operand) -- and ONE v_mfma_f32_32x32x16_f16 per product.  Half the bytes
+// and a third of the MFMAs of the hi/lo kernel; it is bound by the operand stream.
+template <bool HAS_W>
+__device__ __forceinline__ void wgrad_h16_256_body(const WgArgs &a) {
+    constexpr int MTW = 2, KTW = 8, Mp = 256, Kp = 256;
+    constexpr int PLANE = 256 * 64;                       // bytes: one operand, 256 features x 32 points x 2 B
+    constexpr int BUF = 2 * PLANE;                        // A, B
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char *lb = (char *)lds;
+    typedef _Float16 half8_ __attribute__((ext_vector_type(8)));
+
+    const WgDesc &d = a.d[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int64_t p0 = (int64_t)blockIdx.x * a.chunk_pts;
+    const int64_t p1 = p0 + a.chunk_pts < a.P ? p0 + a.chunk_pts : a.P;
+    const int nblk = (int)((p1 - p0 + 31) / 32);
+
+    floatx16 acc[MTW][KTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int j = 0; j < KTW; ++j) acc[i][j] = (floatx16)(0.f);
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    float ws[4] = {0.f, 0.f, 0.f, 0.f}, wsum = 0.f;
+    float wv[8];
+
+    uint2 ua[8], ub[8];                                   // rows wave + 4 i, features 4 lane .. + 3 (4 halves = 8 bytes)
+    const uint2 *A2 = (const uint2 *)d.A, *B2 = (const uint2 *)d.B;   // a row = 256 halves = 64 uint2
+    auto gload = [&](int blk) {
+        const int64_t pb = p0 + (int64_t)blk * 32;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t row = pb + wave + 4 * i;
+            const bool ok = row < p1;
+            ua[i] = ok ? A2[(size_t)row * 64 + lane] : make_uint2(0u, 0u);
+            ub[i] = ok ? B2[(size_t)row * 64 + lane] : make_uint2(0u, 0u);
+            if (HAS_W) wv[i] = ok ? d.wcol[(size_t)row * d.wcol_stride] : 0.f;
+        }
+    };
+    auto half_of = [](const uint2 &u, int c) -> float {   // feature c (0..3) of a row's 8 bytes
+        const unsigned w = c < 2 ? u.x : u.y;
+        const unsigned short bits = (unsigned short)((c & 1) ? (w >> 16) : (w & 0xffffu));
+        return (float)__builtin_bit_cast(_Float16, bits);
+    };
+    // the 8 points of feature c: dword k packs rows 2k (low half) and 2k + 1 (high half)
+    auto gather = [](const uint2 (&u)[8], int c, uint4 &o) {
+        const unsigned sel = (c & 1) ? 0x07060302u : 0x05040100u;
+        unsigned r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned lo = c < 2 ? u[2 * k].x : u[2 * k].y, hi = c < 2 ? u[2 * k + 1].x : u[2 * k + 1].y;
+            r[k] = __builtin_amdgcn_perm(hi, lo, sel);
+        }
+        o = make_uint4(r[0], r[1], r[2], r[3]);
+    };
+    auto lstore = [&](int buf) {
+        char *base = lb + buf * BUF;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int f = 4 * lane + c;
+            const int off = f * 64 + ((wave ^ ((f >> 2) & 3)) << 4);
+            uint4 pa, pb;
+            gather(ua, c, pa);
+            gather(ub, c, pb);
+            *(uint4 *)(base + off) = pa;
+            *(uint4 *)(base + PLANE + off) = pb;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                bs[c] += half_of(ua[i], c);
+                if (HAS_W) ws[c] = fmaf(wv[i], half_of(ub[i], c), ws[c]);
+            }
+        }
+        if (HAS_W) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wsum += wv[i];
+        }
+    };
+
+    if (nblk > 0) { gload(0); lstore(0); }
+    __syncthreads();
+    int cur = 0;
+    for (int blk = 0; blk < nblk; ++blk) {
+        if (blk + 1 < nblk) gload(blk + 1);
+        const char *base = lb + cur * BUF;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int slot = 2 * ks + h;
+            half8_ af[MTW], bf[KTW];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+                const int f = 32 * (wave * MTW + i) + l31;
+                af[i] = *(const half8_ *)(base + f * 64 + ((slot ^ ((f >> 2) & 3)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < KTW; ++j) {
+                const int f = 32 * j + l31;
+                bf[j] = *(const half8_ *)(base + PLANE + f * 64 + ((slot ^ ((f >> 2) & 3)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                for (int j = 0; j < KTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (blk + 1 < nblk) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    float *part = a.partial + d.part_off + (size_t)blockIdx.x * d.part_stride;
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int ot = wave * MTW + i;
+#pragma unroll
+        for (int j = 0; j < KTW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * h;
+                part[(size_t)o * Kp + 32 * j + l31] = acc[i][j][r];
+            }
+    }
+    float *red = (float *)lb;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[wave * 256 + 4 * lane + c] = bs[c];
+    __syncthreads();
+    part[(size_t)Mp * Kp + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+    if (HAS_W) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[wave * 256 + 4 * lane + c] = ws[c];
+        if (lane == 0) red[1024 + wave] = wsum;
+        __syncthreads();
+        part[(size_t)Mp * Kp + Mp + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+        if (tid == 0) part[(size_t)Mp * Kp + Mp + 256] = (red[1024] + red[1025]) + (red[1026] + red[1027]);
+    }
+}
+__global__ __launch_bounds__(256) void k_wgrad_h16_256(WgArgs a) {
+    if ((int)blockIdx.x >= a.d[blockIdx.y].n_chunks) return;
+    if (a.d[blockIdx.y].wcol) wgrad_h16_256_body<true>(a);
+    else wgrad_h16_256_body<false>(a);
+}
+
 // Ordered sum over chunks.  A workgroup of 256 threads handles 64 consecutive output elements: thread (e, q) sums
 // every 4th chunk starting at q (4 independent load streams per element), the four partial sums are folded in a
 // fixed order through LDS -> deterministic, and 4x the memory-level parallelism of one thread per element.
@@ -584,7 +729,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
             const size_t o = add(c82, n82, 256, 64, dy, W, W, pex, DPE_PAD, DPE_PAD);
             group(n_small, o, 1, 256, 64, W, DPE, dW, DPE, 0, db);
         } else if (i == SKIP_LAYER) {
-            const size_t o1 = add(c82, n82, 256, 64, dy, W, W, pex, DPE_PAD, DPE_PAD);
+            const size_t o1 = add(c82, n82, 256, 64, precision == VIPNERF_PREC_FP16X3H ? bwd + bl.dy5f : dy, W, W, pex, DPE_PAD, DPE_PAD);
             group(n_small, o1, 1, 256, 64, W, DPE, dW, W + DPE, 0, nullptr);
             const size_t o2 = add(c88, n88, 256, 256, dy, W, W, acts + al.h[i - 1], W, W);
             group(n_chunks, o2, 1, 256, 256, W, W, dW, W + DPE, DPE, db);
@@ -642,6 +787,11 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
         ProfScope ps("wgrad_256x256", st);
         if (precision == VIPNERF_PREC_FP32) {
             if ((rc = launch_class<2, 8, 4>(c88, n88, n_chunks, st))) return rc;
+        } else if (precision == VIPNERF_PREC_FP16X3H) {   // operands stored as fp16: single-MFMA kernel, half the bytes
+            const size_t ldsb = (size_t)2 * 2 * 256 * 64;
+            VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_h16_256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+            hipLaunchKernelGGL(k_wgrad_h16_256, dim3(n_chunks, n88), dim3(256), ldsb, st, c88);
+            VN_HIP(hipGetLastError());
         } else {                                   // bf16x3 and bf16x6 both use the hi/lo kernel for the weight gradients
             const size_t ldsb = (size_t)2 * 4 * 256 * 64;
             VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_bf16x3_256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));

@@ -177,6 +177,14 @@ __device__ __forceinline__ floatx4 load_tile16(const float *base, int64_t p, int
     floatx4 v = {f.x, f.y, f.z, f.w};
     return v;
 }
+// -DVN_F16_PRESPLIT=1: FP16X3 stores the trunk activations / gradients that only the 256x256 weight-gradient GEMMs read
+// back pre-split (hi and lo fp16 planes, the same bytes as fp32), and those GEMMs stage with a v_perm gather and run
+// 3 fp16 cross terms.  Built, correct (all tests pass) and measured on the same box: SLOWER -- forward 5.3 vs 4.34 ms,
+// data gradients 6.3 vs 5.0 ms (two 8-byte stores per lane and tile instead of one 16-byte store), weight gradients
+// unchanged (5.69 vs 5.66 ms: the conversion VALU is gone, but the loads are 8 bytes per lane too).  Off.
+#ifndef VN_F16_PRESPLIT
+#define VN_F16_PRESPLIT 0
+#endif
 // FP16X3H: the fp16 high parts of a B fragment (k-step s <- tiles 2s, 2s+1) ARE the fp16 image of those two tiles:
 // elements 4u .. 4u+3 of part 0 are features 16 (2s+u) + 4q .. +3.  Stored as [P][ld] halves (8 bytes per lane, tile).
 __device__ __forceinline__ void store_pair16h(float *base, int64_t p, int ld, int q, int s, const half8 &hi, bool valid) {

@@ -47,7 +47,7 @@ __global__ void k_seed_absmax(MlpBwdArgs a, unsigned *slot) {
 // H16 (with F16, FP16X3H): dY of the feature layer and of layers 1..7 -- read back only by the 256x256 weight-gradient
 // GEMMs -- are stored as fp16 (the high parts of the split that is made for the next GEMM anyway); dY_5 additionally
 // in fp32 for layer 5's gamma(x) GEMM; dY_0 stays fp32.
-template <int NS, bool F16, bool H16 = false>
+template <int NS, bool F16, int H16 = 0>
 __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) {
     typedef BnPlan<NS> PL;
     typedef typename FragOf<F16>::type FR;
@@ -149,7 +149,10 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
             store_tile16(a.bwd + a.bl.dyf, p, W, q, 2 * s + 1, x1, valid);
         }
         split_pair<NS>(x0, x1, bin[s]);
-        if (H16) store_pair16h(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0], valid);
+        if (H16) {
+            store_pair16h(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0], valid);
+            if (H16 == 2) store_pair16h(a.bwd + a.bl.dyf + (size_t)a.src.P * (W / 2), p, W, q, s, bin[s][1], valid);
+        }
     }
 
     // ---------------------------------------------------------------- feature layer, then layers 7..1
@@ -183,14 +186,17 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
             }
             if (it < 7) {
                 split_pair<NS>(x[0], x[1], bin[s]);
-                if (H16) store_pair16h(dst, p, W, q, s, bin[s][0], valid);
+                if (H16) {
+                    store_pair16h(dst, p, W, q, s, bin[s][0], valid);
+                    if (H16 == 2) store_pair16h(dst + (size_t)a.src.P * (W / 2), p, W, q, s, bin[s][1], valid);
+                }
             }
         }
     }
     stream_end(ws);
 }
 
-template <int NS, bool F16 = false, bool H16 = false>
+template <int NS, bool F16 = false, int H16 = 0>
 static int launch_one_bwd_n(const MlpBwdArgs &a, unsigned grid, hipStream_t st) {
     const size_t lds = (size_t)BnPlan<NS>::LDS_F * sizeof(float);
     VN_HIP(hipFuncSetAttribute((const void *)k_mlp_bwd_bf16n<NS, F16, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -212,7 +218,7 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
         VN_HIP(hipGetLastError());
         MlpBwdArgs b = a;
         b.gmax = slot;
-        return precision == 4 ? launch_one_bwd_n<2, true, true>(b, grid, st) : launch_one_bwd_n<2, true>(b, grid, st);
+        return precision == 4 ? launch_one_bwd_n<2, true, 1>(b, grid, st) : launch_one_bwd_n<2, true, VN_F16_PRESPLIT ? 2 : 0>(b, grid, st);
     }
     set_error("mlp_bwd_bf16n: precision %d", precision);
     return VIPNERF_E_ARG;

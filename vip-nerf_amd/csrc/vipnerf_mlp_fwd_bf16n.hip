@@ -70,8 +70,10 @@ __device__ __forceinline__ void store_d16(float *row, int q, const float (&pd)[1
 }
 
 // F16: fp16 fragments with power-of-two operand scaling (vipnerf_bf16n.h); otherwise bf16 fragments.
-// H16 (with F16 and SAVE): the trunk activations h_1..h_8 are stored as fp16 (FP16X3H); everything else stays fp32.
-template <bool SAVE, int NS, bool F16, bool H16 = false>
+// H16 (with F16 and SAVE): how the trunk activations h_1..h_8 are stored for the weight-gradient GEMMs: 0 = fp32 [P][256];
+// 1 = fp16 high parts only (FP16X3H); 2 = both fp16 parts, as two [P][256]-half planes in the array's slot (FP16X3: the
+// same bytes as fp32, but already split).  Everything else stays fp32.
+template <bool SAVE, int NS, bool F16, int H16 = 0>
 __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) {
     typedef BnPlan<NS> PL;
     typedef typename FragOf<F16>::type FR;
@@ -181,7 +183,10 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             }
             if (F16) { x[0] *= XS; x[1] *= XS; }
             split_pair<NS>(x[0], x[1], bin[s]);
-            if (SAVE && H16 && layer < 8) store_pair16h(dst, p, W, q, s, bin[s][0], valid);
+            if (SAVE && H16 && layer < 8) {
+                store_pair16h(dst, p, W, q, s, bin[s][0], valid);
+                if (H16 == 2) store_pair16h(dst + (size_t)a.src.P * (W / 2), p, W, q, s, bin[s][1], valid);
+            }
         }
         if (SAVE && valid && layer < 8) *(uint2 *)(a.acts + a.al.hm[layer] + ((size_t)p * 4 + q) * 2) = make_uint2(mk0, mk1);
     }
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
     }
 }
 
-template <bool SAVE, int NS, bool F16 = false, bool H16 = false>
+template <bool SAVE, int NS, bool F16 = false, int H16 = 0>
 static int launch_one_n(const MlpFwdArgs &a, unsigned grid, hipStream_t st) {
     const size_t lds = (size_t)BnPlan<NS>::LDS_F * sizeof(float);
     VN_HIP(hipFuncSetAttribute((const void *)k_mlp_fwd_bf16n<SAVE, NS, F16, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -281,8 +286,8 @@ int launch_mlp_fwd_bf16n(const MlpFwdArgs &a, int precision, hipStream_t st) {
     const unsigned grid = (unsigned)((a.src.P + MLP_PTS_PER_WG - 1) / MLP_PTS_PER_WG);
     if (precision == 1) return a.acts ? launch_one_n<true, 2>(a, grid, st) : launch_one_n<false, 2>(a, grid, st);
     if (precision == 2) return a.acts ? launch_one_n<true, 3>(a, grid, st) : launch_one_n<false, 3>(a, grid, st);
-    if (precision == 3) return a.acts ? launch_one_n<true, 2, true>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);
-    if (precision == 4) return a.acts ? launch_one_n<true, 2, true, true>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);
+    if (precision == 3) return a.acts ? launch_one_n<true, 2, true, VN_F16_PRESPLIT ? 2 : 0>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);
+    if (precision == 4) return a.acts ? launch_one_n<true, 2, true, 1>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);
     set_error("mlp_fwd_bf16n: precision %d", precision);
     return VIPNERF_E_ARG;
 }

@@ -10,6 +10,7 @@
 // writes its partial product; an ordered second pass sums the chunks (deterministic; no atomics) straight into
 // the nn.Linear-layout gradient tensors.
 #include "vipnerf_wgrad.h"
+#include "vipnerf_bf16n.h"
 #include "vipnerf_prof.h"
 
 namespace vn {
@@ -483,16 +484,17 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16x3_256(WgArgs a) {
     else wgrad_bf16x3_256_body<false>(a);
 }
 
-// FP16X3H: the 256x256 class when both operands were STORED as fp16 ([P][256] halves: the trunk activations h_1..h_8 and
-// the gradients dY_1..dY_7, dY_feature).  No split and no conversion while staging -- a thread gathers the 8 points of
-// a feature from its 8 row registers with v_perm and writes them as one 16-byte LDS store (same [feature][4 slots of 8
-// points] plane, same swizzle, one plane per operand) -- and ONE v_mfma_f32_32x32x16_f16 per product.  Half the bytes
-// and a third of the MFMAs of the hi/lo kernel; it is bound by the operand stream.
-template <bool HAS_W>
+// The 256x256 class when both operands were STORED as fp16 ([P][256] halves: the trunk activations h_1..h_8 and the
+// gradients dY_1..dY_7, dY_feature).  PARTS = 1 (FP16X3H): high parts only, ONE v_mfma_f32_32x32x16_f16 per product --
+// half the bytes and a third of the MFMAs of the bf16 hi/lo kernel.  PARTS = 2 (FP16X3): a second plane of low parts
+// follows the first in the array's slot (P * 128 floats further), three cross terms -- the bytes of the fp32 arrays, but
+// no split and no conversion while staging: a thread gathers the 8 points of a feature from its 8 row registers with
+// v_perm and writes them as one 16-byte LDS store per plane (same [feature][4 slots of 8 points] planes and swizzle).
+template <bool HAS_W, int PARTS>
 __device__ __forceinline__ void wgrad_h16_256_body(const WgArgs &a) {
     constexpr int MTW = 2, KTW = 8, Mp = 256, Kp = 256;
-    constexpr int PLANE = 256 * 64;                       // bytes: one operand, 256 features x 32 points x 2 B
-    constexpr int BUF = 2 * PLANE;                        // A, B
+    constexpr int PLANE = 256 * 64;                       // bytes: one operand, one part, 256 features x 32 points x 2 B
+    constexpr int BUF = 2 * PARTS * PLANE;                // A parts, then B parts
     extern __shared__ __attribute__((aligned(16))) float lds[];
     char *lb = (char *)lds;
     typedef _Float16 half8_ __attribute__((ext_vector_type(8)));
@@ -513,16 +515,20 @@ __device__ __forceinline__ void wgrad_h16_256_body(const WgArgs &a) {
     float ws[4] = {0.f, 0.f, 0.f, 0.f}, wsum = 0.f;
     float wv[8];
 
-    uint2 ua[8], ub[8];                                   // rows wave + 4 i, features 4 lane .. + 3 (4 halves = 8 bytes)
+    uint2 ua[PARTS][8], ub[PARTS][8];                     // rows wave + 4 i, features 4 lane .. + 3 (4 halves = 8 bytes)
     const uint2 *A2 = (const uint2 *)d.A, *B2 = (const uint2 *)d.B;   // a row = 256 halves = 64 uint2
+    const size_t plane2 = (size_t)a.P * 64;               // second (low-part) plane, in uint2
     auto gload = [&](int blk) {
         const int64_t pb = p0 + (int64_t)blk * 32;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int64_t row = pb + wave + 4 * i;
             const bool ok = row < p1;
-            ua[i] = ok ? A2[(size_t)row * 64 + lane] : make_uint2(0u, 0u);
-            ub[i] = ok ? B2[(size_t)row * 64 + lane] : make_uint2(0u, 0u);
+#pragma unroll
+            for (int pt = 0; pt < PARTS; ++pt) {
+                ua[pt][i] = ok ? A2[pt * plane2 + (size_t)row * 64 + lane] : make_uint2(0u, 0u);
+                ub[pt][i] = ok ? B2[pt * plane2 + (size_t)row * 64 + lane] : make_uint2(0u, 0u);
+            }
             if (HAS_W) wv[i] = ok ? d.wcol[(size_t)row * d.wcol_stride] : 0.f;
         }
     };
@@ -548,15 +554,20 @@ __device__ __forceinline__ void wgrad_h16_256_body(const WgArgs &a) {
         for (int c = 0; c < 4; ++c) {
             const int f = 4 * lane + c;
             const int off = f * 64 + ((wave ^ ((f >> 2) & 3)) << 4);
-            uint4 pa, pb;
-            gather(ua, c, pa);
-            gather(ub, c, pb);
-            *(uint4 *)(base + off) = pa;
-            *(uint4 *)(base + PLANE + off) = pb;
+#pragma unroll
+            for (int pt = 0; pt < PARTS; ++pt) {
+                uint4 pa, pb;
+                gather(ua[pt], c, pa);
+                gather(ub[pt], c, pb);
+                *(uint4 *)(base + pt * PLANE + off) = pa;
+                *(uint4 *)(base + (PARTS + pt) * PLANE + off) = pb;
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                bs[c] += half_of(ua[i], c);
-                if (HAS_W) ws[c] = fmaf(wv[i], half_of(ub[i], c), ws[c]);
+                float av = half_of(ua[0][i], c), bv = HAS_W ? half_of(ub[0][i], c) : 0.f;
+                if (PARTS == 2) { av += half_of(ua[PARTS - 1][i], c); if (HAS_W) bv += half_of(ub[PARTS - 1][i], c); }
+                bs[c] += av;
+                if (HAS_W) ws[c] = fmaf(wv[i], bv, ws[c]);
             }
         }
         if (HAS_W) {
@@ -574,21 +585,31 @@ __device__ __forceinline__ void wgrad_h16_256_body(const WgArgs &a) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int slot = 2 * ks + h;
-            half8_ af[MTW], bf[KTW];
+            half8_ af[MTW][PARTS], bf[KTW][PARTS];
 #pragma unroll
             for (int i = 0; i < MTW; ++i) {
                 const int f = 32 * (wave * MTW + i) + l31;
-                af[i] = *(const half8_ *)(base + f * 64 + ((slot ^ ((f >> 2) & 3)) << 4));
+#pragma unroll
+                for (int pt = 0; pt < PARTS; ++pt) af[i][pt] = *(const half8_ *)(base + pt * PLANE + f * 64 + ((slot ^ ((f >> 2) & 3)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < KTW; ++j) {
                 const int f = 32 * j + l31;
-                bf[j] = *(const half8_ *)(base + PLANE + f * 64 + ((slot ^ ((f >> 2) & 3)) << 4));
+#pragma unroll
+                for (int pt = 0; pt < PARTS; ++pt) bf[j][pt] = *(const half8_ *)(base + (PARTS + pt) * PLANE + f * 64 + ((slot ^ ((f >> 2) & 3)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < MTW; ++i)
 #pragma unroll
-                for (int j = 0; j < KTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < KTW; ++j) {
+                    floatx16 c = acc[i][j];
+                    if (PARTS == 2) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][PARTS - 1], bf[j][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][PARTS - 1], c, 0, 0, 0);
+                    }
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
         }
         if (blk + 1 < nblk) lstore(cur ^ 1);
         __syncthreads();
@@ -622,10 +643,11 @@ __device__ __forceinline__ void wgrad_h16_256_body(const WgArgs &a) {
         if (tid == 0) part[(size_t)Mp * Kp + Mp + 256] = (red[1024] + red[1025]) + (red[1026] + red[1027]);
     }
 }
+template <int PARTS>
 __global__ __launch_bounds__(256) void k_wgrad_h16_256(WgArgs a) {
     if ((int)blockIdx.x >= a.d[blockIdx.y].n_chunks) return;
-    if (a.d[blockIdx.y].wcol) wgrad_h16_256_body<true>(a);
-    else wgrad_h16_256_body<false>(a);
+    if (a.d[blockIdx.y].wcol) wgrad_h16_256_body<true, PARTS>(a);
+    else wgrad_h16_256_body<false, PARTS>(a);
 }
 
 // Ordered sum over chunks.  A workgroup of 256 threads handles 64 consecutive output elements: thread (e, q) sums
@@ -692,6 +714,8 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
     const int n_chunks = wgrad_chunks(P), n_small = wgrad_chunks_small(P), n_single = wgrad_chunks_single(P);
     const int chunk_pts = wgrad_chunk_pts(P), chunk_small = chunk_pts / WGRAD_SMALL_SPLIT, chunk_single = chunk_pts / WGRAD_SINGLE_SPLIT;
     float *partial = bwd + bl.partial;
+    // storage of the 256x256 class's operands: 0 = fp32, 1 = fp16 high parts (FP16X3H), 2 = fp16 hi + lo planes (FP16X3)
+    const int halves = precision == VIPNERF_PREC_FP16X3H ? 1 : (precision == VIPNERF_PREC_FP16X3 && VN_F16_PRESPLIT ? 2 : 0);
 
     WgArgs c88, c82, c48, c41, c18, c14;       // classes by (M tiles, K tiles)
     WgReduceArgs red;
@@ -729,7 +753,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
             const size_t o = add(c82, n82, 256, 64, dy, W, W, pex, DPE_PAD, DPE_PAD);
             group(n_small, o, 1, 256, 64, W, DPE, dW, DPE, 0, db);
         } else if (i == SKIP_LAYER) {
-            const size_t o1 = add(c82, n82, 256, 64, precision == VIPNERF_PREC_FP16X3H ? bwd + bl.dy5f : dy, W, W, pex, DPE_PAD, DPE_PAD);
+            const size_t o1 = add(c82, n82, 256, 64, halves ? bwd + bl.dy5f : dy, W, W, pex, DPE_PAD, DPE_PAD);
             group(n_small, o1, 1, 256, 64, W, DPE, dW, W + DPE, 0, nullptr);
             const size_t o2 = add(c88, n88, 256, 256, dy, W, W, acts + al.h[i - 1], W, W);
             group(n_chunks, o2, 1, 256, 256, W, W, dW, W + DPE, DPE, db);
@@ -787,10 +811,15 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
         ProfScope ps("wgrad_256x256", st);
         if (precision == VIPNERF_PREC_FP32) {
             if ((rc = launch_class<2, 8, 4>(c88, n88, n_chunks, st))) return rc;
-        } else if (precision == VIPNERF_PREC_FP16X3H) {   // operands stored as fp16: single-MFMA kernel, half the bytes
+        } else if (halves == 1) {                  // operands stored as fp16 high parts: single-MFMA kernel, half the bytes
             const size_t ldsb = (size_t)2 * 2 * 256 * 64;
-            VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_h16_256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-            hipLaunchKernelGGL(k_wgrad_h16_256, dim3(n_chunks, n88), dim3(256), ldsb, st, c88);
+            VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_h16_256<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+            hipLaunchKernelGGL(k_wgrad_h16_256<1>, dim3(n_chunks, n88), dim3(256), ldsb, st, c88);
+            VN_HIP(hipGetLastError());
+        } else if (halves == 2) {                  // operands stored pre-split (hi and lo fp16 planes): 3 fp16 cross terms
+            const size_t ldsb = (size_t)2 * 4 * 256 * 64;
+            VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_h16_256<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+            hipLaunchKernelGGL(k_wgrad_h16_256<2>, dim3(n_chunks, n88), dim3(256), ldsb, st, c88);
             VN_HIP(hipGetLastError());
         } else {                                   // bf16x3 and bf16x6 both use the hi/lo kernel for the weight gradients
             const size_t ldsb = (size_t)2 * 4 * 256 * 64;

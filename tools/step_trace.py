@@ -22,4 +22,7 @@ torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     step(2); torch.cuda.synchronize()
-print(prof.key_averages(group_by_stack_n=4).table(sort_by='cuda_time_total', row_limit=40, max_name_column_width=60, max_src_column_width=90))
+evs = [e for e in prof.key_averages(group_by_stack_n=6) if e.key in ('aten::fill_', 'aten::zero_', 'aten::zeros', 'aten::copy_', 'aten::mul', 'aten::add', 'aten::add_', 'aten::_to_copy', 'aten::sum', 'aten::select_backward')]
+for e in sorted(evs, key=lambda e: -e.count)[:40]:
+    st = [s for s in e.stack if 'site-packages' not in s and 'dist-packages' not in s][:3]
+    print('%-22s x%-3d cuda %.0f us | %s' % (e.key, e.count, e.device_time_total, ' <- '.join(x.strip()[-70:] for x in st)))

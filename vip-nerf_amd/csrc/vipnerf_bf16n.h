@@ -178,10 +178,12 @@ __device__ __forceinline__ floatx4 load_tile16(const float *base, int64_t p, int
     return v;
 }
 // -DVN_F16_PRESPLIT=1: FP16X3 stores the trunk activations / gradients that only the 256x256 weight-gradient GEMMs read
-// back pre-split (hi and lo fp16 planes, the same bytes as fp32), and those GEMMs stage with a v_perm gather and run
-// 3 fp16 cross terms.  Built, correct (all tests pass) and measured on the same box: SLOWER -- forward 5.3 vs 4.34 ms,
-// data gradients 6.3 vs 5.0 ms (two 8-byte stores per lane and tile instead of one 16-byte store), weight gradients
-// unchanged (5.69 vs 5.66 ms: the conversion VALU is gone, but the loads are 8 bytes per lane too).  Off.
+// back already split (hi and lo fp16 parts in the bytes of the fp32 values they replace; store_pair_split), and those
+// GEMMs stage with a v_perm gather instead of ~500 VALU of conversion per 32-point block and run 3 fp16 cross terms
+// (k_wgrad_split16_256).  Built, all tests pass; measured on the same box 14.96-15.00 vs 15.03-15.34 ms per step
+// (weight gradients 5.37 vs 5.46 ms): the conversion VALU was not what bounds that kernel (its global loads run only
+// one 32-point block ahead and there are no registers for two).  Within noise; kept off so that the stored activations
+// stay plain fp32.  (A first version with two separate [P][256]-half planes was clearly slower: 8-byte stores / loads.)
 #ifndef VN_F16_PRESPLIT
 #define VN_F16_PRESPLIT 0
 #endif
@@ -196,6 +198,19 @@ __device__ __forceinline__ void store_pair16h(float *base, int64_t p, int ld, in
     __builtin_nontemporal_store(b, (half4 *)(row + 16 * (2 * s + 1)));
 }
 __device__ __forceinline__ void store_pair16h(float *, int64_t, int, int, int, const bf16x8 &, bool) {}   // never used
+// VN_F16_PRESPLIT: both fp16 parts of the two tiles, in the fp32 array's own geometry: the 16 bytes a lane owns per tile
+// (4 features) hold [hi(f0,f1)] [hi(f2,f3)] [lo(f0,f1)] [lo(f2,f3)] -- the registers of the split as they are, one 16-byte
+// store per tile exactly like the fp32 store.
+__device__ __forceinline__ void store_pair_split(float *base, int64_t p, int ld, int q, int s, const half8 &hi, const half8 &lo, bool valid) {
+    if (!valid) return;
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4 h = __builtin_bit_cast(u4, hi), l = __builtin_bit_cast(u4, lo);
+    float *row = base + (size_t)p * ld + 4 * q;
+    const u4 t0 = {h[0], h[1], l[0], l[1]}, t1 = {h[2], h[3], l[2], l[3]};
+    __builtin_nontemporal_store(t0, (u4 *)(row + 16 * (2 * s)));
+    __builtin_nontemporal_store(t1, (u4 *)(row + 16 * (2 * s + 1)));
+}
+__device__ __forceinline__ void store_pair_split(float *, int64_t, int, int, int, const bf16x8 &, const bf16x8 &, bool) {}
 
 // two C/D tiles (2s, 2s+1) -> the NS-part B fragment of k-step s
 template <int NS, typename FR>

@@ -149,10 +149,8 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
             store_tile16(a.bwd + a.bl.dyf, p, W, q, 2 * s + 1, x1, valid);
         }
         split_pair<NS>(x0, x1, bin[s]);
-        if (H16) {
-            store_pair16h(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0], valid);
-            if (H16 == 2) store_pair16h(a.bwd + a.bl.dyf + (size_t)a.src.P * (W / 2), p, W, q, s, bin[s][1], valid);
-        }
+        if (H16 == 1) store_pair16h(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0], valid);
+        if (H16 == 2) store_pair_split(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0], bin[s][1], valid);
     }
 
     // ---------------------------------------------------------------- feature layer, then layers 7..1
@@ -186,10 +184,8 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
             }
             if (it < 7) {
                 split_pair<NS>(x[0], x[1], bin[s]);
-                if (H16) {
-                    store_pair16h(dst, p, W, q, s, bin[s][0], valid);
-                    if (H16 == 2) store_pair16h(dst + (size_t)a.src.P * (W / 2), p, W, q, s, bin[s][1], valid);
-                }
+                if (H16 == 1) store_pair16h(dst, p, W, q, s, bin[s][0], valid);
+                if (H16 == 2) store_pair_split(dst, p, W, q, s, bin[s][0], bin[s][1], valid);
             }
         }
     }

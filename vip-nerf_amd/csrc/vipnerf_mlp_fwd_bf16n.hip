@@ -183,10 +183,8 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             }
             if (F16) { x[0] *= XS; x[1] *= XS; }
             split_pair<NS>(x[0], x[1], bin[s]);
-            if (SAVE && H16 && layer < 8) {
-                store_pair16h(dst, p, W, q, s, bin[s][0], valid);
-                if (H16 == 2) store_pair16h(dst + (size_t)a.src.P * (W / 2), p, W, q, s, bin[s][1], valid);
-            }
+            if (SAVE && H16 == 1 && layer < 8) store_pair16h(dst, p, W, q, s, bin[s][0], valid);
+            if (SAVE && H16 == 2 && layer < 8) store_pair_split(dst, p, W, q, s, bin[s][0], bin[s][1], valid);
         }
         if (SAVE && valid && layer < 8) *(uint2 *)(a.acts + a.al.hm[layer] + ((size_t)p * 4 + q) * 2) = make_uint2(mk0, mk1);
     }

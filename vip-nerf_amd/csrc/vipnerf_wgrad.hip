@@ -643,6 +643,174 @@ __device__ __forceinline__ void wgrad_h16_256_body(const WgArgs &a) {
         if (tid == 0) part[(size_t)Mp * Kp + Mp + 256] = (red[1024] + red[1025]) + (red[1026] + red[1027]);
     }
 }
+// FP16X3 with VN_F16_PRESPLIT: both operands stored already split, in the fp32 arrays' own geometry -- the 16 bytes of
+// (row, 4 features) hold [hi(f0,f1)] [hi(f2,f3)] [lo(f0,f1)] [lo(f2,f3)] (store_pair_split).  Same 16-byte loads as the
+// fp32 layout, staging = v_perm gathers (8 per feature), three fp16 cross terms.
+template <bool HAS_W>
+__device__ __forceinline__ void wgrad_split16_256_body(const WgArgs &a) {
+    constexpr int MTW = 2, KTW = 8, Mp = 256, Kp = 256;
+    constexpr int PLANE = 256 * 64;
+    constexpr int BUF = 4 * PLANE;                        // A hi, A lo, B hi, B lo
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char *lb = (char *)lds;
+    typedef _Float16 half8_ __attribute__((ext_vector_type(8)));
+
+    const WgDesc &d = a.d[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int64_t p0 = (int64_t)blockIdx.x * a.chunk_pts;
+    const int64_t p1 = p0 + a.chunk_pts < a.P ? p0 + a.chunk_pts : a.P;
+    const int nblk = (int)((p1 - p0 + 31) / 32);
+
+    floatx16 acc[MTW][KTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int j = 0; j < KTW; ++j) acc[i][j] = (floatx16)(0.f);
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    float ws[4] = {0.f, 0.f, 0.f, 0.f}, wsum = 0.f;
+    float wv[8];
+
+    uint4 ua[8], ub[8];                                   // rows wave + 4 i, features 4 lane .. + 3
+    auto gload = [&](int blk) {
+        const int64_t pb = p0 + (int64_t)blk * 32;
+        if (HAS_W) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t row = pb + wave + 4 * i;
+                wv[i] = row < p1 ? d.wcol[(size_t)row * d.wcol_stride] : 0.f;
+            }
+        }
+        if (pb + 32 <= p1) {
+            const uint4 *ta = (const uint4 *)(d.A + (size_t)pb * Mp) + tid;
+            const uint4 *tb = (const uint4 *)(d.B + (size_t)pb * Kp) + tid;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { ua[i] = ta[256 * i]; ub[i] = tb[256 * i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t row = pb + wave + 4 * i;
+                const bool ok = row < p1;
+                ua[i] = ok ? *((const uint4 *)(d.A + (size_t)row * Mp) + lane) : make_uint4(0u, 0u, 0u, 0u);
+                ub[i] = ok ? *((const uint4 *)(d.B + (size_t)row * Kp) + lane) : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    };
+    auto word_of = [](const uint4 &u, int c, int part) -> unsigned {   // the dword holding feature c of part (0 hi, 1 lo)
+        return part == 0 ? (c < 2 ? u.x : u.y) : (c < 2 ? u.z : u.w);
+    };
+    auto value_of = [&](const uint4 &u, int c) -> float {  // hi + lo of feature c
+        const unsigned wh = word_of(u, c, 0), wl = word_of(u, c, 1);
+        const unsigned short bh = (unsigned short)((c & 1) ? (wh >> 16) : (wh & 0xffffu));
+        const unsigned short bl = (unsigned short)((c & 1) ? (wl >> 16) : (wl & 0xffffu));
+        return (float)__builtin_bit_cast(_Float16, bh) + (float)__builtin_bit_cast(_Float16, bl);
+    };
+    auto gather = [&](const uint4 (&u)[8], int c, int part, uint4 &o) {
+        const unsigned sel = (c & 1) ? 0x07060302u : 0x05040100u;
+        unsigned r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = __builtin_amdgcn_perm(word_of(u[2 * k + 1], c, part), word_of(u[2 * k], c, part), sel);
+        o = make_uint4(r[0], r[1], r[2], r[3]);
+    };
+    auto lstore = [&](int buf) {
+        char *base = lb + buf * BUF;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int f = 4 * lane + c;
+            const int off = f * 64 + ((wave ^ ((f >> 2) & 3)) << 4);
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                uint4 pa, pb;
+                gather(ua, c, pt, pa);
+                gather(ub, c, pt, pb);
+                *(uint4 *)(base + pt * PLANE + off) = pa;
+                *(uint4 *)(base + (2 + pt) * PLANE + off) = pb;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                bs[c] += value_of(ua[i], c);
+                if (HAS_W) ws[c] = fmaf(wv[i], value_of(ub[i], c), ws[c]);
+            }
+        }
+        if (HAS_W) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wsum += wv[i];
+        }
+    };
+
+    if (nblk > 0) { gload(0); lstore(0); }
+    __syncthreads();
+    int cur = 0;
+    for (int blk = 0; blk < nblk; ++blk) {
+        if (blk + 1 < nblk) gload(blk + 1);
+        const char *base = lb + cur * BUF;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int slot = 2 * ks + h;
+            half8_ af[MTW][2], bf[KTW][2];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+                const int f = 32 * (wave * MTW + i) + l31;
+                const int off = f * 64 + ((slot ^ ((f >> 2) & 3)) << 4);
+                af[i][0] = *(const half8_ *)(base + off);
+                af[i][1] = *(const half8_ *)(base + PLANE + off);
+            }
+#pragma unroll
+            for (int j = 0; j < KTW; ++j) {
+                const int f = 32 * j + l31;
+                const int off = f * 64 + ((slot ^ ((f >> 2) & 3)) << 4);
+                bf[j][0] = *(const half8_ *)(base + 2 * PLANE + off);
+                bf[j][1] = *(const half8_ *)(base + 3 * PLANE + off);
+            }
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                for (int j = 0; j < KTW; ++j) {
+                    floatx16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], bf[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        }
+        if (blk + 1 < nblk) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    float *part = a.partial + d.part_off + (size_t)blockIdx.x * d.part_stride;
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int ot = wave * MTW + i;
+#pragma unroll
+        for (int j = 0; j < KTW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * h;
+                part[(size_t)o * Kp + 32 * j + l31] = acc[i][j][r];
+            }
+    }
+    float *red = (float *)lb;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[wave * 256 + 4 * lane + c] = bs[c];
+    __syncthreads();
+    part[(size_t)Mp * Kp + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+    if (HAS_W) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[wave * 256 + 4 * lane + c] = ws[c];
+        if (lane == 0) red[1024 + wave] = wsum;
+        __syncthreads();
+        part[(size_t)Mp * Kp + Mp + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+        if (tid == 0) part[(size_t)Mp * Kp + Mp + 256] = (red[1024] + red[1025]) + (red[1026] + red[1027]);
+    }
+}
+__global__ __launch_bounds__(256) void k_wgrad_split16_256(WgArgs a) {
+    if ((int)blockIdx.x >= a.d[blockIdx.y].n_chunks) return;
+    if (a.d[blockIdx.y].wcol) wgrad_split16_256_body<true>(a);
+    else wgrad_split16_256_body<false>(a);
+}
+
 template <int PARTS>
 __global__ __launch_bounds__(256) void k_wgrad_h16_256(WgArgs a) {
     if ((int)blockIdx.x >= a.d[blockIdx.y].n_chunks) return;
@@ -818,8 +986,8 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
             VN_HIP(hipGetLastError());
         } else if (halves == 2) {                  // operands stored pre-split (hi and lo fp16 planes): 3 fp16 cross terms
             const size_t ldsb = (size_t)2 * 4 * 256 * 64;
-            VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_h16_256<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-            hipLaunchKernelGGL(k_wgrad_h16_256<2>, dim3(n_chunks, n88), dim3(256), ldsb, st, c88);
+            VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_split16_256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+            hipLaunchKernelGGL(k_wgrad_split16_256, dim3(n_chunks, n88), dim3(256), ldsb, st, c88);
             VN_HIP(hipGetLastError());
         } else {                                   // bf16x3 and bf16x6 both use the hi/lo kernel for the weight gradients
             const size_t ldsb = (size_t)2 * 4 * 256 * 64;

@@ -15,6 +15,19 @@
 
 namespace vn {
 
+// LDS plane layout of the split-precision kernels: [row][4 slots of 8 points], 64 bytes per feature row, NF features.
+// A staging thread writes features 4 g .. 4 g + 3 for consecutive g across lanes, a fragment read takes features
+// 32 t + lane.  Rows are grouped by feature & 3 (row = (f & 3) * NF/4 + f >> 2: consecutive writers 64 bytes apart
+// instead of 256) and the slot is XORed with (f & 3) ^ (f >> 4), so that 8 consecutive writers and each 16-lane read
+// group hit 16 distinct 4-bank groups.  (SQ_LDS_BANK_CONFLICT of these kernels is exactly 8 cycles per ds_write_b128
+// wave-instruction with this and with the previous layout alike: the counter charges the 8 LDS cycles a 1 KiB store
+// needs, it does not indicate address conflicts here.)
+template <int NF>
+__device__ __forceinline__ int wg_off(int f, int slot) {
+    const int row = (f & 3) * (NF / 4) + (f >> 2);
+    return row * 64 + ((slot ^ (((f & 3) ^ (f >> 4)) & 3)) << 4);
+}
+
 struct WgDesc {
     const float *A; int lda; int m_load;      // A[p][0..m_load) is read (m_load multiple of 4), zero beyond
     const float *B; int ldb; int k_load;
@@ -229,7 +242,7 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16x3(WgArgs a) {
         bf16x8 hi, lo;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { hi[e] = (__bf16)x[e]; lo[e] = (__bf16)(x[e] - (float)hi[e]); }
-        const int off = f * 64 + ((sl ^ ((f >> 2) & 3)) << 4);
+        const int off = psize == PA ? wg_off<Mp>(f, sl) : wg_off<Kp>(f, sl);
         *(bf16x8 *)(plane + off) = hi;
         *(bf16x8 *)(plane + psize + off) = lo;
     };
@@ -262,14 +275,14 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16x3(WgArgs a) {
 #pragma unroll
             for (int i = 0; i < MTW; ++i) {
                 const int f = 32 * (wave * MTW + i) + l31;
-                const int off = f * 64 + ((slot ^ ((f >> 2) & 3)) << 4);
+                const int off = wg_off<Mp>(f, slot);
                 af[i][0] = *(const bf16x8 *)(base + off);
                 af[i][1] = *(const bf16x8 *)(base + PA + off);
             }
 #pragma unroll
             for (int j = 0; j < KT; ++j) {
                 const int f = 32 * j + l31;
-                const int off = f * 64 + ((slot ^ ((f >> 2) & 3)) << 4);
+                const int off = wg_off<Kp>(f, slot);
                 bf[j][0] = *(const bf16x8 *)(base + 2 * PA + off);
                 bf[j][1] = *(const bf16x8 *)(base + 2 * PA + PB + off);
             }
@@ -384,7 +397,7 @@ __device__ __forceinline__ void wgrad_bf16x3_256_body(const WgArgs &a) {
         bf16x8 hi, lo;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { hi[e] = (__bf16)x[e]; lo[e] = (__bf16)(x[e] - (float)hi[e]); }
-        const int off = f * 64 + ((wave ^ ((f >> 2) & 3)) << 4);
+        const int off = wg_off<256>(f, wave);
         *(bf16x8 *)(plane + off) = hi;
         *(bf16x8 *)(plane + PLANE + off) = lo;
     };
@@ -422,14 +435,14 @@ __device__ __forceinline__ void wgrad_bf16x3_256_body(const WgArgs &a) {
 #pragma unroll
             for (int i = 0; i < MTW; ++i) {
                 const int f = 32 * (wave * MTW + i) + l31;
-                const int off = f * 64 + ((slot ^ ((f >> 2) & 3)) << 4);
+                const int off = wg_off<256>(f, slot);
                 af[i][0] = *(const bf16x8 *)(base + off);
                 af[i][1] = *(const bf16x8 *)(base + PLANE + off);
             }
 #pragma unroll
             for (int j = 0; j < KTW; ++j) {
                 const int f = 32 * j + l31;
-                const int off = f * 64 + ((slot ^ ((f >> 2) & 3)) << 4);
+                const int off = wg_off<256>(f, slot);
                 bf[j][0] = *(const bf16x8 *)(base + 2 * PLANE + off);
                 bf[j][1] = *(const bf16x8 *)(base + 3 * PLANE + off);
             }
@@ -553,7 +566,7 @@ __device__ __forceinline__ void wgrad_h16_256_body(const WgArgs &a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int f = 4 * lane + c;
-            const int off = f * 64 + ((wave ^ ((f >> 2) & 3)) << 4);
+            const int off = wg_off<256>(f, wave);
 #pragma unroll
             for (int pt = 0; pt < PARTS; ++pt) {
                 uint4 pa, pb;
@@ -590,13 +603,13 @@ __device__ __forceinline__ void wgrad_h16_256_body(const WgArgs &a) {
             for (int i = 0; i < MTW; ++i) {
                 const int f = 32 * (wave * MTW + i) + l31;
 #pragma unroll
-                for (int pt = 0; pt < PARTS; ++pt) af[i][pt] = *(const half8_ *)(base + pt * PLANE + f * 64 + ((slot ^ ((f >> 2) & 3)) << 4));
+                for (int pt = 0; pt < PARTS; ++pt) af[i][pt] = *(const half8_ *)(base + pt * PLANE + wg_off<256>(f, slot));
             }
 #pragma unroll
             for (int j = 0; j < KTW; ++j) {
                 const int f = 32 * j + l31;
 #pragma unroll
-                for (int pt = 0; pt < PARTS; ++pt) bf[j][pt] = *(const half8_ *)(base + (PARTS + pt) * PLANE + f * 64 + ((slot ^ ((f >> 2) & 3)) << 4));
+                for (int pt = 0; pt < PARTS; ++pt) bf[j][pt] = *(const half8_ *)(base + (PARTS + pt) * PLANE + wg_off<256>(f, slot));
             }
 #pragma unroll
             for (int i = 0; i < MTW; ++i)
@@ -717,7 +730,7 @@ __device__ __forceinline__ void wgrad_split16_256_body(const WgArgs &a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int f = 4 * lane + c;
-            const int off = f * 64 + ((wave ^ ((f >> 2) & 3)) << 4);
+            const int off = wg_off<256>(f, wave);
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) {
                 uint4 pa, pb;
@@ -751,14 +764,14 @@ __device__ __forceinline__ void wgrad_split16_256_body(const WgArgs &a) {
 #pragma unroll
             for (int i = 0; i < MTW; ++i) {
                 const int f = 32 * (wave * MTW + i) + l31;
-                const int off = f * 64 + ((slot ^ ((f >> 2) & 3)) << 4);
+                const int off = wg_off<256>(f, slot);
                 af[i][0] = *(const half8_ *)(base + off);
                 af[i][1] = *(const half8_ *)(base + PLANE + off);
             }
 #pragma unroll
             for (int j = 0; j < KTW; ++j) {
                 const int f = 32 * j + l31;
-                const int off = f * 64 + ((slot ^ ((f >> 2) & 3)) << 4);
+                const int off = wg_off<256>(f, slot);
                 bf[j][0] = *(const half8_ *)(base + 2 * PLANE + off);
                 bf[j][1] = *(const half8_ *)(base + 3 * PLANE + off);
             }

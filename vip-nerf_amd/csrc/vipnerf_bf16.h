@@ -146,6 +146,7 @@ struct WStreamT {
     int cur, fill;         // ring slot to consume next / to fill next
     int lane, wave;
     int turn;              // ROTATE: the wave that issues the next stage's DMA
+    int cturn;             // ROTATE: the wave that issued the stage about to be consumed
     static constexpr int SF = CH * CHUNK_F;
     static constexpr int PER_WAVE = ROTATE ? CH : CH / WAVES;
     static_assert(CH % WAVES == 0 && (NBUF == 2 || PER_WAVE * (NBUF - 2) <= 63), "vmcnt is a 6-bit counter");
@@ -165,7 +166,7 @@ struct WStreamT {
         fill = fill + 1 == NBUF ? 0 : fill + 1;
     }
     __device__ __forceinline__ void start(const float *stream, int n_stages, float *lds_buf, int lane_, int wave_) {
-        g = stream; buf = lds_buf; n_left = n_stages; in_flight = 0; cur = 0; fill = 0; lane = lane_; wave = wave_; turn = 0;
+        g = stream; buf = lds_buf; n_left = n_stages; in_flight = 0; cur = 0; fill = 0; lane = lane_; wave = wave_; turn = 0; cturn = 0;
 #pragma unroll
         for (int i = 0; i < NBUF - 1; ++i)
             if (n_left > 0) fetch();
@@ -178,7 +179,19 @@ struct WStreamT {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __device__ __forceinline__ const float *wait() {
-        if (NBUF == 2) {
+        if (NBUF == 2 && ROTATE) {
+            // only the wave that issued this stage's DMA has to see it land; a vmcnt(0) in every wave (what
+            // __syncthreads() also implies: its fence waits for the wave's outstanding global stores and loads) made
+            // all of them sit out the HBM latency of their activation stores / mask loads at every stage boundary.
+            // The data goes global -> LDS by DMA and LDS -> registers by ds_read: no cache to fence, a bare barrier
+            // after the issuer's drain publishes it.
+            __builtin_amdgcn_sched_barrier(0);
+            if (wave == cturn) glds_drain();
+            cturn = cturn + 1 == WAVES ? 0 : cturn + 1;
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        } else if (NBUF == 2) {
             glds_drain();
             __syncthreads();
         } else {

@@ -146,6 +146,7 @@ struct WStreamSkew {
     }
     __device__ __forceinline__ void begin() { if (lag) tick(); }
     __device__ __forceinline__ void end() { if (!lag) tick(); }
+    template <int YOUNGER = 0>
     __device__ __forceinline__ const float *wait() {
         tick();
         const float *ret = buf + slot * SF;
@@ -161,13 +162,41 @@ __device__ __forceinline__ void stream_end(...) {}
 template <int CH> __device__ __forceinline__ void stream_begin(WStreamSkew<CH> &w) { w.begin(); }
 template <int CH> __device__ __forceinline__ void stream_end(WStreamSkew<CH> &w) { w.end(); }
 
-// max(x, lo); the NaN-propagating form for the fp16 kernels (v_max_f32 returns the non-NaN operand)
+// max(x, lo) with lo = 0 (ReLU) or -inf (none).  The fp16 kernels use the form that passes NaN on (v_max_f32 returns
+// the non-NaN operand) and maps -0.0 to +0.0, so that the result is +0, a positive number or NaN -- nothing else.
+// (The one-instruction alternative, a signed-integer max of the bit patterns against 0, was measured: the NaN an MFMA
+// produces for inf - inf has its sign bit SET and would be squashed to 0 -- tests/test_hip_bf16.py::test_fp16x3_range.)
 template <bool NAN_THROUGH>
-__device__ __forceinline__ float relu_lo(float x, float lo) { return NAN_THROUGH ? (x < lo ? lo : x) : fmaxf(x, lo); }
+__device__ __forceinline__ float relu_bound(bool relu) { return relu ? 0.f : -INFINITY; }
+template <bool NAN_THROUGH>
+__device__ __forceinline__ float relu_lo(float x, float lo) { return NAN_THROUGH ? (x <= lo ? lo : x) : fmaxf(x, lo); }
+// 1 if y > 0, for a y that went through relu_lo<true>(., 0) (+0, positive or NaN: "bits != 0").  v_min_u32 + shifts
+// instead of v_cmp + v_cndmask + or: on gfx950 a VALU that reads VCC needs two wait states behind the v_cmp that wrote
+// it, ~3.5 issue slots per element against 2.  Inline asm: the compiler turns umin(b, 1) back into the compare form.
+__device__ __forceinline__ unsigned positive_bit(float y) {
+    unsigned r;
+    asm("v_min_u32 %0, 1, %1" : "=v"(r) : "v"(__float_as_uint(y)));
+    return r;
+}
+// the four ReLU bits of a C/D tile (bit r: element r > 0), Horner form on v_lshl_or_b32 (the compiler expands
+// (m << 1) | b into a shift and an or)
+__device__ __forceinline__ unsigned positive_nibble(const floatx4 &y) {
+    unsigned m = positive_bit(y[3]);
+#pragma unroll
+    for (int r = 2; r >= 0; --r) {
+        const unsigned b = positive_bit(y[r]);
+        asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(m) : "v"(m), "v"(b));
+    }
+    return m;
+}
+// append a tile's nibble to a mask word from the top: after eight tiles the first one sits in bits 0..3
+__device__ __forceinline__ unsigned push_nibble(unsigned word, unsigned nib) { return __builtin_amdgcn_alignbit(nib, word, 4); }
 
-// C/D tile T of a narrow fragment <-> row-major [P][ld]: lane (j, q) owns features 16T + 4q .. +3
-__device__ __forceinline__ void store_tile16(float *base, int64_t p, int ld, int q, int T, const floatx4 &v, bool valid) {
-    if (!valid) return;
+// C/D tile T of a narrow fragment <-> row-major [P][ld]: lane (j, q) owns features 16T + 4q .. +3.
+// The per-point stores of the narrow kernels are NOT predicated on the point being in range: a lane beyond P works on
+// point P - 1 (clamped index, same inputs, same arithmetic) and so writes the very bytes the lane that owns P - 1 writes
+// -- a benign duplicate in place of a branch around each of the 16 tile stores of a layer.
+__device__ __forceinline__ void store_tile16(float *base, int64_t p, int ld, int q, int T, const floatx4 &v) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     f4 val = {v[0], v[1], v[2], v[3]};
     __builtin_nontemporal_store(val, (f4 *)(base + (size_t)p * ld + 16 * T + 4 * q));
@@ -189,20 +218,18 @@ __device__ __forceinline__ floatx4 load_tile16(const float *base, int64_t p, int
 #endif
 // FP16X3H: the fp16 high parts of a B fragment (k-step s <- tiles 2s, 2s+1) ARE the fp16 image of those two tiles:
 // elements 4u .. 4u+3 of part 0 are features 16 (2s+u) + 4q .. +3.  Stored as [P][ld] halves (8 bytes per lane, tile).
-__device__ __forceinline__ void store_pair16h(float *base, int64_t p, int ld, int q, int s, const half8 &hi, bool valid) {
-    if (!valid) return;
+__device__ __forceinline__ void store_pair16h(float *base, int64_t p, int ld, int q, int s, const half8 &hi) {
     typedef _Float16 half4 __attribute__((ext_vector_type(4)));
     _Float16 *row = (_Float16 *)base + (size_t)p * ld + 4 * q;
     const half4 a = {hi[0], hi[1], hi[2], hi[3]}, b = {hi[4], hi[5], hi[6], hi[7]};
     __builtin_nontemporal_store(a, (half4 *)(row + 16 * (2 * s)));
     __builtin_nontemporal_store(b, (half4 *)(row + 16 * (2 * s + 1)));
 }
-__device__ __forceinline__ void store_pair16h(float *, int64_t, int, int, int, const bf16x8 &, bool) {}   // never used
+__device__ __forceinline__ void store_pair16h(float *, int64_t, int, int, int, const bf16x8 &) {}   // never used
 // VN_F16_PRESPLIT: both fp16 parts of the two tiles, in the fp32 array's own geometry: the 16 bytes a lane owns per tile
 // (4 features) hold [hi(f0,f1)] [hi(f2,f3)] [lo(f0,f1)] [lo(f2,f3)] -- the registers of the split as they are, one 16-byte
 // store per tile exactly like the fp32 store.
-__device__ __forceinline__ void store_pair_split(float *base, int64_t p, int ld, int q, int s, const half8 &hi, const half8 &lo, bool valid) {
-    if (!valid) return;
+__device__ __forceinline__ void store_pair_split(float *base, int64_t p, int ld, int q, int s, const half8 &hi, const half8 &lo) {
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     const u4 h = __builtin_bit_cast(u4, hi), l = __builtin_bit_cast(u4, lo);
     float *row = base + (size_t)p * ld + 4 * q;
@@ -210,7 +237,7 @@ __device__ __forceinline__ void store_pair_split(float *base, int64_t p, int ld,
     __builtin_nontemporal_store(t0, (u4 *)(row + 16 * (2 * s)));
     __builtin_nontemporal_store(t1, (u4 *)(row + 16 * (2 * s + 1)));
 }
-__device__ __forceinline__ void store_pair_split(float *, int64_t, int, int, int, const bf16x8 &, const bf16x8 &, bool) {}
+__device__ __forceinline__ void store_pair_split(float *, int64_t, int, int, int, const bf16x8 &, const bf16x8 &) {}
 
 // two C/D tiles (2s, 2s+1) -> the NS-part B fragment of k-step s
 template <int NS, typename FR>

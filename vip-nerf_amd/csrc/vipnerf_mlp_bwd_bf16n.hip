@@ -120,12 +120,12 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
             d[1] = g[1] > 0.f ? dg.y : 0.f;
             d[2] = g[2] > 0.f ? dg.z : 0.f;
             d[3] = g[3] > 0.f ? dg.w : 0.f;
-            store_tile16(a.bwd + a.bl.dyv[dsel], p, WV, q, t, d, valid);
+            store_tile16(a.bwd + a.bl.dyv[dsel], p, WV, q, t, d);
             vsum[t] += d;
         }
     }
 #pragma unroll
-    for (int t = 0; t < 8; ++t) store_tile16(a.bwd + a.bl.dyvsum, p, WV, q, t, vsum[t], valid);
+    for (int t = 0; t < 8; ++t) store_tile16(a.bwd + a.bl.dyvsum, p, WV, q, t, vsum[t]);
 
     // ---------------------------------------------------------------- d(feature) = W_vf^T sum_a dYv_a   (K = 128: 4 k-steps)
     FR bin[8][NS];
@@ -145,12 +145,12 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
     for (int s = 0; s < 8; ++s) {
         const floatx4 x0 = acc[2 * s] * AU, x1 = acc[2 * s + 1] * AU;
         if (!H16) {
-            store_tile16(a.bwd + a.bl.dyf, p, W, q, 2 * s, x0, valid);
-            store_tile16(a.bwd + a.bl.dyf, p, W, q, 2 * s + 1, x1, valid);
+            store_tile16(a.bwd + a.bl.dyf, p, W, q, 2 * s, x0);
+            store_tile16(a.bwd + a.bl.dyf, p, W, q, 2 * s + 1, x1);
         }
         split_pair<NS>(x0, x1, bin[s]);
-        if (H16 == 1) store_pair16h(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0], valid);
-        if (H16 == 2) store_pair_split(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0], bin[s][1], valid);
+        if (H16 == 1) store_pair16h(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0]);
+        if (H16 == 2) store_pair_split(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0], bin[s][1]);
     }
 
     // ---------------------------------------------------------------- feature layer, then layers 7..1
@@ -162,7 +162,8 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
         for (int t = 0; t < 16; ++t) acc[t] = (floatx4)(0.f);
 #pragma unroll
         for (int jj = 0; jj < PL::ST_256; ++jj) {
-            const float *st = ws.wait();
+            // the first stage of a layer follows an epilogue with >= 16 gradient stores (every storage mode)
+            const float *st = jj == 0 ? ws.template wait<16>() : ws.template wait<0>();
             gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
         }
         float *dst = a.bwd + a.bl.dy[layer];
@@ -179,13 +180,13 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[u][r] = mask_apply16(x[u][r], mk.x, mk.y, t, r);
-                if (!H16 || it == 7) store_tile16(dst, p, W, q, t, x[u], valid);
-                if (H16 && layer == SKIP_LAYER) store_tile16(a.bwd + a.bl.dy5f, p, W, q, t, x[u], valid);
+                if (!H16 || it == 7) store_tile16(dst, p, W, q, t, x[u]);
+                if (H16 && layer == SKIP_LAYER) store_tile16(a.bwd + a.bl.dy5f, p, W, q, t, x[u]);
             }
             if (it < 7) {
                 split_pair<NS>(x[0], x[1], bin[s]);
-                if (H16 == 1) store_pair16h(dst, p, W, q, s, bin[s][0], valid);
-                if (H16 == 2) store_pair_split(dst, p, W, q, s, bin[s][0], bin[s][1], valid);
+                if (H16 == 1) store_pair16h(dst, p, W, q, s, bin[s][0]);
+                if (H16 == 2) store_pair_split(dst, p, W, q, s, bin[s][0], bin[s][1]);
             }
         }
     }

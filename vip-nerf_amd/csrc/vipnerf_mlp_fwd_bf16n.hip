@@ -78,8 +78,8 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
     typedef BnPlan<NS> PL;
     typedef typename FragOf<F16>::type FR;
     constexpr float XS = F16 ? F16_XSCALE : 1.f;           // B operands are split as XS * x
-    constexpr float AS = F16 ? F16_ACC_SCALE : 1.f;        // accumulators hold AS * (pre-activation)
     constexpr float AU = F16 ? F16_ACC_UNSCALE : 1.f;
+    constexpr int EPI_STORES = SAVE ? 16 : 0;              // vector-memory instructions every wave issues per layer epilogue (lower bound)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *res = lds;
     float *stage_buf = lds + PL::R_TOTAL_PAD;
@@ -126,13 +126,14 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const float4 b4 = *(const float4 *)(bias + 16 * t);
-            acc[t][0] = b4.x * AS; acc[t][1] = b4.y * AS; acc[t][2] = b4.z * AS; acc[t][3] = b4.w * AS;
+            acc[t][0] = b4.x; acc[t][1] = b4.y; acc[t][2] = b4.z; acc[t][3] = b4.w;     // packed as AS * bias
         }
 
         if (layer != 0) {
 #pragma unroll
             for (int jj = 0; jj < PL::ST_256; ++jj) {
-                const float *st = ws.wait();
+                // the first stage of a layer follows the previous layer's epilogue: >= 16 tile stores when saving
+                const float *st = jj == 0 ? ws.template wait<EPI_STORES>() : ws.template wait<0>();
                 gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
             }
         }
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
         // epilogue: ReLU (trunk), activation store, mask, sigma head, split into the next layer's B fragments.
         // Kept free of per-tile branches on `layer`: ReLU is a max with a per-layer bound (0, or -inf for the feature
         // layer), the sigma head is one block for layer 7.
-        const float lo = layer < 8 ? 0.f : -INFINITY;
+        const float lo = relu_bound<F16>(layer < 8);
         if (layer == 7) {
             float sg[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -174,19 +175,23 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[u][r] = relu_lo<F16>(x[u][r] * AU, lo);
                 if (SAVE) {
-                    if (!(H16 && layer < 8)) store_tile16(dst, p, W, q, t, x[u], valid);
-                    unsigned m = 0;
+                    if (!(H16 && layer < 8)) store_tile16(dst, p, W, q, t, x[u]);
+                    if (F16) {
+                        if (t < 8) mk0 = push_nibble(mk0, positive_nibble(x[u])); else mk1 = push_nibble(mk1, positive_nibble(x[u]));
+                    } else {
+                        unsigned m = 0;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) m |= (x[u][r] > 0.f ? 1u : 0u) << r;
-                    if (t < 8) mk0 |= m << (4 * t); else mk1 |= m << (4 * (t - 8));
+                        for (int r = 0; r < 4; ++r) m |= (x[u][r] > 0.f ? 1u : 0u) << r;
+                        if (t < 8) mk0 |= m << (4 * t); else mk1 |= m << (4 * (t - 8));
+                    }
                 }
             }
             if (F16) { x[0] *= XS; x[1] *= XS; }
             split_pair<NS>(x[0], x[1], bin[s]);
-            if (SAVE && H16 == 1 && layer < 8) store_pair16h(dst, p, W, q, s, bin[s][0], valid);
-            if (SAVE && H16 == 2 && layer < 8) store_pair_split(dst, p, W, q, s, bin[s][0], bin[s][1], valid);
+            if (SAVE && H16 == 1 && layer < 8) store_pair16h(dst, p, W, q, s, bin[s][0]);
+            if (SAVE && H16 == 2 && layer < 8) store_pair_split(dst, p, W, q, s, bin[s][0], bin[s][1]);
         }
-        if (SAVE && valid && layer < 8) *(uint2 *)(a.acts + a.al.hm[layer] + ((size_t)p * 4 + q) * 2) = make_uint2(mk0, mk1);
+        if (SAVE && layer < 8) *(uint2 *)(a.acts + a.al.hm[layer] + ((size_t)p * 4 + q) * 2) = make_uint2(mk0, mk1);
     }
 
     {
@@ -204,11 +209,11 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const float4 b4 = *(const float4 *)(rf + PL::N_BVIEW + 16 * t + 4 * q);
-        vb[t][0] = b4.x * AS; vb[t][1] = b4.y * AS; vb[t][2] = b4.z * AS; vb[t][3] = b4.w * AS;
+        vb[t][0] = b4.x; vb[t][1] = b4.y; vb[t][2] = b4.z; vb[t][3] = b4.w;                 // packed as AS * bias
     }
 #pragma unroll
     for (int jj = 0; jj < PL::ST_VIEW_F; ++jj) {
-        const float *st = ws.wait();
+        const float *st = jj == 0 ? ws.template wait<EPI_STORES>() : ws.template wait<0>();   // behind the feature layer's epilogue
         gemm_stage_bf<8, PL::KSV, NS>(st, lane, vb, bin, PL::KSV * jj, ws);
     }
     stream_end(ws);
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             for (int r = 0; r < 4; ++r) g[t][r] = relu_lo<F16>(g[t][r] * AU, 0.f);
         if (SAVE) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) store_tile16(a.acts + a.al.g[dsel], p, WV, q, t, g[t], valid);
+            for (int t = 0; t < 8; ++t) store_tile16(a.acts + a.al.g[dsel], p, WV, q, t, g[t]);
             if (valid) store_d16(a.acts + a.al.ped[dsel] + (size_t)p * DVE_PAD, q, ped);
         }
         float qv[4];

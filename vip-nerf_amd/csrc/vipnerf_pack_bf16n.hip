@@ -110,6 +110,7 @@ __global__ void k_pack_bf16n(PackBnArgs a) {
                 const int rem = f - PL::N_BHEAD;
                 v = rem == 0 ? a.p.p[P_SB][0] : (rem <= 4 ? a.p.p[P_OB][rem - 1] : 0.f);
             }
+            if (F16 && f < PL::N_WSIG) v *= F16_ACC_SCALE;                         // layer biases enter the accumulators scaled
             cell = __float_as_uint(v);
         }
     }

@@ -181,9 +181,9 @@ struct WStreamT {
     // YOUNGER: a lower bound on the vector-memory instructions (the activation stores of a layer's epilogue) the
     // issuing wave has executed since it issued this stage's DMA.  VM_CNT retires in issue order, loads and stores
     // alike, so vmcnt(YOUNGER) proves the DMA has landed without waiting for those stores to reach memory.
-    template <int YOUNGER = 0>
-    __device__ __forceinline__ const float *wait() {
-        static_assert(YOUNGER >= 0 && YOUNGER <= 63, "vmcnt is a 6-bit counter");
+    template <int YOUNGER = 0, int YOUNGER_FIRST = YOUNGER>
+    __device__ __forceinline__ const float *wait(bool first = false) {     // `first`: use YOUNGER_FIRST (a call site shared by loop iterations)
+        static_assert(YOUNGER >= 0 && YOUNGER <= 63 && YOUNGER_FIRST >= 0 && YOUNGER_FIRST <= 63, "vmcnt is a 6-bit counter");
         if (NBUF == 2 && ROTATE) {
             // only the wave that issued this stage's DMA has to see it land -- and not its own younger stores: a
             // vmcnt(0) in every wave (what __syncthreads() also implies: its fence waits for the wave's outstanding
@@ -192,7 +192,10 @@ struct WStreamT {
             // The data goes global -> LDS by DMA and LDS -> registers by ds_read: no cache to fence, a bare barrier
             // after the issuer's drain publishes it.
             __builtin_amdgcn_sched_barrier(0);
-            if (wave == cturn) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+            if (wave == cturn) {
+                if (YOUNGER_FIRST != YOUNGER && first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER_FIRST) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+            }
             cturn = cturn + 1 == WAVES ? 0 : cturn + 1;
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");

@@ -146,8 +146,8 @@ struct WStreamSkew {
     }
     __device__ __forceinline__ void begin() { if (lag) tick(); }
     __device__ __forceinline__ void end() { if (!lag) tick(); }
-    template <int YOUNGER = 0>
-    __device__ __forceinline__ const float *wait() {
+    template <int YOUNGER = 0, int YOUNGER_FIRST = YOUNGER>
+    __device__ __forceinline__ const float *wait(bool = false) {
         tick();
         const float *ret = buf + slot * SF;
         slot = slot == 2 ? 0 : slot + 1;
@@ -214,7 +214,13 @@ __device__ __forceinline__ floatx4 load_tile16(const float *base, int64_t p, int
 // one 32-point block ahead and there are no registers for two).  Within noise; kept off so that the stored activations
 // stay plain fp32.  (A first version with two separate [P][256]-half planes was clearly slower: 8-byte stores / loads.)
 #ifndef VN_F16_PRESPLIT
-#define VN_F16_PRESPLIT 0
+#define VN_F16_PRESPLIT 1
+#endif
+// When the stored form of a layer's output IS the next GEMM's B operand (the fp16 parts: FP16X3H, VN_F16_PRESPLIT), the
+// stores need not leave in a burst at the layer's epilogue: the operand registers stay live through the whole next layer,
+// so each of its weight stages sends a quarter of them -- in the shadow of the other wave's MFMAs.
+#ifndef VN_DEFER_STORES
+#define VN_DEFER_STORES 1
 #endif
 // FP16X3H: the fp16 high parts of a B fragment (k-step s <- tiles 2s, 2s+1) ARE the fp16 image of those two tiles:
 // elements 4u .. 4u+3 of part 0 are features 16 (2s+u) + 4q .. +3.  Stored as [P][ld] halves (8 bytes per lane, tile).

@@ -52,6 +52,8 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
     typedef BnPlan<NS> PL;
     typedef typename FragOf<F16>::type FR;
     constexpr float AU = F16 ? 1.f / F16_WSCALE : 1.f;
+    constexpr bool DEFER = H16 != 0 && VN_DEFER_STORES;    // fp16-stored gradients leave from the next GEMM's stages (vipnerf_bf16n.h)
+    constexpr int S_PER_STAGE = 8 / PL::ST_256;
     const float gs = (F16 && a.gmax) ? grad_scale_from_max(*a.gmax) : 1.f;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *res = lds;
@@ -149,8 +151,8 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
             store_tile16(a.bwd + a.bl.dyf, p, W, q, 2 * s + 1, x1);
         }
         split_pair<NS>(x0, x1, bin[s]);
-        if (H16 == 1) store_pair16h(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0]);
-        if (H16 == 2) store_pair_split(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0], bin[s][1]);
+        if (!DEFER && H16 == 1) store_pair16h(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0]);
+        if (!DEFER && H16 == 2) store_pair_split(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0], bin[s][1]);
     }
 
     // ---------------------------------------------------------------- feature layer, then layers 7..1
@@ -162,9 +164,20 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
         for (int t = 0; t < 16; ++t) acc[t] = (floatx4)(0.f);
 #pragma unroll
         for (int jj = 0; jj < PL::ST_256; ++jj) {
-            // the first stage of a layer follows an epilogue with >= 16 gradient stores (every storage mode)
-            const float *st = jj == 0 ? ws.template wait<16>() : ws.template wait<0>();
+            // younger than the stage's DMA -- first stage of a layer: the epilogue before it (>= 16 gradient tile stores;
+            // with deferred stores only those behind the previous GEMM's last stage, and nothing before the first layer);
+            // later stages: the deferred stores behind the stage before
+            const float *st = jj == 0 ? ws.template wait<DEFER ? 2 * S_PER_STAGE : 16, DEFER ? 0 : 16>(it == 0)
+                                      : ws.template wait<DEFER ? 2 * S_PER_STAGE : 0>();
             gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
+            if (DEFER) {                                 // bin = the fp16 parts of the gradient this GEMM consumes
+                float *prev = a.bwd + (it == 0 ? a.bl.dyf : a.bl.dy[layer + 1]);
+#pragma unroll
+                for (int s = S_PER_STAGE * jj; s < S_PER_STAGE * (jj + 1); ++s) {
+                    if (H16 == 1) store_pair16h(prev, p, W, q, s, bin[s][0]);
+                    if (H16 == 2) store_pair_split(prev, p, W, q, s, bin[s][0], bin[s][1]);
+                }
+            }
         }
         float *dst = a.bwd + a.bl.dy[layer];
 #pragma unroll
@@ -185,8 +198,8 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
             }
             if (it < 7) {
                 split_pair<NS>(x[0], x[1], bin[s]);
-                if (H16 == 1) store_pair16h(dst, p, W, q, s, bin[s][0]);
-                if (H16 == 2) store_pair_split(dst, p, W, q, s, bin[s][0], bin[s][1]);
+                if (!DEFER && H16 == 1) store_pair16h(dst, p, W, q, s, bin[s][0]);
+                if (!DEFER && H16 == 2) store_pair_split(dst, p, W, q, s, bin[s][0], bin[s][1]);
             }
         }
     }

@@ -79,7 +79,9 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
     typedef typename FragOf<F16>::type FR;
     constexpr float XS = F16 ? F16_XSCALE : 1.f;           // B operands are split as XS * x
     constexpr float AU = F16 ? F16_ACC_UNSCALE : 1.f;
+    constexpr bool DEFER = SAVE && H16 != 0 && VN_DEFER_STORES;   // h_1..h_8 leave from the next layer's stages (vipnerf_bf16n.h)
     constexpr int EPI_STORES = SAVE ? 16 : 0;              // vector-memory instructions every wave issues per layer epilogue (lower bound)
+    constexpr int S_PER_STAGE = 8 / PL::ST_256;            // operand k-steps a stage's deferred stores cover (2 stores each)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *res = lds;
     float *stage_buf = lds + PL::R_TOTAL_PAD;
@@ -132,9 +134,18 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
         if (layer != 0) {
 #pragma unroll
             for (int jj = 0; jj < PL::ST_256; ++jj) {
-                // the first stage of a layer follows the previous layer's epilogue: >= 16 tile stores when saving
-                const float *st = jj == 0 ? ws.template wait<EPI_STORES>() : ws.template wait<0>();
+                // younger than the stage's DMA -- first stage: the previous layer's epilogue (>= 16 tile stores, or just
+                // the mask store when the tiles are deferred); later stages: the deferred stores behind the stage before
+                const float *st = jj == 0 ? ws.template wait<DEFER ? 1 : EPI_STORES>() : ws.template wait<DEFER ? 2 * S_PER_STAGE : 0>();
                 gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
+                if (DEFER) {                             // bin = the fp16 parts of h_layer, the output of layer - 1
+                    float *prev = a.acts + a.al.h[layer - 1];
+#pragma unroll
+                    for (int s = S_PER_STAGE * jj; s < S_PER_STAGE * (jj + 1); ++s) {
+                        if (H16 == 1) store_pair16h(prev, p, W, q, s, bin[s][0]);
+                        if (H16 == 2) store_pair_split(prev, p, W, q, s, bin[s][0], bin[s][1]);
+                    }
+                }
             }
         }
         if (layer == 0 || layer == SKIP_LAYER) {         // gamma(x) columns last: bin is dead, its registers hold bpe
@@ -188,8 +199,8 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             }
             if (F16) { x[0] *= XS; x[1] *= XS; }
             split_pair<NS>(x[0], x[1], bin[s]);
-            if (SAVE && H16 == 1 && layer < 8) store_pair16h(dst, p, W, q, s, bin[s][0]);
-            if (SAVE && H16 == 2 && layer < 8) store_pair_split(dst, p, W, q, s, bin[s][0], bin[s][1]);
+            if (SAVE && !DEFER && H16 == 1 && layer < 8) store_pair16h(dst, p, W, q, s, bin[s][0]);
+            if (SAVE && !DEFER && H16 == 2 && layer < 8) store_pair_split(dst, p, W, q, s, bin[s][0], bin[s][1]);
         }
         if (SAVE && layer < 8) *(uint2 *)(a.acts + a.al.hm[layer] + ((size_t)p * 4 + q) * 2) = make_uint2(mk0, mk1);
     }

@@ -9,6 +9,7 @@
 // 32x32 tiles = 256 registers per wave), streams 32-point tiles of A and B through double-buffered LDS, and
 // writes its partial product; an ordered second pass sums the chunks (deterministic; no atomics) straight into
 // the nn.Linear-layout gradient tensors.
+#include <type_traits>
 #include "vipnerf_wgrad.h"
 #include "vipnerf_bf16n.h"
 #include "vipnerf_prof.h"
@@ -818,10 +819,246 @@ __device__ __forceinline__ void wgrad_split16_256_body(const WgArgs &a) {
         if (tid == 0) part[(size_t)Mp * Kp + Mp + 256] = (red[1024] + red[1025]) + (red[1026] + red[1027]);
     }
 }
+// The pre-split GEMM with the staging of block n+1 and the reloads for block n+2 issued in the shadow of block n's MFMAs.
+// With one wave per SIMD (256 accumulators) nothing else can fill that time, and measured piece by piece (this kernel's
+// fp32-input sibling on the same box: MFMAs alone 1.67 ms per step, + fragment reads 1.96, + staging 2.90, loads + MFMAs
+// without staging 2.95, everything 3.7-3.9) the staging VALU does not hide for free: a wave issues one instruction per
+// 4 cycles, a 32x32x16 MFMA leaves ~6 slots, and conversions (v_cvt_pk_*: 8 cycles) use two (tools/
+// mfma_valu_coissue.hip).  Hence: operands that arrive already split (a v_perm gather, no conversion), bias sums on
+// v_dot2_f32_f16 (one instruction adds one stored half to an fp32 sum), and an explicit schedule:
+//   * fragment order j-outer / i-inner: a B fragment pair lives for six MFMAs, so four pairs (32 registers) are in
+//     flight instead of all eight of a k-step (64); the A fragments of both k-steps stay resident (32)
+//   * eight super-steps of two (k-step, j) cells = 12 MFMAs; super-step u carries staging piece u (operand, component
+//     c: the 8 points of one feature per lane -> two 16-byte LDS stores) and the fragment reads of super-step u + 1;
+//     an operand's 8 row registers are reloaded (block n+2) right after its fourth piece -- no second register set
+//   * the main loop is branch-free (full blocks only, reload index clamped); the last full block and a ragged tail run
+//     without staging
+template <bool HAS_W>
+__device__ __forceinline__ void wgrad_split16_256_pipe(const WgArgs &a) {
+    constexpr int Mp = 256, Kp = 256;
+    constexpr int PLANE = 256 * 64;
+    constexpr int BUF = 4 * PLANE;                        // A hi, A lo, B hi, B lo
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char *lb = (char *)lds;
+    typedef _Float16 half8_ __attribute__((ext_vector_type(8)));
+    typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+
+    const WgDesc &d = a.d[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int64_t p0 = (int64_t)blockIdx.x * a.chunk_pts;
+    const int64_t p1 = p0 + a.chunk_pts < a.P ? p0 + a.chunk_pts : a.P;
+    const int nfull = (int)((p1 - p0) / 32);
+    const bool tail = ((p1 - p0) & 31) != 0;
+
+    floatx16 acc[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (floatx16)(0.f);
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    float ws[4] = {0.f, 0.f, 0.f, 0.f}, wsum = 0.f;
+    float wv[8];
+    uint4 ua[8], ub[8];                                   // rows wave + 4 i, features 4 lane .. + 3: [hi01][hi23][lo01][lo23]
+
+    // fragment read offsets (wg_off<256>(32 tt + l31, 2 ks + h)): e0 ^ (((ks ^ tt) & 1) << 5), + 512 tt
+    const int e0 = ((l31 & 3) * 64 + (l31 >> 2)) * 64 + (((h ^ (l31 & 3) ^ (l31 >> 4)) & 3) << 4);
+    // staging store offset of feature 4 lane + c, slot wave: (w0 ^ (c << 4)) + 4096 c
+    const int w0 = lane * 64 + (((wave ^ (lane >> 2)) & 3) << 4);
+
+    auto load_a = [&](int blk) {                          // full blocks only
+        const uint4 *ta = (const uint4 *)(d.A + (size_t)(p0 + (int64_t)blk * 32) * Mp) + tid;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ua[i] = ta[256 * i];
+    };
+    auto load_b = [&](int blk) {
+        const int64_t pb = p0 + (int64_t)blk * 32;
+        const uint4 *tb = (const uint4 *)(d.B + (size_t)pb * Kp) + tid;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ub[i] = tb[256 * i];
+        if (HAS_W) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wv[i] = d.wcol[(size_t)(pb + wave + 4 * i) * d.wcol_stride];
+        }
+    };
+    auto load_tail = [&](int blk) {                       // ragged last block: rows beyond p1 read as zero
+        const int64_t pb = p0 + (int64_t)blk * 32;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t row = pb + wave + 4 * i;
+            const bool ok = row < p1;
+            ua[i] = ok ? *((const uint4 *)(d.A + (size_t)row * Mp) + lane) : make_uint4(0u, 0u, 0u, 0u);
+            ub[i] = ok ? *((const uint4 *)(d.B + (size_t)row * Kp) + lane) : make_uint4(0u, 0u, 0u, 0u);
+            if (HAS_W) wv[i] = ok ? d.wcol[(size_t)row * d.wcol_stride] : 0.f;
+        }
+    };
+    auto word_of = [](const uint4 &u, int c, int part) -> unsigned {   // the dword holding feature c of part (0 hi, 1 lo)
+        return part == 0 ? (c < 2 ? u.x : u.y) : (c < 2 ? u.z : u.w);
+    };
+    // staging piece u of the block in the registers: u < 4: operand A, component u; else operand B, component u - 4
+    auto piece = [&](char *base, int u) {
+        const int c = u & 3;
+        const uint4 (&r)[8] = u < 4 ? ua : ub;
+        char *q = base + (u < 4 ? 0 : 2 * PLANE) + ((w0 ^ (c << 4)) + 4096 * c);
+        const unsigned sel = (c & 1) ? 0x07060302u : 0x05040100u;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            uint4 o;
+            o.x = __builtin_amdgcn_perm(word_of(r[1], c, part), word_of(r[0], c, part), sel);
+            o.y = __builtin_amdgcn_perm(word_of(r[3], c, part), word_of(r[2], c, part), sel);
+            o.z = __builtin_amdgcn_perm(word_of(r[5], c, part), word_of(r[4], c, part), sel);
+            o.w = __builtin_amdgcn_perm(word_of(r[7], c, part), word_of(r[6], c, part), sel);
+            *(uint4 *)(q + part * PLANE) = o;
+        }
+        const half2_ one = (c & 1) ? half2_{(_Float16)0.f, (_Float16)1.f} : half2_{(_Float16)1.f, (_Float16)0.f};
+        if (u < 4) {                                      // bias sums: one v_dot2_f32_f16 per stored half
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                bs[c] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_, word_of(r[i], c, 0)), one, bs[c], false);
+                bs[c] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_, word_of(r[i], c, 1)), one, bs[c], false);
+            }
+        } else if (HAS_W) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_, word_of(r[i], c, 0)), one, 0.f, false);
+                v = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_, word_of(r[i], c, 1)), one, v, false);
+                ws[c] = fmaf(wv[i], v, ws[c]);
+            }
+            if (c == 3) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wsum += wv[i];
+            }
+        }
+    };
+    auto read_a = [&](const char *base, int ks, half8_ (&af)[2][2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const char *q = base + ((e0 ^ (((ks ^ i) & 1) << 5)) + 512 * (2 * wave + i));
+            af[i][0] = *(const half8_ *)q;
+            af[i][1] = *(const half8_ *)(q + PLANE);
+        }
+    };
+    auto read_b = [&](const char *base, int ks, int j, half8_ (&bq)[2]) {
+        const char *q = base + 2 * PLANE + ((e0 ^ (((ks ^ j) & 1) << 5)) + 512 * j);
+        bq[0] = *(const half8_ *)q;
+        bq[1] = *(const half8_ *)(q + PLANE);
+    };
+    auto mfma6 = [&](const half8_ (&af)[2][2], const half8_ (&bq)[2], int j) {   // per accumulator: lo*hi, hi*lo, hi*hi
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][1], bq[0], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][1], bq[0], acc[1][j], 0, 0, 0);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bq[1], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][0], bq[1], acc[1][j], 0, 0, 0);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bq[0], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][0], bq[0], acc[1][j], 0, 0, 0);
+    };
+    // the MFMAs of the block in `base`; STAGE: stage the block in the registers into `nbase`, reloading them for block `nb`
+    auto block = [&](const char *base, auto stage_tag, char *nbase, int nb) {
+        constexpr bool STAGE = decltype(stage_tag)::value;
+        half8_ af[2][2][2], bq[4][2];
+        read_a(base, 0, af[0]);
+        read_b(base, 0, 0, bq[0]);
+        read_b(base, 0, 1, bq[1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t0 = 2 * u, t1 = 2 * u + 1;
+            int nread = 0;
+            if (u < 7) {
+                read_b(base, (t0 + 2) >> 3, (t0 + 2) & 7, bq[(t0 + 2) & 3]);
+                read_b(base, (t1 + 2) >> 3, (t1 + 2) & 7, bq[(t1 + 2) & 3]);
+                nread += 4;
+            }
+            if (u == 2) { read_a(base, 1, af[1]); nread += 4; }
+            mfma6(af[t0 >> 3], bq[t0 & 3], t0 & 7);
+            mfma6(af[t1 >> 3], bq[t1 & 3], t1 & 7);
+            if (STAGE) {
+                piece(nbase, u);
+                if (u == 4) load_a(nb);
+                if (u == 7) load_b(nb);
+            }
+            // MFMA, then what may issue in its shadow: a fragment read, a reload, staging VALU, a staging store
+#pragma unroll
+            for (int m = 0; m < 12; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                if (m < nread) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (STAGE) {
+                    if (u == 4 && m < 4) __builtin_amdgcn_sched_group_barrier(0x20, 2, 0);     // A reload first: its registers are free
+                    __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
+                    if (m >= 10) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    if (u == 7 && m >= 10) __builtin_amdgcn_sched_group_barrier(0x20, HAS_W ? 8 : 4, 0);   // B reload behind its last piece
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    int cur = 0;
+    if (nfull > 0) {
+        load_a(0);
+        load_b(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) piece(lb, u);
+        if (nfull > 1) { load_a(1); load_b(1); }
+    }
+    __syncthreads();
+    for (int blk = 0; blk + 1 < nfull; ++blk) {
+        const int nb = blk + 2 < nfull ? blk + 2 : nfull - 1;
+        block(lb + cur * BUF, std::true_type(), lb + (cur ^ 1) * BUF, nb);
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (tail) load_tail(nfull);
+    if (nfull > 0) {
+        block(lb + cur * BUF, std::false_type(), nullptr, 0);
+        cur ^= 1;
+    }
+    if (tail) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) piece(lb + cur * BUF, u);
+        __syncthreads();
+        block(lb + cur * BUF, std::false_type(), nullptr, 0);
+    }
+    __syncthreads();                                      // fragment reads done before the LDS is reused below
+
+    float *part = a.partial + d.part_off + (size_t)blockIdx.x * d.part_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ot = wave * 2 + i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * h;
+                part[(size_t)o * Kp + 32 * j + l31] = acc[i][j][r];
+            }
+    }
+    float *red = (float *)lb;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[wave * 256 + 4 * lane + c] = bs[c];
+    __syncthreads();
+    part[(size_t)Mp * Kp + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+    if (HAS_W) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[wave * 256 + 4 * lane + c] = ws[c];
+        if (lane == 0) red[1024 + wave] = wsum;
+        __syncthreads();
+        part[(size_t)Mp * Kp + Mp + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+        if (tid == 0) part[(size_t)Mp * Kp + Mp + 256] = (red[1024] + red[1025]) + (red[1026] + red[1027]);
+    }
+}
+#ifndef VN_WGRAD_PIPE
+#define VN_WGRAD_PIPE 1
+#endif
 __global__ __launch_bounds__(256) void k_wgrad_split16_256(WgArgs a) {
     if ((int)blockIdx.x >= a.d[blockIdx.y].n_chunks) return;
+#if VN_WGRAD_PIPE
+    if (a.d[blockIdx.y].wcol) wgrad_split16_256_pipe<true>(a);
+    else wgrad_split16_256_pipe<false>(a);
+#else
     if (a.d[blockIdx.y].wcol) wgrad_split16_256_body<true>(a);
     else wgrad_split16_256_body<false>(a);
+#endif
 }
 
 template <int PARTS>

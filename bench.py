@@ -187,7 +187,8 @@ def main():
     achieved = flop_per_launch / (stage_ms[dom] * 1e-3) / 1e12 if stage_ms[dom] > 0 else 0.0
     peak, peak_note = PEAK[args.precision]
     if dom == 'wgrad':
-        # the weight-gradient GEMMs stream both fp32 operands from HBM once per GEMM and are bound by that, not by MFMA
+        # the weight-gradient GEMMs stream both operands (4 bytes per element: fp32, or fp16 hi/lo pairs) from HBM once per GEMM
+        # and are bound by that, not by MFMA
         bytes_per_step = WGRAD_BYTES_PER_POINT * POINTS_PER_RAY * args.rays
         gbs = bytes_per_step / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

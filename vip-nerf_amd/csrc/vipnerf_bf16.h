@@ -137,7 +137,9 @@ __device__ __forceinline__ ACC mfma_split(const FR (&a)[NS], const FR (&b)[NS], 
 // The texture path takes a 1 KiB piece every ~16 cycles whoever issues it; when every wave issues its share at the
 // same time each of them is stuck ~60 cycles per piece and no MFMA issues meanwhile, whereas a single issuing wave
 // leaves the other seven (including its SIMD partner) computing.
-template <int CH, int NBUF, int WAVES = 4, bool ROTATE = false>
+// STAGGER (narrow layout, -DVN_DMA_MODE=2): every wave issues its 1/WAVES share, wave w behind MFMA group w * NG / WAVES of the
+// stage instead of all of them behind group 0 -- no single wave is ~60 cycles x CH behind the others at the stage barrier.
+template <int CH, int NBUF, int WAVES = 4, bool ROTATE = false, bool STAGGER = false>
 struct WStreamT {
     const float *g;
     float *buf;
@@ -184,7 +186,15 @@ struct WStreamT {
     template <int YOUNGER = 0, int YOUNGER_FIRST = YOUNGER>
     __device__ __forceinline__ const float *wait(bool first = false) {     // `first`: use YOUNGER_FIRST (a call site shared by loop iterations)
         static_assert(YOUNGER >= 0 && YOUNGER <= 63 && YOUNGER_FIRST >= 0 && YOUNGER_FIRST <= 63, "vmcnt is a 6-bit counter");
-        if (NBUF == 2 && ROTATE) {
+        if (NBUF == 2 && STAGGER) {
+            // every wave drains its own share (counted: its younger stores stay in flight), bare barrier
+            __builtin_amdgcn_sched_barrier(0);
+            if (YOUNGER_FIRST != YOUNGER && first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER_FIRST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        } else if (NBUF == 2 && ROTATE) {
             // only the wave that issued this stage's DMA has to see it land -- and not its own younger stores: a
             // vmcnt(0) in every wave (what __syncthreads() also implies: its fence waits for the wave's outstanding
             // global stores and loads) made all of them sit out the HBM latency of their activation stores / mask
@@ -217,6 +227,15 @@ struct WStreamT {
     }
     __device__ __forceinline__ void prefetch() {
         if (n_left > 0) fetch();
+    }
+    // called behind every MFMA group g of NG of a stage (compile-time g): where this stream issues the next stage's DMA
+    template <int g, int NG>
+    __device__ __forceinline__ void prefetch_at() {
+        if (STAGGER) {
+            static_assert(!STAGGER || NG % WAVES == 0, "groups per stage must be a multiple of the waves");
+            constexpr int EVERY = STAGGER ? NG / WAVES : 1;
+            if (g % EVERY == 0 && wave == g / EVERY) prefetch();
+        } else if (g == 0) prefetch();
     }
     __device__ __forceinline__ const float *next() {
         const float *ret = wait();
@@ -258,7 +277,7 @@ __device__ __forceinline__ void gemm_groups_bf(const float *base, ACC (&acc)[NT]
         // the next stage's DMA goes out as ONE burst behind the first group: a global_load_lds costs its wave ~60
         // cycles of issue time; spread over the groups (one piece per group) the same 16 pieces measured 6-10 %
         // SLOWER than the burst, and before/after the first reads makes no difference
-        if (g == 0) ws.prefetch();
+        ws.template prefetch_at<g, NG>();
         __builtin_amdgcn_sched_barrier(0);
         gemm_groups_bf<g + 1, NG, NT, NS, G, D, NBUF>(base, acc, B, ks0, fr, ws);
     }
@@ -273,6 +292,7 @@ __device__ __forceinline__ void gemm_groups_bf(const float *base, ACC (&acc)[NT]
 //   acc[t] += A(ks, t) * B[ks0 + ks],  chunk index (ks * NT + t) * NS + part
 struct NoStream {
     __device__ __forceinline__ void prefetch() {}
+    template <int g, int NG> __device__ __forceinline__ void prefetch_at() {}
 };
 template <int NT, int NKS, int NS, int NB, typename WS, typename ACC, typename FR>
 __device__ __forceinline__ void gemm_stage_bf(const float *stage, int lane, ACC (&acc)[NT],

@@ -154,8 +154,12 @@ struct WStreamSkew {
         return ret;
     }
     __device__ __forceinline__ void prefetch() {}
+    template <int g, int NG> __device__ __forceinline__ void prefetch_at() {}
 };
-template <typename PL, bool SK> struct StreamOf { typedef WStreamT<PL::CH, PL::NBUF, PL::WAVES, true> type; };
+#ifndef VN_DMA_MODE
+#define VN_DMA_MODE 1      // 1: one wave issues a whole stage (ROTATE); 2: every wave its share, staggered over the stage
+#endif
+template <typename PL, bool SK> struct StreamOf { typedef WStreamT<PL::CH, PL::NBUF, PL::WAVES, VN_DMA_MODE == 1, VN_DMA_MODE == 2> type; };
 template <typename PL> struct StreamOf<PL, true> { typedef WStreamSkew<PL::CH> type; };
 __device__ __forceinline__ void stream_begin(...) {}
 __device__ __forceinline__ void stream_end(...) {}

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
 // LDS plane layout: [feature][4 slots of 8 points], slot XOR-swizzled by (feature >> 2) & 3 so that the 16-lane
 // groups of ds_read_b128 hit 16 distinct slots.  Point q of a 32-point block sits in slot q & 3, element q >> 2:
 // a fixed permutation of the contraction index, identical for A and B.
-template <int MT, int KT>
+template <int MT, int KT, int NSET>
 __global__ __launch_bounds__(256) void k_wgrad_bf16x3(WgArgs a) {
     constexpr int MTW = MT / 4, Mp = 32 * MT, Kp = 32 * KT;
     constexpr int PA = Mp * 64, PB = Kp * 64;             // bytes of one plane (one part) of A / B
@@ -215,28 +215,33 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16x3(WgArgs a) {
     // task of this thread for A / B: feature group c (features 4c..4c+3) and slot sl (points sl + 4e, e = 0..7)
     const bool hasA = tid < TA, hasB = tid < TB;
     const int cA = tid % (Mp / 4), slA = tid / (Mp / 4), cB = tid % (Kp / 4), slB = tid / (Kp / 4);
-    float4 ra[8], rb[8];
+    // NSET register sets: block b is loaded into set b % NSET, and the set is re-armed (block b + NSET) as soon as it has
+    // been staged, so a workgroup keeps NSET 32-point blocks in flight.  These GEMMs have few MFMAs per byte: what bounds
+    // them is how much they have outstanding against the HBM latency -- from a second set where the accumulators leave
+    // room for it without costing a co-resident workgroup (128x256: 253 vs 276 us per launch; 256x64, which runs two
+    // workgroups per CU on 160 registers, loses with 268: 369 vs 351 us).
+    float4 ra[NSET][8], rb[NSET][8];
     const bool fullA = d.m_load == Mp, fullB = d.k_load == Kp;
-    auto gload = [&](int blk) {
+    auto gload = [&](float4 (&qa)[8], float4 (&qb)[8], int blk) {
         const int64_t pb = p0 + (int64_t)blk * 32;
         if (pb + 32 <= p1 && fullA && fullB) {             // whole block in range, all columns valid: no predication
             if (hasA) {
                 const float4 *ta = (const float4 *)(d.A + (size_t)(pb + slA) * d.lda) + cA;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) ra[e] = ta[(size_t)e * d.lda];          // rows slA + 4e: 4*lda floats = lda float4
+                for (int e = 0; e < 8; ++e) qa[e] = ta[(size_t)e * d.lda];          // rows slA + 4e: 4*lda floats = lda float4
             }
             if (hasB) {
                 const float4 *tb = (const float4 *)(d.B + (size_t)(pb + slB) * d.ldb) + cB;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) rb[e] = tb[(size_t)e * d.ldb];
+                for (int e = 0; e < 8; ++e) qb[e] = tb[(size_t)e * d.ldb];
             }
             return;
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int64_t rA = pb + slA + 4 * e, rB = pb + slB + 4 * e;
-            ra[e] = (hasA && rA < p1 && 4 * cA < d.m_load) ? *((const float4 *)(d.A + (size_t)rA * d.lda) + cA) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[e] = (hasB && rB < p1 && 4 * cB < d.k_load) ? *((const float4 *)(d.B + (size_t)rB * d.ldb) + cB) : make_float4(0.f, 0.f, 0.f, 0.f);
+            qa[e] = (hasA && rA < p1 && 4 * cA < d.m_load) ? *((const float4 *)(d.A + (size_t)rA * d.lda) + cA) : make_float4(0.f, 0.f, 0.f, 0.f);
+            qb[e] = (hasB && rB < p1 && 4 * cB < d.k_load) ? *((const float4 *)(d.B + (size_t)rB * d.ldb) + cB) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto put = [&](char *plane, int psize, int f, int sl, const float (&x)[8]) {   // 8 points of feature f -> hi / lo planes
@@ -247,28 +252,24 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16x3(WgArgs a) {
         *(bf16x8 *)(plane + off) = hi;
         *(bf16x8 *)(plane + psize + off) = lo;
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](const float4 (&qa)[8], const float4 (&qb)[8], int buf) {
         char *base = lb + buf * BUF;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float xa[8], xb[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                xa[i] = c == 0 ? ra[i].x : (c == 1 ? ra[i].y : (c == 2 ? ra[i].z : ra[i].w));
-                xb[i] = c == 0 ? rb[i].x : (c == 1 ? rb[i].y : (c == 2 ? rb[i].z : rb[i].w));
+                xa[i] = c == 0 ? qa[i].x : (c == 1 ? qa[i].y : (c == 2 ? qa[i].z : qa[i].w));
+                xb[i] = c == 0 ? qb[i].x : (c == 1 ? qb[i].y : (c == 2 ? qb[i].z : qb[i].w));
                 bs[c] += xa[i];
             }
             if (hasA) put(base, PA, 4 * cA + c, slA, xa);
             if (hasB) put(base + 2 * PA, PB, 4 * cB + c, slB, xb);
         }
     };
-
-    if (nblk > 0) { gload(0); lstore(0); }
-    __syncthreads();
-    int cur = 0;
-    for (int blk = 0; blk < nblk; ++blk) {
-        if (blk + 1 < nblk) gload(blk + 1);
-        const char *base = lb + cur * BUF;
+    // the MFMAs of block blk (LDS buffer blk & 1), then stage block blk + 1 from its register set and re-arm the set
+    auto iter = [&](float4 (&qa)[8], float4 (&qb)[8], int blk) {
+        const char *base = lb + (blk & 1) * BUF;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int slot = 2 * ks + h;
@@ -298,9 +299,25 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16x3(WgArgs a) {
                     acc[i][j] = c;
                 }
         }
-        if (blk + 1 < nblk) lstore(cur ^ 1);
+        if (blk + 1 < nblk) {
+            lstore(qa, qb, (blk + 1) & 1);
+            if (blk + 1 + NSET < nblk) gload(qa, qb, blk + 1 + NSET);
+        }
         __syncthreads();
-        cur ^= 1;
+    };
+
+    if (nblk > 0) {
+#pragma unroll
+        for (int k = 0; k < NSET; ++k)
+            if (k < nblk) gload(ra[k], rb[k], k);
+        lstore(ra[0], rb[0], 0);
+        if (NSET < nblk) gload(ra[0], rb[0], NSET);
+    }
+    __syncthreads();
+    for (int blk = 0; blk < nblk; blk += NSET) {          // iteration b stages block b + 1 from set (b + 1) % NSET
+#pragma unroll
+        for (int k = 0; k < NSET; ++k)
+            if (blk + k < nblk) iter(ra[(k + 1) % NSET], rb[(k + 1) % NSET], blk + k);
     }
 
     float *part = a.partial + d.part_off + (size_t)blockIdx.x * d.part_stride;
@@ -324,12 +341,12 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16x3(WgArgs a) {
     if (tid < Mp) part[(size_t)Mp * Kp + tid] = (red[tid] + red[Mp + tid]) + (red[2 * Mp + tid] + red[3 * Mp + tid]);
 }
 
-template <int MT, int KT>
+template <int MT, int KT, int NSET>
 static int launch_bf16x3(const WgArgs &args, int n_desc, int n_chunks, hipStream_t st) {
     if (n_desc == 0) return VIPNERF_OK;
     const size_t ldsb = (size_t)2 * 2 * (32 * MT + 32 * KT) * 64;
-    VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_bf16x3<MT, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-    hipLaunchKernelGGL((k_wgrad_bf16x3<MT, KT>), dim3(n_chunks, n_desc), dim3(256), ldsb, st, args);
+    VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_bf16x3<MT, KT, NSET>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    hipLaunchKernelGGL((k_wgrad_bf16x3<MT, KT, NSET>), dim3(n_chunks, n_desc), dim3(256), ldsb, st, args);
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;
 }
@@ -1251,8 +1268,8 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
         if ((rc = launch_class<1, 8, 4>(c48, n48, n_single, st))) return rc;
         if ((rc = launch_class<2, 2, 4>(c82, n82, n_small, st))) return rc;
     } else {
-        if ((rc = launch_bf16x3<4, 8>(c48, n48, n_single, st))) return rc;
-        if ((rc = launch_bf16x3<8, 2>(c82, n82, n_small, st))) return rc;
+        if ((rc = launch_bf16x3<4, 8, 2>(c48, n48, n_single, st))) return rc;
+        if ((rc = launch_bf16x3<8, 2, 1>(c82, n82, n_small, st))) return rc;
     }
     if ((rc = launch_class<1, 1, 4>(c41, n41, n_small, st))) return rc;
     if ((rc = launch_class<1, 2, 1>(c18, n18, n_single, st))) return rc;

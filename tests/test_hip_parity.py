@@ -328,6 +328,44 @@ def test_gradients_arrive_in_one_flat_buffer(dev):
     assert torch.equal(flat, ref), 'same kernels, same inputs: the two paths must agree bit for bit'
 
 
+def test_short_rng_array_is_rejected(dev):
+    """Injected random numbers must cover every ray: a short array is an error, not an out-of-bounds read."""
+    b = vo.synthetic_batch(64, 3, scene='fern', nf=2)
+    model, _ = make_model(dev, b['ndc'], vo.init_params(4, scale=1.6))
+    model.train()
+    model.injected_rng = {k: cu(v.numpy(), dev) for k, v in vo.synthetic_rng(32, 64, 128, 5).items()}
+    with pytest.raises(RuntimeError, match='rng'):
+        model(ref_batch(b, dev, 0))
+
+
+def test_fused_total_loss_equals_generic_path(dev):
+    """LossComputerHip's one-dot TotalLoss (all losses fused) against its generic weight * value accumulation:
+    same per-loss values, same total, same parameter gradients (to fp32 rounding of the different summation order)."""
+    from loss_functions.LossComputerHip01 import LossComputerHip
+    for scene, nf, n_sparse in (('fern', 2, 0), ('realestate', 3, 128)):
+        b = vo.synthetic_batch(256, 31, scene=scene, nf=nf, n_sparse=n_sparse)
+        params = vo.init_params(11, scale=1.6)
+        model, cfg = make_model(dev, b['ndc'], params, sparse=n_sparse > 0)
+        model.train()
+        rng = {k: cu(v.numpy(), dev) for k, v in vo.synthetic_rng(int(b['rays_o'].shape[0]), 64, 128, 5).items()}
+        res = {}
+        for fused in (True, False):
+            lossc = LossComputerHip(cfg)
+            lossc.fused_total = fused
+            model.zero_grad(set_to_none=True)
+            model.injected_rng = rng
+            rb = ref_batch(b, dev, 40000)
+            lv = lossc.compute_losses(rb, model(rb))
+            lv['TotalLoss'].backward()
+            res[fused] = ({k: float(v['loss_value'] if k != 'TotalLoss' else v) for k, v in lv.items()},
+                          torch.cat([p.grad.flatten() for p in model.parameters()]).clone())
+        assert res[True][0].keys() == res[False][0].keys()
+        for k in res[True][0]:
+            np.testing.assert_allclose(res[True][0][k], res[False][0][k], rtol=2e-6, atol=1e-9, err_msg=f'{scene} {k}')
+        d = (res[True][1] - res[False][1]).norm() / res[False][1].norm()
+        assert float(d) < 1e-6, f'{scene}: gradients differ by {float(d):.2e}'
+
+
 def test_backward_all_cotangents_vs_oracle(dev):
     """Every differentiable output gets a random cotangent; parameter gradients vs the oracle's autograd."""
     n = 40

@@ -8,7 +8,7 @@ from models.ModelFactory import get_model
 from loss_functions.LossComputerHip01 import LossComputerHip
 from vipnerf_hip import dist as vdist
 dev = torch.device('cuda:0')
-cfg = bench.model_configs(); cfg['model']['hip_precision'] = 'bf16x6'
+cfg = bench.model_configs(); cfg['model']['hip_precision'] = os.environ.get('HIP_PRECISION', 'fp16x3')
 model = get_model(cfg, None).to(dev); model.train()
 lossc = LossComputerHip(cfg)
 opt = torch.optim.Adam(model.parameters(), lr=5e-4, fused=True)

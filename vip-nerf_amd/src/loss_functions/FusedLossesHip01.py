@@ -48,6 +48,13 @@ def fused_loss_values(configs: dict, input_dict: dict, output_dict: dict):
                 output_dict.get(f'visibility2_{lv}'), output_dict[f'depth_{lv}'])
     vals = FusedLossFunction.apply(cfg, n, input_dict['target_rgb'], input_dict['indices_mask_nerf'], prior, mask_sd, sd,
                                    *level('coarse'), *(level('fine') if fine else (None,) * 5))
+    output_dict[CACHE_KEY + '_vector'] = vals
     vals = vals.unbind(0)
     output_dict[CACHE_KEY] = vals
     return vals
+
+
+def fused_loss_vector(configs: dict, input_dict: dict, output_dict: dict):
+    """The same eight values as ONE tensor of shape (8,) (what a weighted total can be taken from with a single dot)."""
+    fused_loss_values(configs, input_dict, output_dict)
+    return output_dict[CACHE_KEY + '_vector']

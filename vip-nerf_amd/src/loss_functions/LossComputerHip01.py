@@ -11,6 +11,7 @@ import torch
 class LossComputerHip:
     def __init__(self, configs: dict):
         self.losses = {}
+        self.fused_total = True                      # TotalLoss by one dot product when every loss is a fused *Hip class
         for loss_configs in configs['losses']:
             name = loss_configs['name']
             self.losses[name] = self.get_loss_object(name, configs, loss_configs)
@@ -29,8 +30,11 @@ class LossComputerHip:
                 v = input_dict['common_data'][key]
                 if isinstance(v, torch.Tensor) and v.dim() > 0 and key == 'poses' and v.dim() == 4:
                     input_dict['common_data'][key] = v[0]
-        loss_values, total = {}, 0
         iter_num = input_dict['iter_num']
+        fast = self._fused_total(input_dict, output_dict, iter_num) if self.fused_total and not return_loss_maps else None
+        if fast is not None:
+            return fast
+        loss_values, total = {}, 0
         for name, obj in self.losses.items():
             weight = self.get_loss_weight(obj, iter_num)
             ld = obj.compute_loss(input_dict, output_dict, return_loss_maps=return_loss_maps)
@@ -38,6 +42,39 @@ class LossComputerHip:
                 loss_values[name] = ld
                 total = total + weight * ld['loss_value']
         loss_values['TotalLoss'] = total
+        return loss_values
+
+    def _fused_total(self, input_dict, output_dict, iter_num):
+        """When every configured loss is one of the fused *Hip classes: TotalLoss as ONE dot product of the fused loss
+        vector with the weights (same values as the generic path below, which costs ~3 zero-dim kernels per loss forward
+        and as many backward), the per-loss values for logging from one detached pair-sum."""
+        from loss_functions.FusedLossesHip01 import fused_loss_vector
+        if not self.losses or any(not hasattr(o, 'FUSED_SLOTS') for o in self.losses.values()):
+            return None
+        configs = next(iter(self.losses.values())).configs
+        fine = 'fine_mlp' in configs['model']
+        w8, present = [0.0] * 8, {}
+        for name, obj in self.losses.items():
+            a, b = obj.FUSED_SLOTS
+            if a == 4 and ('raw_visibility2_coarse' not in output_dict or (fine and 'raw_visibility2_fine' not in output_dict)):
+                continue                                  # VisibilityPriorLoss reports None on frames without secondary views
+            if a == 6 and 'indices_mask_sparse_depth' not in input_dict:
+                present[name] = None                      # SparseDepthMSE reports a constant 0
+                continue
+            weight = self.get_loss_weight(obj, iter_num)
+            w8[a] = weight
+            if fine and b != 7:
+                w8[b] = weight
+            present[name] = (a, b)
+        vec = fused_loss_vector(configs, input_dict, output_dict)
+        key = (tuple(w8), vec.device)
+        if getattr(self, '_w8_key', None) != key:
+            self._w8, self._w8_key = torch.tensor(w8, dtype=vec.dtype, device=vec.device), key
+        pairs = vec.detach().view(4, 2).sum(1).unbind(0) if fine else vec.detach()[0::2].unbind(0)
+        loss_values = {}
+        for name, slots in present.items():
+            loss_values[name] = {'loss_value': pairs[slots[0] // 2] if slots is not None else vec.detach()[7] * 0}
+        loss_values['TotalLoss'] = torch.dot(vec, self._w8)
         return loss_values
 
     @staticmethod

@@ -3,6 +3,8 @@ from loss_functions.FusedLossesHip01 import fused_loss_values
 
 
 class SparseDepthMSEHip:
+    FUSED_SLOTS = (6, 7)                      # (coarse, fine) entries of the fused loss vector this class reports
+
     def __init__(self, configs: dict, loss_configs: dict):
         self.configs, self.loss_configs = configs, loss_configs
 

@@ -5,6 +5,8 @@ from loss_functions.FusedLossesHip01 import fused_loss_values
 
 
 class VisibilityPriorLossHip:
+    FUSED_SLOTS = (4, 5)                      # (coarse, fine) entries of the fused loss vector this class reports
+
     def __init__(self, configs: dict, loss_configs: dict):
         self.configs, self.loss_configs = configs, loss_configs
         self.fine_mlp_needed = 'fine_mlp' in configs['model']

@@ -154,8 +154,13 @@ def render_forward(cfg: L.Config, batch: Dict[str, torch.Tensor], rng: Optional[
     rs = None
     if rng is not None:
         rs = L.Rng()
+        need = {'t_rand': n * cfg.n_coarse, 'u': n * cfg.n_fine, 'noise_coarse': n * cfg.n_coarse,
+                'noise_fine': n * (cfg.n_coarse + cfg.n_fine)}
         for k in ('t_rand', 'u', 'noise_coarse', 'noise_fine'):
             if rng.get(k) is not None:
+                if rng[k].numel() != need[k]:       # the library reads n_rays rows: a short array would be read past its end
+                    raise RuntimeError(f"render_forward: rng['{k}'] has {rng[k].numel()} elements, {need[k]} expected "
+                                       f"({n} rays)")
                 tc = f32c(rng[k])
                 keep.append(tc)
                 setattr(rs, k, _p(tc, name=k))

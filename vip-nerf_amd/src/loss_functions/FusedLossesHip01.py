@@ -44,7 +44,8 @@ def fused_loss_values(configs: dict, input_dict: dict, output_dict: dict):
     def level(lv):
         if f'rgb_{lv}' not in output_dict:
             return (None,) * 5
-        return (output_dict[f'rgb_{lv}'], output_dict[f'visibility_{lv}'], output_dict[f'raw_visibility_{lv}'][..., 0],
+        # raw_visibility (N,S,1) -> (N,S) by squeeze: a view both ways ([..., 0] costs a zeros + a copy kernel in backward)
+        return (output_dict[f'rgb_{lv}'], output_dict[f'visibility_{lv}'], output_dict[f'raw_visibility_{lv}'].squeeze(-1),
                 output_dict.get(f'visibility2_{lv}'), output_dict[f'depth_{lv}'])
     vals = FusedLossFunction.apply(cfg, n, input_dict['target_rgb'], input_dict['indices_mask_nerf'], prior, mask_sd, sd,
                                    *level('coarse'), *(level('fine') if fine else (None,) * 5))

@@ -136,8 +136,14 @@ struct BwdLayout {
 // its partial product to `partial`, then an ordered reduction sums the chunks (deterministic, no atomics).
 constexpr int WGRAD_CHUNK_PTS = 8192;
 constexpr int WGRAD_MAX_CHUNKS = 256;
+// The chunk count is a multiple of 32 -- the eight 256x256 GEMMs of a level then come to whole rounds of the 256 CUs
+// (4096 rays: 32 / 96 chunks as before; 1024 rays: 32 / 32 instead of 8 / 24, which filled a quarter of the chip) -- with
+// chunks of at most WGRAD_CHUNK_PTS and, for small inputs, at least 1024 points.
 __host__ __device__ inline int wgrad_chunks(size_t P) {
-    size_t c = (P + WGRAD_CHUNK_PTS - 1) / WGRAD_CHUNK_PTS;
+    const size_t round = 32 * (size_t)WGRAD_CHUNK_PTS;
+    size_t c = 32 * ((P + round - 1) / round);
+    const size_t cmax = (P + 1023) / 1024;
+    if (c > cmax) c = cmax;
     return (int)(c < 1 ? 1 : (c > WGRAD_MAX_CHUNKS ? WGRAD_MAX_CHUNKS : c));
 }
 // The eight 256x256 GEMMs use 4096-point chunks; the small GEMMs (few MFMAs per point) use chunks 4x shorter so

@@ -210,13 +210,13 @@ __device__ __forceinline__ floatx4 load_tile16(const float *base, int64_t p, int
     floatx4 v = {f.x, f.y, f.z, f.w};
     return v;
 }
-// -DVN_F16_PRESPLIT=1: FP16X3 stores the trunk activations / gradients that only the 256x256 weight-gradient GEMMs read
-// back already split (hi and lo fp16 parts in the bytes of the fp32 values they replace; store_pair_split), and those
-// GEMMs stage with a v_perm gather instead of ~500 VALU of conversion per 32-point block and run 3 fp16 cross terms
-// (k_wgrad_split16_256).  Built, all tests pass; measured on the same box 14.96-15.00 vs 15.03-15.34 ms per step
-// (weight gradients 5.37 vs 5.46 ms): the conversion VALU was not what bounds that kernel (its global loads run only
-// one 32-point block ahead and there are no registers for two).  Within noise; kept off so that the stored activations
-// stay plain fp32.  (A first version with two separate [P][256]-half planes was clearly slower: 8-byte stores / loads.)
+// VN_F16_PRESPLIT (default; 0 = plain fp32 storage): FP16X3 stores the trunk activations / gradients that only the
+// 256x256 weight-gradient GEMMs read back already split -- hi and lo fp16 parts in the bytes of the fp32 values they
+// replace (store_pair_split) -- and those GEMMs stage with a v_perm gather instead of ~320 VALU slots of conversion per
+// 32-point block (k_wgrad_split16_256).  On its own this measured within noise (weight gradients 5.37 vs 5.46 ms per
+// step); it pays together with two things it makes possible: the stores leave from the next layer's stages
+// (VN_DEFER_STORES below) and the weight-gradient kernel hides its now cheap staging under its MFMAs:
+// 15.2 -> 14.3 ms per step.  (A first version with two separate [P][256]-half planes was clearly slower: 8-byte stores.)
 #ifndef VN_F16_PRESPLIT
 #define VN_F16_PRESPLIT 1
 #endif

@@ -44,9 +44,10 @@ __global__ void k_seed_absmax(MlpBwdArgs a, unsigned *slot) {
 
 // F16: fp16 fragments (VIPNERF_PREC_FP16X3): W^T is packed as 2^8 W^T, every gradient in the workspace is 2^S times its
 // true value (grad_scale_from_max), accumulators are taken back by 2^-8
-// H16 (with F16, FP16X3H): dY of the feature layer and of layers 1..7 -- read back only by the 256x256 weight-gradient
-// GEMMs -- are stored as fp16 (the high parts of the split that is made for the next GEMM anyway); dY_5 additionally
-// in fp32 for layer 5's gamma(x) GEMM; dY_0 stays fp32.
+// H16 (with F16): dY of the feature layer and of layers 1..7 -- read back only by the 256x256 weight-gradient GEMMs -- are
+// stored as the fp16 parts of the split that is made for the next GEMM anyway: 1 = high parts only (FP16X3H), 2 = high
+// and low parts in the fp32 slot (FP16X3, store_pair_split), sent from the next GEMM's weight stages (DEFER); dY_5
+// additionally in fp32 for layer 5's gamma(x) GEMM; dY_0 stays fp32.
 template <int NS, bool F16, int H16 = 0>
 __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) {
     typedef BnPlan<NS> PL;

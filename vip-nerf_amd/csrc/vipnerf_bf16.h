@@ -245,9 +245,15 @@ struct WStreamT {
 };
 // group g of a stage (see gemm_stage_bf): reads of group g+D interleaved one by one behind the first MFMAs of group
 // g, then this group's share of the next stage's DMA
-template <int g, int NG, int NT, int NS, int G, int D, int NBUF, int NB, typename WS, typename ACC, typename FR>
+// `mid.at<g, NG>()` runs behind every group: the hook through which the narrow kernels send their deferred activation
+// stores from inside a stage (vipnerf_bf16n.h).
+struct NoMid {
+    template <int g, int NG> static constexpr bool active() { return false; }
+    template <int g, int NG> __device__ __forceinline__ void at() const {}
+};
+template <int g, int NG, int NT, int NS, int G, int D, int NBUF, int NB, typename WS, typename ACC, typename FR, typename MIDF>
 __device__ __forceinline__ void gemm_groups_bf(const float *base, ACC (&acc)[NT], const FR (&B)[NB][NS], int ks0,
-                                               FR (&fr)[NBUF][G][NS], WS &ws) {
+                                               FR (&fr)[NBUF][G][NS], WS &ws, MIDF &mid) {
     if constexpr (g < NG) {
         constexpr int R = (g + D < NG) ? G * NS : 0;           // ds_read_b128 in this group
         constexpr int M = G * NS * (NS + 1) / 2;               // MFMAs in this group
@@ -279,7 +285,8 @@ __device__ __forceinline__ void gemm_groups_bf(const float *base, ACC (&acc)[NT]
         // SLOWER than the burst, and before/after the first reads makes no difference
         ws.template prefetch_at<g, NG>();
         __builtin_amdgcn_sched_barrier(0);
-        gemm_groups_bf<g + 1, NG, NT, NS, G, D, NBUF>(base, acc, B, ks0, fr, ws);
+        if (MIDF::template active<g, NG>()) { mid.template at<g, NG>(); __builtin_amdgcn_sched_barrier(0); }
+        gemm_groups_bf<g + 1, NG, NT, NS, G, D, NBUF>(base, acc, B, ks0, fr, ws, mid);
     }
 }
 
@@ -294,9 +301,9 @@ struct NoStream {
     __device__ __forceinline__ void prefetch() {}
     template <int g, int NG> __device__ __forceinline__ void prefetch_at() {}
 };
-template <int NT, int NKS, int NS, int NB, typename WS, typename ACC, typename FR>
+template <int NT, int NKS, int NS, int NB, typename WS, typename ACC, typename FR, typename MIDF>
 __device__ __forceinline__ void gemm_stage_bf(const float *stage, int lane, ACC (&acc)[NT],
-                                              const FR (&B)[NB][NS], int ks0, WS &ws) {
+                                              const FR (&B)[NB][NS], int ks0, WS &ws, MIDF &mid) {
     // narrow layout (floatx4 accumulators, 256 registers per wave) in bf16x6: one tile per group, two groups ahead
     constexpr bool TIGHT = sizeof(ACC) == 16 && NS == 3;
     constexpr int G = TIGHT ? 1 : 2;
@@ -313,7 +320,13 @@ __device__ __forceinline__ void gemm_stage_bf(const float *stage, int lane, ACC 
 #pragma unroll
             for (int i = 0; i < NS; ++i) fr[g][tt][i] = *(const FR *)(base + ((g * G + tt) * NS + i) * CHUNK_F);
     __builtin_amdgcn_sched_barrier(0);
-    gemm_groups_bf<0, NG, NT, NS, G, D, NBUF>(base, acc, B, ks0, fr, ws);
+    gemm_groups_bf<0, NG, NT, NS, G, D, NBUF>(base, acc, B, ks0, fr, ws, mid);
+}
+template <int NT, int NKS, int NS, int NB, typename WS, typename ACC, typename FR>
+__device__ __forceinline__ void gemm_stage_bf(const float *stage, int lane, ACC (&acc)[NT],
+                                              const FR (&B)[NB][NS], int ks0, WS &ws) {
+    NoMid none;
+    gemm_stage_bf<NT, NKS, NS>(stage, lane, acc, B, ks0, ws, none);
 }
 #endif
 

@@ -255,6 +255,33 @@ __device__ __forceinline__ void split_pair(const floatx4 &lo, const floatx4 &hi,
     const float xs[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     split8<NS>(xs, out);
 }
+// The deferred stores of one weight stage (VN_DEFER_STORES), sent from INSIDE the stage: the four stores of the waves
+// 0..3 behind MFMA group GA, those of the waves 4..7 behind group GB.  Wave w and wave w + 4 share a SIMD: while one of
+// them queues at the vector-memory port the other keeps the SIMD's MFMA pipe busy -- at the stage's end all eight queue
+// there together with nothing left to compute (and the first groups belong to the DMA burst).
+#ifndef VN_STORE_GROUP_A
+#define VN_STORE_GROUP_A 6
+#endif
+#ifndef VN_STORE_GROUP_B
+#define VN_STORE_GROUP_B 12
+#endif
+template <int H16, int NS, typename FR>
+struct DeferredStores {
+    float *dst; int64_t p; int q, wave, s0;
+    const FR (*bin)[NS];
+    template <int g, int NG> static constexpr bool active() { return g == VN_STORE_GROUP_A || g == VN_STORE_GROUP_B; }
+    template <int g, int NG>
+    __device__ __forceinline__ void at() const {
+        if ((g == VN_STORE_GROUP_A) == (wave < 4)) {
+#pragma unroll
+            for (int s = s0; s < s0 + 2; ++s) {
+                if (H16 == 1) store_pair16h(dst, p, 256, q, s, bin[s][0]);
+                if (H16 == 2) store_pair_split(dst, p, 256, q, s, bin[s][0], bin[s][1]);
+            }
+        }
+    }
+};
+
 template <bool F16> struct FragOf { typedef bf16x8 type; };
 template <> struct FragOf<true> { typedef half8 type; };
 #endif

@@ -171,14 +171,12 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
             // later stages: the deferred stores behind the stage before
             const float *st = jj == 0 ? ws.template wait<DEFER ? 2 * S_PER_STAGE : 16, DEFER ? 0 : 16>(it == 0)
                                       : ws.template wait<DEFER ? 2 * S_PER_STAGE : 0>();
-            gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
             if (DEFER) {                                 // bin = the fp16 parts of the gradient this GEMM consumes
-                float *prev = a.bwd + (it == 0 ? a.bl.dyf : a.bl.dy[layer + 1]);
-#pragma unroll
-                for (int s = S_PER_STAGE * jj; s < S_PER_STAGE * (jj + 1); ++s) {
-                    if (H16 == 1) store_pair16h(prev, p, W, q, s, bin[s][0]);
-                    if (H16 == 2) store_pair_split(prev, p, W, q, s, bin[s][0], bin[s][1]);
-                }
+                static_assert(!DEFER || S_PER_STAGE == 2, "DeferredStores sends two k-steps (four stores) per stage");
+                DeferredStores<H16, NS, FR> ds{a.bwd + (it == 0 ? a.bl.dyf : a.bl.dy[layer + 1]), p, q, wave, S_PER_STAGE * jj, bin};
+                gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws, ds);
+            } else {
+                gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
             }
         }
         float *dst = a.bwd + a.bl.dy[layer];

@@ -138,14 +138,12 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
                 // younger than the stage's DMA -- first stage: the previous layer's epilogue (>= 16 tile stores, or just
                 // the mask store when the tiles are deferred); later stages: the deferred stores behind the stage before
                 const float *st = jj == 0 ? ws.template wait<DEFER ? 1 : EPI_STORES>() : ws.template wait<DEFER ? 2 * S_PER_STAGE : 0>();
-                gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
                 if (DEFER) {                             // bin = the fp16 parts of h_layer, the output of layer - 1
-                    float *prev = a.acts + a.al.h[layer - 1];
-#pragma unroll
-                    for (int s = S_PER_STAGE * jj; s < S_PER_STAGE * (jj + 1); ++s) {
-                        if (H16 == 1) store_pair16h(prev, p, W, q, s, bin[s][0]);
-                        if (H16 == 2) store_pair_split(prev, p, W, q, s, bin[s][0], bin[s][1]);
-                    }
+                    static_assert(!DEFER || S_PER_STAGE == 2, "DeferredStores sends two k-steps (four stores) per stage");
+                    DeferredStores<H16, NS, FR> ds{a.acts + a.al.h[layer - 1], p, q, wave, S_PER_STAGE * jj, bin};
+                    gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws, ds);
+                } else {
+                    gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
                 }
             }
         }

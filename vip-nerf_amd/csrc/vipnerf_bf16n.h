@@ -269,10 +269,11 @@ template <int H16, int NS, typename FR>
 struct DeferredStores {
     float *dst; int64_t p; int q, wave, s0;
     const FR (*bin)[NS];
-    template <int g, int NG> static constexpr bool active() { return g == VN_STORE_GROUP_A || g == VN_STORE_GROUP_B; }
+    // the 8-byte stores of the high-parts-only storage (H16 = 1) measured better all together behind the last group
+    template <int g, int NG> static constexpr bool active() { return H16 == 1 ? g == NG - 1 : (g == VN_STORE_GROUP_A || g == VN_STORE_GROUP_B); }
     template <int g, int NG>
     __device__ __forceinline__ void at() const {
-        if ((g == VN_STORE_GROUP_A) == (wave < 4)) {
+        if (H16 == 1 || (g == VN_STORE_GROUP_A) == (wave < 4)) {
 #pragma unroll
             for (int s = s0; s < s0 + 2; ++s) {
                 if (H16 == 1) store_pair16h(dst, p, 256, q, s, bin[s][0]);

@@ -146,36 +146,29 @@ __host__ __device__ inline int wgrad_chunks(size_t P) {
     if (c > cmax) c = cmax;
     return (int)(c < 1 ? 1 : (c > WGRAD_MAX_CHUNKS ? WGRAD_MAX_CHUNKS : c));
 }
-// The eight 256x256 GEMMs use 4096-point chunks; the small GEMMs (few MFMAs per point) use chunks 4x shorter so
-// that their single-GEMM launches still fill the chip.
-constexpr int WGRAD_SMALL_SPLIT = 4;
-__host__ __device__ inline int wgrad_chunk_pts(size_t P) {            // multiple of 32 * 2 * WGRAD_SMALL_SPLIT
+// The small GEMMs (few MFMAs per point) use shorter chunks, chosen per class so that each launch comes to whole rounds
+// of the workgroups the chip holds of that class (4096 rays: 32 / 96 chunks of the 256x256 class):
+//   256x64 (gamma(x) columns, 2 GEMMs, 2 workgroups per CU)                 chunks / 8  -> 512 / 1536 workgroups
+//   128x32 and 32x128 (per direction, 40 KiB of LDS: 4 workgroups per CU)   chunks / 16 -> 1024 / 3072 with V = 1
+//   128x256 and the fp32 mode's sigma head (alone in their launch, 1 per CU) chunks / 8 -> 256 / 768
+constexpr int WGRAD_SPLIT_PE = 8, WGRAD_SPLIT_THIN = 16, WGRAD_SINGLE_SPLIT = 8;
+__host__ __device__ inline int wgrad_chunk_pts(size_t P) {            // multiple of 32 * WGRAD_SPLIT_THIN
     const int n = wgrad_chunks(P);
-    const size_t c = (P + n - 1) / n, q = 32 * 2 * WGRAD_SMALL_SPLIT;
+    const size_t c = (P + n - 1) / n, q = 32 * WGRAD_SPLIT_THIN;
     return (int)((c + q - 1) / q * q);
 }
-__host__ __device__ inline int wgrad_chunks_small(size_t P) {
-    const size_t c = wgrad_chunk_pts(P) / WGRAD_SMALL_SPLIT;
-    return (int)((P + c - 1) / c);
-}
-// Small GEMMs that are alone in their launch (sigma head, view-layer feature columns) are cut twice as fine again:
-// with 4096 rays the other launches come to 256 / 768 workgroups (1 / 3 full rounds of the 256 CUs), these would
-// be 128 / 384.
-constexpr int WGRAD_SINGLE_SPLIT = 2 * WGRAD_SMALL_SPLIT;
-__host__ __device__ inline int wgrad_chunks_single(size_t P) {
-    const size_t c = wgrad_chunk_pts(P) / WGRAD_SINGLE_SPLIT;
+__host__ __device__ inline int wgrad_chunks_split(size_t P, int split) {
+    const size_t c = wgrad_chunk_pts(P) / split;
     return (int)((P + c - 1) / c);
 }
 // floats of partial output: sum over GEMMs of chunks * (Mp*Kp + Mp)   (Mp for the bias column sums)
 __host__ __device__ inline size_t wgrad_partial_total(size_t P, int V) {
-    size_t big = 8 * (size_t)(256 * 256 + 256) + 320;   // layers 1-4, 5(h part), 6, 7, feature (+ the sigma head's column sums)
-    size_t sm = 0, single = 0;
-    sm += 2 * (size_t)(256 * 64 + 256);             // layer 0, layer 5 gamma(x) part
-    single += (size_t)(32 * 256 + 32);              // sigma head
-    single += (size_t)(128 * 256 + 128);            // view layer, feature columns
-    sm += (size_t)(1 + V) * (128 * 32 + 128);       // view layer, direction columns (per direction)
-    sm += (size_t)(1 + V) * (32 * 128 + 32);        // output head (per direction)
-    return (size_t)wgrad_chunks(P) * big + (size_t)wgrad_chunks_small(P) * sm + (size_t)wgrad_chunks_single(P) * single;
+    const size_t big = 8 * (size_t)(256 * 256 + 256) + 320;   // layers 1-4, 5(h part), 6, 7, feature (+ the sigma head's column sums)
+    const size_t pe = 2 * (size_t)(256 * 64 + 256);           // layer 0, layer 5 gamma(x) part
+    const size_t single = (size_t)(32 * 256 + 32) + (size_t)(128 * 256 + 128);   // sigma head; view layer, feature columns
+    const size_t thin = (size_t)(1 + V) * (128 * 32 + 128) + (size_t)(1 + V) * (32 * 128 + 32);   // view-layer direction columns, output head
+    return (size_t)wgrad_chunks(P) * big + (size_t)wgrad_chunks_split(P, WGRAD_SPLIT_PE) * pe +
+           (size_t)wgrad_chunks_split(P, WGRAD_SINGLE_SPLIT) * single + (size_t)wgrad_chunks_split(P, WGRAD_SPLIT_THIN) * thin;
 }
 __host__ __device__ inline BwdLayout bwd_layout(size_t P, int V, bool h16 = false) {
     BwdLayout b; size_t o = 0;

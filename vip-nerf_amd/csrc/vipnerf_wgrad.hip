@@ -1164,8 +1164,10 @@ static int launch_class(const WgArgs &args, int n_desc, int n_chunks, hipStream_
 int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float *bwd, const BwdLayout &bl,
                  const vipnerf_mlp_grads *G, int precision, hipStream_t st, const unsigned *gmax) {
     if (P == 0) return VIPNERF_OK;
-    const int n_chunks = wgrad_chunks(P), n_small = wgrad_chunks_small(P), n_single = wgrad_chunks_single(P);
-    const int chunk_pts = wgrad_chunk_pts(P), chunk_small = chunk_pts / WGRAD_SMALL_SPLIT, chunk_single = chunk_pts / WGRAD_SINGLE_SPLIT;
+    const int n_chunks = wgrad_chunks(P), n_pe = wgrad_chunks_split(P, WGRAD_SPLIT_PE), n_thin = wgrad_chunks_split(P, WGRAD_SPLIT_THIN),
+              n_single = wgrad_chunks_split(P, WGRAD_SINGLE_SPLIT);
+    const int chunk_pts = wgrad_chunk_pts(P), chunk_pe = chunk_pts / WGRAD_SPLIT_PE, chunk_thin = chunk_pts / WGRAD_SPLIT_THIN,
+              chunk_single = chunk_pts / WGRAD_SINGLE_SPLIT;
     float *partial = bwd + bl.partial;
     // storage of the 256x256 class's operands: 0 = fp32, 1 = fp16 high parts (FP16X3H), 2 = fp16 hi + lo planes (FP16X3)
     const int halves = precision == VIPNERF_PREC_FP16X3H ? 1 : (precision == VIPNERF_PREC_FP16X3 && VN_F16_PRESPLIT ? 2 : 0);
@@ -1175,7 +1177,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
     int n88 = 0, n82 = 0, n48 = 0, n41 = 0, n18 = 0, n14 = 0, ng = 0;
     size_t off = 0;
     auto init = [&](WgArgs &w, int cp) { w.P = (int64_t)P; w.chunk_pts = cp; w.partial = partial; };
-    init(c88, chunk_pts); init(c82, chunk_small); init(c48, chunk_single); init(c41, chunk_small); init(c18, chunk_single); init(c14, chunk_small);
+    init(c88, chunk_pts); init(c82, chunk_pe); init(c48, chunk_single); init(c41, chunk_thin); init(c18, chunk_single); init(c14, chunk_thin);
     red.partial = partial;
     red.gmax = gmax;
 
@@ -1185,7 +1187,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
         d.A = A; d.lda = lda; d.m_load = m_load; d.B = B; d.ldb = ldb; d.k_load = k_load;
         d.wcol = nullptr; d.wcol_stride = 0; d.a_split16 = 0;
         d.part_off = off; d.part_stride = (size_t)Mp * Kp + Mp;
-        d.n_chunks = (&w == &c88) ? n_chunks : ((&w == &c48 || &w == &c18) ? n_single : n_small);
+        d.n_chunks = (&w == &c88) ? n_chunks : ((&w == &c48 || &w == &c18) ? n_single : (&w == &c82 ? n_pe : n_thin));
         const size_t o = off;
         off += (size_t)d.n_chunks * d.part_stride;
         return o;
@@ -1204,12 +1206,12 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
         float *dW = G->g[2 * i], *db = G->g[2 * i + 1];
         if (i == 0) {
             const size_t o = add(c82, n82, 256, 64, dy, W, W, pex, DPE_PAD, DPE_PAD);
-            group(n_small, o, 1, 256, 64, W, DPE, dW, DPE, 0, db);
+            group(n_pe, o, 1, 256, 64, W, DPE, dW, DPE, 0, db);
         } else if (i == SKIP_LAYER) {
             // fp16 high parts only (FP16X3H): the fp32 copy the data-gradient kernel leaves; pre-split: dY_5 itself, decoded on the way
             const size_t o1 = add(c82, n82, 256, 64, halves == 1 ? bwd + bl.dy5f : dy, W, W, pex, DPE_PAD, DPE_PAD);
             c82.d[n82 - 1].a_split16 = halves == 2;
-            group(n_small, o1, 1, 256, 64, W, DPE, dW, W + DPE, 0, nullptr);
+            group(n_pe, o1, 1, 256, 64, W, DPE, dW, W + DPE, 0, nullptr);
             const size_t o2 = add(c88, n88, 256, 256, dy, W, W, acts + al.h[i - 1], W, W);
             group(n_chunks, o2, 1, 256, 256, W, W, dW, W + DPE, DPE, db);
         } else {
@@ -1249,7 +1251,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
             const size_t o = add(c41, n41, 128, 32, bwd + bl.dyv[k], WV, WV, acts + al.ped[k], DVE_PAD, DVE_PAD);
             if (k == 0) first = o;
         }
-        group(n_small, first, 1 + V, 128, 32, WV, DVE, G->g[P_VW], W + DVE, W, nullptr);
+        group(n_thin, first, 1 + V, 128, 32, WV, DVE, G->g[P_VW], W + DVE, W, nullptr);
     }
     {   // output head: A = DQ[k][:, 0:4], B = view hidden of direction k
         size_t first = 0;
@@ -1257,7 +1259,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
             const size_t o = add(c14, n14, 32, 128, bwd + bl.dq[k], 8, 4, acts + al.g[k], WV, WV);
             if (k == 0) first = o;
         }
-        group(n_small, first, 1 + V, 32, 128, 4, WV, G->g[P_OW], WV, 0, G->g[P_OB]);
+        group(n_thin, first, 1 + V, 32, 128, 4, WV, G->g[P_OW], WV, 0, G->g[P_OB]);
     }
     if (off > wgrad_partial_total(P, V)) { set_error("wgrad: partial buffer plan mismatch"); return VIPNERF_E_ARG; }
 
@@ -1286,14 +1288,14 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
     ProfScope ps("wgrad_small", st);
     if (precision == VIPNERF_PREC_FP32) {
         if ((rc = launch_class<1, 8, 4>(c48, n48, n_single, st))) return rc;
-        if ((rc = launch_class<2, 2, 4>(c82, n82, n_small, st))) return rc;
+        if ((rc = launch_class<2, 2, 4>(c82, n82, n_pe, st))) return rc;
     } else {
         if ((rc = launch_bf16x3<4, 8, 2>(c48, n48, n_single, st))) return rc;
-        if ((rc = launch_bf16x3<8, 2, 1>(c82, n82, n_small, st))) return rc;
+        if ((rc = launch_bf16x3<8, 2, 1>(c82, n82, n_pe, st))) return rc;
     }
-    if ((rc = launch_class<1, 1, 4>(c41, n41, n_small, st))) return rc;
+    if ((rc = launch_class<1, 1, 4>(c41, n41, n_thin, st))) return rc;
     if ((rc = launch_class<1, 2, 1>(c18, n18, n_single, st))) return rc;
-    if ((rc = launch_class<1, 1, 1>(c14, n14, n_small, st))) return rc;
+    if ((rc = launch_class<1, 1, 1>(c14, n14, n_thin, st))) return rc;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(512, ng), dim3(256), 0, st, red);
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;

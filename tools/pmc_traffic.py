@@ -17,8 +17,10 @@ def table(path):
 STAGES = {'mlp_fwd': ('k_mlp_fwd',), 'mlp_dgrad': ('k_mlp_bwd',), 'wgrad': ('k_wgrad',)}
 
 
-def main(d, prec, out, steps_profiled=4):
+def main(d, prec, out):
     f, w = table(f'{d}/pmc_FETCH_SIZE_{prec}.txt'), table(f'{d}/pmc_WRITE_SIZE_{prec}.txt')
+    # steps in the profiled run (timed + warm-up + initialisation): the MLP forward kernel runs twice per step (coarse, fine)
+    steps_profiled = max(v[0] for k, v in f.items() if 'k_mlp_fwd' in k) // 2
     m, b = table(f'{d}/pmc_SQ_VALU_MFMA_BUSY_CYCLES_{prec}.txt'), table(f'{d}/pmc_SQ_BUSY_CYCLES_{prec}.txt')
     per = {}
     for st, keys in STAGES.items():

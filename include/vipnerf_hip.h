@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VIPNERF_ABI_VERSION 1
+#define VIPNERF_ABI_VERSION 2
 
 #define VIPNERF_OK             0
 #define VIPNERF_E_ARG         (-1)   /* null / inconsistent argument */
@@ -109,6 +109,13 @@ typedef struct vipnerf_rng {
     const float *noise_fine;    /* (N,n_coarse+n_fine)  sigma noise, fine pass */
     uint64_t seed;
     uint64_t offset;
+    uint64_t ray_base;          /* index of this call's ray 0 in the (global) batch the stream is drawn for: draw (n, k) of a
+                                   stream is keyed by (ray_base + n)*S + k, so a rank that renders rays [r0, r0+N) of a batch,
+                                   or a call that renders one chunk of it, sees the numbers a single call over the whole
+                                   batch would (per-rank Philox offset = rank * shard). 0 for a whole batch. */
+    const int64_t *ray_ids;     /* (N) or NULL: explicit global row index of every ray (replaces ray_base + n) -- for shards
+                                   that are not one contiguous range, e.g. a rank's share of the nerf rows followed by its
+                                   share of the sparse-depth rows */
 } vipnerf_rng;
 
 /* The 24 parameter tensors of one MLP in the reference's construction order (VipNeRF01.py:472-491),
@@ -168,6 +175,8 @@ typedef struct vipnerf_level_grads {
     const float *raw_rgb;      /* (N,S,3) */
     const float *raw_vis;      /* (N,S) */
     const float *raw_vis2;     /* (N,S,V) */
+    const float *depth_var;    /* (N) */
+    const float *depth_var_ndc;/* (N) */
 } vipnerf_level_grads;
 
 typedef struct vipnerf_out_grads {
@@ -288,6 +297,13 @@ typedef struct vipnerf_raygen {
     int64_t first_index;
     const float *images;             /* (n_frames,H,W,3) float32 in [0,1] or NULL: source of target_rgb */
     const float *prior;              /* (n_frames,n_frames-1,H,W) float32 or NULL: visibility prior masks / weights */
+    /* sparse-depth rows (select_batch_indices / load_sparse_depth_cached_batch, DataPreprocessor01.py:544-563, :635-681):
+     * rows with row_is_sparse[n] != 0 get rays / pixel_id / bounds like any row, -1 as target_rgb and prior, and their
+     * entries of the dense per-pixel tables below; the other rows get -1 in the sparse_* outputs.  NULL = no such rows. */
+    const uint8_t *row_is_sparse;    /* (N) or NULL */
+    const float *sparse_depths;      /* (n_frames*H*W) sparse_depth_data['depths'] (-1 where unknown) or NULL */
+    const float *sparse_errors;      /* (n_frames*H*W) ['reprojection_errors'] or NULL */
+    const float *sparse_depths_ndc;  /* (n_frames*H*W) ['depths_ndc'] or NULL */
 } vipnerf_raygen;
 
 /* The ray batch the model consumes (load_nerf_cached_batch, DataPreprocessor01.py:566-615).  Any pointer except
@@ -300,6 +316,9 @@ typedef struct vipnerf_ray_batch {
     float *target_rgb;                         /* (N,3) */
     float *prior;                              /* (N,n_frames-1) */
     float *rays_o2;                            /* (N,n_frames-1,3) secondary camera centres (VipNeRF01.py:88-98) */
+    float *sparse_depth_values;                /* (N) sparse_depth_values[:,0]; -1 on rows that are not sparse-depth rows */
+    float *sparse_depth_errors;                /* (N) */
+    float *sparse_depth_values_ndc;            /* (N) */
 } vipnerf_ray_batch;
 
 /* DataPreprocessor.get_rays / get_ndc_rays / get_view_dirs (DataPreprocessor01.py:335-378) for the selected
@@ -331,6 +350,19 @@ typedef struct vipnerf_psv {
 } vipnerf_psv;
 int32_t vipnerf_visibility_prior(const vipnerf_psv *psv, double *weights64, float *weights32, uint8_t *mask,
                                  vipnerf_stream_t stream);
+
+/* ---- stage exports used by the parity tests of the production-only pieces ------------------------------------ */
+/* VipNeRF.compute_other_view_dirs (VipNeRF01.py:218-226) exactly as the MLP kernels evaluate it:
+ * z (N,S) sampling-space depths, rays->rays_o/rays_d/rays_o2 -> dirs2 (N,S,V,3) unit vectors. */
+int32_t vipnerf_secondary_dirs(const vipnerf_config *cfg, const vipnerf_rays *rays, int32_t n_samples, const float *z,
+                               float *dirs2, vipnerf_stream_t stream);
+/* The on-device generator behind vipnerf_rng (the reference draws torch.rand / torch.randn on the CPU generator,
+ * VipNeRF01.py:200,242,551).  philox4x32_10: out[i] = Philox4x32-10(counter[i], key[i]) (Random123 known-answer
+ * vectors).  rng_draw: the n numbers idx = first_idx .. first_idx+n-1 of stream `stream_id` (1 t_rand, 2 u, 3 sigma
+ * noise coarse, 4 sigma noise fine) for (seed, offset): kind 0 = U[0,1) (24 bits), kind 1 = N(0,1) (Box-Muller). */
+int32_t vipnerf_philox4x32_10(int64_t n, const uint32_t *counters, const uint32_t *keys, uint32_t *out, vipnerf_stream_t stream);
+int32_t vipnerf_rng_draw(int32_t kind, uint64_t seed, uint64_t offset, uint32_t stream_id, uint64_t first_idx, int64_t n,
+                         float *out, vipnerf_stream_t stream);
 
 /* ---- measurement --------------------------------------------------------------------------------------- */
 /* Per-stage device time from HIP events recorded on the launch stream around each kernel (group) the calls

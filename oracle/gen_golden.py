@@ -343,6 +343,88 @@ def gen_f6():
     npz('f6_raygen', **out)
 
 
+# ------------------------------------------------------------------------------------------------ F6b
+def gen_f6b():
+    """The reference's whole training-side batch loader (DataPreprocessor in 'train' mode, cached batching) on a 3-camera
+    24x32 scene with sparse depth and visibility-prior masks: the index schedule (shuffles on numpy's global generator,
+    pre-crop, epoch wrap; DataPreprocessor01.py:248-265, 532-563) and, per iteration, every array of the batch dict
+    (:566-615 nerf rows, :635-681 sparse-depth rows, :702-724 visibility prior)."""
+    import types
+    import pandas
+    for m in ('skimage', 'skimage.transform', 'skimage.io'):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    from data_preprocessors.DataPreprocessor01 import DataPreprocessor
+    g = np.random.default_rng(62)
+    n, h, w = 3, 24, 32
+    K = np.array([[40.3, 0, 16.2], [0, 39.7, 11.9], [0, 0, 1.]])
+    extr = []
+    for i in range(n):
+        q, _ = np.linalg.qr(g.standard_normal((3, 3)))
+        if np.linalg.det(q) < 0:
+            q[:, 0] *= -1
+        q = 0.1 * q + 0.9 * np.eye(3)
+        u, _, vt = np.linalg.svd(q)
+        e = np.eye(4)
+        e[:3, :3] = u @ vt
+        e[:3, 3] = g.uniform(-0.3, 0.3, 3)
+        extr.append(e)
+    extr = np.stack(extr)
+    images = g.integers(0, 256, size=(n, h, w, 3)).astype(np.uint8)
+    masks = g.random((n, n - 1, h, w)) < 0.6
+    sparse = {}
+    for fn in (0, 2):                                   # frame 1 has no sparse depth (the reference fills -1 there)
+        k = 40
+        xs = g.uniform(0, w - 1.01, k)
+        ys = g.uniform(0, h - 1.01, k)
+        sparse[fn] = pandas.DataFrame({'x': xs, 'y': ys, 'depth': g.uniform(2.0, 9.0, k), 'reprojection_error': g.uniform(0.1, 2.0, k)})
+    raw = {'frame_nums': np.arange(n),
+           'nerf_data': {'images': images, 'extrinsics': extr, 'intrinsics': np.stack([K] * n), 'bounds': np.array([1.6, 11.0]),
+                         'resolution': (h, w)},
+           'sparse_depth_data': sparse, 'visibility_prior_data': {'masks': masks}}
+    num_rays, num_sd, iters = 40, 8, 17
+    configs = {'device': 'cpu', 'model': {'white_bkgd': False},
+               'data_loader': {'bd_factor': 0.75, 'batching': True, 'ndc': True, 'downsampling_factor': 1, 'num_rays': num_rays,
+                               'sparse_depth': {'num_rays': num_sd}, 'visibility_prior': {'load_masks': True, 'load_weights': False},
+                               'recenter_camera_poses': True, 'spherify': False, 'precrop_fraction': 0.5, 'precrop_iterations': 3}}
+    np.random.seed(620)
+    dp = DataPreprocessor(configs, 'train', raw)
+    pd_ = dp.preprocessed_data_dict
+    out = {'n': n, 'h': h, 'w': w, 'num_rays': num_rays, 'num_rays_sparse': num_sd, 'iters': iters, 'numpy_seed': 620,
+           'precrop_fraction': 0.5, 'precrop_iterations': 3,
+           'poses': np.asarray(pd_['nerf_data']['poses']), 'intrinsics': np.asarray(pd_['nerf_data']['intrinsics']),
+           'near': float(pd_['nerf_data']['near']), 'far': float(pd_['nerf_data']['far']),
+           'near_ndc': float(pd_['nerf_data']['near_ndc']), 'far_ndc': float(pd_['nerf_data']['far_ndc']),
+           'images': np.asarray(pd_['nerf_data']['images']).astype(np.float32),
+           'masks': masks.astype(np.float32),
+           'sparse_depths': pd_['sparse_depth_data']['depths'].numpy().reshape(n, h, w),
+           'sparse_errors': pd_['sparse_depth_data']['reprojection_errors'].numpy().reshape(n, h, w),
+           'sparse_depths_ndc': pd_['sparse_depth_data']['depths_ndc'].numpy().reshape(n, h, w),
+           'indices0': np.asarray(pd_['indices']).copy(), 'indices_sd0': np.asarray(pd_['sparse_depth_data']['indices']).copy()}
+    for it in range(iters):
+        b = dp.get_next_batch(it)
+        for k, v in b.items():
+            if isinstance(v, torch.Tensor):
+                out[f'it{it}_{k}'] = v.numpy()
+            elif k == 'common_data':
+                out[f'it{it}_poses'] = v['poses'].numpy()
+            else:
+                out[f'it{it}_{k}'] = v
+    npz('f6b_batches', **out)
+
+
+# ------------------------------------------------------------------------------------------------ F8
+def gen_f8():
+    """state_dict key / shape manifest of the reference model as its trainer saves it (wrapped in DataParallel,
+    Trainer01.py:517, :352-366): what CheckpointHip01 must read and write."""
+    import json
+    model = torch.nn.DataParallel(get_model(ref_configs(True), None))
+    sd = model.state_dict()
+    man = {'keys': list(sd.keys()), 'shapes': {k: list(v.shape) for k, v in sd.items()}}
+    with open(os.path.join(GOLD, 'f8_reference_state_dict_manifest.json'), 'w') as f:
+        json.dump(man, f, indent=0)
+    print('f8_reference_state_dict_manifest.json', len(man['keys']), 'keys')
+
+
 # ------------------------------------------------------------------------------------------------ F7
 def gen_f7():
     """Visibility-prior generator of the reference (plane-sweep volume) on a 40x56 two-camera toy scene."""
@@ -384,4 +466,6 @@ if __name__ == '__main__':
     gen_f5('dtu', 'dtu', 3, 24, 0, 520)
     gen_f5('toy', 'toy', 2, 64, 0, 530, depth=4, width=64, n_fine=0, pscale=1.0)
     gen_f6()
+    gen_f6b()
     gen_f7()
+    gen_f8()

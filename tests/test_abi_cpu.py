@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, 'vip-nerf_amd', 'src'))
 def header_symbols():
     txt = open(os.path.join(ROOT, 'include', 'vipnerf_hip.h')).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
-    return sorted(set(re.findall(r'\b(vipnerf_[a-z_]+)\s*\(', txt)))
+    return sorted(set(re.findall(r'\b(vipnerf_[a-z0-9_]+)\s*\(', txt)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f'{n} declared in include/vipnerf_hip.h but not exported'
     assert set(names) == set(_lib.SYMBOLS), 'ctypes binding and header disagree'
-    assert lib.vipnerf_abi_version() == 1
+    assert lib.vipnerf_abi_version() == 2
     assert lib.vipnerf_packed_weights_bytes() == 4 * (72 * 8192 + 68 * 8192 + 7424)
 
 
@@ -38,7 +38,10 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_lib.Rays) == 8 + 8 * 8
     assert C.sizeof(_lib.LevelOut) == 15 * 8
     assert C.sizeof(_lib.Outputs) == 2 * 15 * 8 + 16
-    assert C.sizeof(_lib.LevelGrads) == 12 * 8
+    assert C.sizeof(_lib.LevelGrads) == 14 * 8
+    assert C.sizeof(_lib.Rng) == 4 * 8 + 3 * 8 + 8
+    assert C.sizeof(_lib.RayGen) == 4 * 4 + 4 * 4 + 2 * 8 + 8 + 2 * 8 + 4 * 8
+    assert C.sizeof(_lib.RayBatch) == 16 * 8
 
 
 def test_argument_validation_without_gpu():
@@ -121,3 +124,41 @@ def test_checkpoint_roundtrip_with_reference_key_layout(tmp_path):
     assert it == 50000
     for (k1, p1), (k2, p2) in zip(m.named_parameters(), m2.named_parameters()):
         assert k1 == k2 and torch.equal(p1, p2)
+
+
+def test_common_utils_contract_on_cpu():
+    """get_device / move_to_device (reference src/utils/CommonUtils01.py:15-42): without a GPU the answer is the CPU
+    device, like the reference's; the HIP model then refuses CPU tensors (test_product_path_has_no_cpu_fallback)."""
+    from utils.CommonUtilsHip01 import get_device, move_to_device
+    assert get_device(None) == torch.device('cpu') and get_device('') == torch.device('cpu')
+    if not torch.cuda.is_available():
+        assert get_device([0]) == torch.device('cpu')
+    d = move_to_device({'a': torch.zeros(2), 'b': [torch.ones(1), 'x'], 'c': 5}, torch.device('cpu'))
+    assert d['a'].device.type == 'cpu' and d['b'][1] == 'x' and d['c'] == 5
+
+
+def test_batch_index_schedule_equals_the_reference():
+    """f-1 host side: BatchIndexScheduler against the index schedule recorded from the reference's DataPreprocessor
+    (golden F6b: shuffles on numpy's global generator, pre-crop incl. the reference's discarded re-generation at
+    precrop_iterations, short last batch of an epoch, epoch reshuffle of both index arrays, sparse-depth rows appended)."""
+    import numpy as np
+    from data_preprocessors.RayGeneratorHip01 import BatchIndexScheduler
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'f6b_batches.npz'))
+    np.random.seed(int(g['numpy_seed']))
+    s = BatchIndexScheduler(int(g['n']), int(g['h']), int(g['w']), int(g['num_rays']), float(g['precrop_fraction']),
+                            int(g['precrop_iterations']), g['sparse_depths'], int(g['num_rays_sparse']))
+    assert np.array_equal(s.indices, g['indices0']) and np.array_equal(s.indices_sparse, g['indices_sd0'])
+    sizes = set()
+    for it in range(int(g['iters'])):
+        idx, sp = s.next(it)
+        assert np.array_equal(idx, g[f'it{it}_indices']), it
+        assert np.array_equal(sp, g[f'it{it}_indices_mask_sparse_depth']) and np.array_equal(~sp, g[f'it{it}_indices_mask_nerf'])
+        sizes.add(idx.shape[0])
+    assert len(sizes) > 1, 'the fixture must contain a short end-of-epoch batch'
+
+
+def test_philox_restatement_reproduces_random123_vectors():
+    import numpy as np
+    from oracle import philox_oracle as po
+    for c, k, want in po.KAT:
+        assert tuple(int(x) for x in po.philox4x32_10(np.array([c], np.uint32), np.array([k], np.uint32))[0]) == want

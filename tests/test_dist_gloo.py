@@ -107,3 +107,33 @@ def test_shard_rows_partition():
     for world in (1, 2, 4, 8):
         rows = np.concatenate([np.arange(4096)[vdist.shard_rows(4096, r, world)] for r in range(world)])
         assert np.array_equal(rows, np.arange(4096))
+
+
+def test_row_class_aware_sharding():
+    """nerf rows and sparse-depth rows are split separately, so that each rank holds N_nerf/R + N_sd/R rows
+    and the mean of the rank means of every loss equals its global mean (config 3: 2048 + 2048 rows)."""
+    from oracle import vipnerf_oracle as vo
+    from vipnerf_hip import dist as vdist
+    b = vo.synthetic_batch(2048, 3, scene='realestate', nf=3, n_sparse=2048)
+    n = 4096
+    for world in (2, 4, 8):
+        seen = []
+        for r in range(world):
+            ids = vdist.shard_row_ids(b, r, world)
+            assert int(b['indices_mask_nerf'][ids].sum()) == 2048 // world
+            assert int(b['indices_mask_sparse_depth'][ids].sum()) == 2048 // world
+            sb = vdist.shard_batch(b, r, world)
+            assert sb['rays_o'].shape[0] == n // world and torch.equal(sb['rng_ray_ids'], ids)
+            assert torch.equal(sb['sparse_depth_values'], b['sparse_depth_values'][ids]) and sb['num_frames'] == b['num_frames']
+            seen.append(ids)
+        assert torch.equal(torch.sort(torch.cat(seen))[0], torch.arange(n))
+    # the losses' means: rank means average to the global mean exactly when the classes are split separately ...
+    out = {'rgb_coarse': torch.rand(n, 3), 'rgb_fine': torch.rand(n, 3), 'depth_fine': torch.rand(n) * 5}
+    g_mse, g_sd = vo.loss_mse(b, out, ('coarse', 'fine')), vo.loss_sparse_depth(b, out, ('coarse', 'fine'))
+    parts = [vdist.shard_batch({**b, **out}, r, 4) for r in range(4)]
+    m_mse = sum(vo.loss_mse(p, p, ('coarse', 'fine')) for p in parts) / 4
+    m_sd = sum(vo.loss_sparse_depth(p, p, ('coarse', 'fine')) for p in parts) / 4
+    assert abs(float(m_mse - g_mse)) < 1e-6 and abs(float(m_sd - g_sd)) < 1e-5
+    # ... which a contiguous split of the mixed batch does not give (ranks 0-1 would hold no sparse-depth row at all)
+    with pytest.raises(ValueError):
+        vdist.shard_rows(4095, 0, 2)

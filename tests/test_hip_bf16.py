@@ -79,13 +79,16 @@ def test_eval_render_golden(dev, prec):
 
 
 @pytest.mark.parametrize('prec', MODES)
-@pytest.mark.parametrize('tag', ['llff', 'dtu'])
+@pytest.mark.parametrize('tag', ['llff', 'realestate', 'dtu'])
 def test_train_step_golden(dev, prec, tag):
+    """F5 in every split arithmetic -- incl. the RealEstate case (NDC, V = 2, sparse-depth rows + SparseDepthMSE), which is
+    BASELINE configs[2]'s shape."""
     from loss_functions.LossComputerHip01 import LossComputerHip
     g = tp.load(f'f5_train_{tag}')
-    b = vo.synthetic_batch(int(g['n']), int(g['seed_batch']), scene=str(g['scene']), nf=int(g['nf']))
+    n_sparse = int(g['n_sparse'])
+    b = vo.synthetic_batch(int(g['n']), int(g['seed_batch']), scene=str(g['scene']), nf=int(g['nf']), n_sparse=n_sparse)
     params = vo.init_params(int(g['seed_params']), scale=float(g['scale_params']))
-    model, cfg = make_model(dev, b['ndc'], params, prec)
+    model, cfg = make_model(dev, b['ndc'], params, prec, sparse=n_sparse > 0)
     model.train()
     lossc = LossComputerHip(cfg)
     model.injected_rng = {k[4:]: tp.cu(v, dev) for k, v in g.items() if k.startswith('rng_')}

@@ -139,3 +139,44 @@ def test_visibility_prior_full_frame_properties(dev):
     ref = np.exp(-img.astype(np.float64).mean(-1) / 10)
     inside = (slice(2, h - 2), slice(2, w - 2))
     assert np.abs(wts[inside] - ref[inside]).max() < 1e-9
+
+
+def test_training_batches_equal_the_reference_loader(dev):
+    """f-1 end to end against golden F6b -- the batch dicts the reference's DataPreprocessor (train mode, cached batching,
+    sparse depth + visibility-prior masks, pre-crop) hands its trainer over 17 iterations: host index schedule
+    (BatchIndexScheduler) -> ONE vipnerf_generate_rays launch per iteration.  Every array bit for bit: the rays of nerf AND
+    sparse-depth rows, -1 fill of target_rgb / prior on sparse-depth rows and of the sparse_* columns on nerf rows, the
+    NDC depths of the sparse points (computed once per scene as preprocess_sparse_depth_data does), ragged end-of-epoch
+    batches."""
+    from data_preprocessors.RayGeneratorHip01 import BatchIndexScheduler, RayGeneratorHip
+    g = load('f6b_batches')
+    n, h, w = int(g['n']), int(g['h']), int(g['w'])
+    gen = RayGeneratorHip((h, w), g['intrinsics'], g['poses'], float(g['near']), float(g['far']), True, dev,
+                          near_ndc=float(g['near_ndc']), far_ndc=float(g['far_ndc']), images=torch.from_numpy(g['images']),
+                          visibility_prior=torch.from_numpy(g['masks']), sparse_depths=g['sparse_depths'],
+                          sparse_errors=g['sparse_errors'])
+    assert np.array_equal(gen.sparse_depths_ndc.cpu().numpy().reshape(n, h, w), g['sparse_depths_ndc']), 'depths_ndc table'
+    np.random.seed(int(g['numpy_seed']))
+    sched = BatchIndexScheduler(n, h, w, int(g['num_rays']), float(g['precrop_fraction']), int(g['precrop_iterations']),
+                                g['sparse_depths'], int(g['num_rays_sparse']))
+    keys = ['rays_o', 'rays_d', 'view_dirs', 'pixel_id', 'target_rgb', 'near', 'far', 'rays_o_ndc', 'rays_d_ndc', 'near_ndc',
+            'far_ndc', 'sparse_depth_values', 'sparse_depth_errors', 'sparse_depth_values_ndc', 'visibility_prior_masks',
+            'indices', 'indices_mask_nerf', 'indices_mask_sparse_depth']
+    for it in range(int(g['iters'])):
+        b = gen.get_next_batch(it, scheduler=sched)
+        for k in keys:
+            ref = g[f'it{it}_{k}']
+            got = b[k].cpu().numpy()
+            assert got.shape == ref.shape and got.dtype == ref.dtype, (it, k, got.shape, ref.shape, got.dtype, ref.dtype)
+            assert np.array_equal(got, ref), (it, k)
+        assert b['iter_num'] == it and b['num_frames'] == n
+        assert np.array_equal(b['common_data']['poses'][0].cpu().numpy(), g[f'it{it}_poses'][0])
+    # the model consumes such a batch as it is (sparse-depth rows included)
+    from models.ModelFactory import get_model
+    import test_hip_parity as tp
+    model, cfg = tp.make_model(dev, True, vo.init_params(3, scale=1.6), sparse=True)
+    model.train()
+    out = model(b)
+    from loss_functions.LossComputerHip01 import LossComputerHip
+    lv = LossComputerHip(cfg).compute_losses(b, out)
+    assert torch.isfinite(lv['TotalLoss']) and float(lv['SparseDepthMSEHip01']['loss_value']) > 0

@@ -1,0 +1,86 @@
+"""The N>1 path with the HIP module itself (tests/test_dist_gloo.py drives the CPU oracle): two ranks share ONE GPU (gloo
+carries the collective; on a multi-GPU node the same code runs one rank per GPU over RCCL), each renders its row-class-aware
+shard of a config-3 style batch (nerf rows + sparse-depth rows) with the ON-DEVICE random numbers, the 48 gradients arrive
+as consecutive views of one buffer that FlatGradBucket adopts and reduces with a single all-reduce -- and the averaged
+gradients equal the single-process gradients of the whole batch."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'vip-nerf_amd'), os.path.join(ROOT, 'vip-nerf_amd', 'src'), os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+N_NERF, N_SD, SEED, ITER = 384, 128, 4242, 40000
+
+
+def _global_batch(dev):
+    from oracle import vipnerf_oracle as vo
+    import test_hip_parity as tp
+    b = vo.synthetic_batch(N_NERF, 11, scene='realestate', nf=3, n_sparse=N_SD)
+    return b, tp.ref_batch(b, dev, ITER)
+
+
+def _step(model, cfg, batch):
+    from loss_functions.LossComputerHip01 import LossComputerHip
+    torch.manual_seed(SEED)                    # every rank: the same seed, like the reference's init_seeds
+    model._last_iter = None
+    out = model(batch)
+    LossComputerHip(cfg).compute_losses(batch, out)['TotalLoss'].backward()
+    return out
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                      VIPNERF_DIST_BACKEND='gloo')
+    from oracle import vipnerf_oracle as vo
+    from vipnerf_hip import dist as vdist
+    import test_hip_parity as tp
+    r, w, _ = vdist.init_from_env(backend='gloo')
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    b, rb = _global_batch(dev)
+    model, cfg = tp.make_model(dev, True, vo.init_params(20 + rank, scale=1.6), sparse=True)    # different on purpose
+    vdist.broadcast_parameters(model, src=0)
+    model.train()
+    bucket = vdist.FlatGradBucket(model.parameters())
+    shard = vdist.shard_batch(rb, r, w)
+    assert int(shard['indices_mask_nerf'].sum()) == N_NERF // w and int(shard['indices_mask_sparse_depth'].sum()) == N_SD // w
+    bucket.release()
+    out = _step(model, cfg, shard)
+    flat = bucket.adopted()
+    assert flat is not None and flat.numel() == 1191946, 'the HIP backward must hand over one flat gradient buffer'
+    ptr = flat.data_ptr()
+    bucket.all_reduce_mean()
+    assert bucket.params[0].grad.data_ptr() == ptr, 'reduced in place'
+    ret[rank] = flat.cpu().numpy()
+    ret[f'ids{rank}'] = shard['rng_ray_ids'].cpu().numpy()
+    ret[f'z{rank}'] = out['z_vals_fine'].detach().cpu().numpy()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_hip_ranks_on_one_gpu_equal_one_process():
+    assert torch.cuda.is_available()
+    world, port = 2, 31000 + (os.getpid() % 2000)
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert np.array_equal(ret[0], ret[1]), 'ranks disagree after the all-reduce'
+    from oracle import vipnerf_oracle as vo
+    import test_hip_parity as tp
+    dev = torch.device('cuda:0')
+    _, rb = _global_batch(dev)
+    model, cfg = tp.make_model(dev, True, vo.init_params(20, scale=1.6), sparse=True)
+    model.train()
+    out = _step(model, cfg, rb)
+    ref = torch.cat([p.grad.flatten() for p in model.parameters()]).cpu().numpy()
+    zf = out['z_vals_fine'].detach().cpu().numpy()
+    for r in range(world):      # the shards drew, ray for ray, the random numbers of the whole batch (keyed by global row index)
+        assert np.array_equal(ret[f'z{r}'], zf[ret[f'ids{r}']]), f'rank {r}: fine depths differ from the single-process run'
+    err = np.linalg.norm(ret[0] - ref) / np.linalg.norm(ref)
+    assert err < 1e-5, f'averaged rank gradients vs single-process gradients: {err:.2e}'

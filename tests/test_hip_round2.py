@@ -1,0 +1,474 @@
+"""GPU tests of the pieces that production runs but the golden-vector tests bypass: the on-device Philox generator and
+its keying (seed, iteration offset, stream, global ray index), the secondary viewing directions, the rarely used config
+branches (V = 3, white_bkgd, lindisp, other sample counts), every arithmetic against the CPU oracle at 1024 rays, the
+depth_var cotangents, the memory-bounded (re-rendering) backward, and the module inside the reference trainer's own
+call sequence (torch.nn.DataParallel wrap, sub-batches, validation merge).  Everything calls through the C ABI.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, os.path.join(ROOT, 'vip-nerf_amd', 'src'))
+
+from oracle import philox_oracle as po  # noqa: E402
+from oracle import vipnerf_oracle as vo  # noqa: E402
+import test_hip_parity as tp  # noqa: E402
+
+RS_TRAND, RS_U, RS_NOISE_C, RS_NOISE_F = 1, 2, 3, 4      # vipnerf_common.h stream ids
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+# ------------------------------------------------------------------------------------------------ the generator
+def test_philox_known_answer_vectors(dev):
+    """vipnerf_philox4x32_10 == Philox4x32-10 of Random123: its three known-answer vectors, then 4096 random
+    (counter, key) pairs against the numpy restatement, bit for bit."""
+    ops = tp.hip_ops()
+    c = np.array([k[0] for k in po.KAT], np.uint32)
+    k = np.array([k[1] for k in po.KAT], np.uint32)
+    want = np.array([k[2] for k in po.KAT], np.uint32)
+    got = ops.philox4x32_10(torch.from_numpy(c.view(np.int32)).to(dev), torch.from_numpy(k.view(np.int32)).to(dev))
+    assert (got.cpu().numpy().view(np.uint32) == want).all()
+    g = np.random.default_rng(1)
+    c = g.integers(0, 2 ** 32, size=(4096, 4), dtype=np.uint64).astype(np.uint32)
+    k = g.integers(0, 2 ** 32, size=(4096, 2), dtype=np.uint64).astype(np.uint32)
+    got = ops.philox4x32_10(torch.from_numpy(c.view(np.int32)).to(dev), torch.from_numpy(k.view(np.int32)).to(dev))
+    assert (got.cpu().numpy().view(np.uint32) == po.philox4x32_10(c, k)).all()
+
+
+def test_device_rng_streams(dev):
+    """The production draws (rng_uniform / rng_normal of vipnerf_common.h through vipnerf_rng_draw): uniforms bit-equal to
+    the restatement, normals to float32 rounding of logf / cosf; range, moments; distinct (seed, offset, stream, index)
+    give distinct numbers -- incl. seeds / offsets that differ only in their HIGH 32 bits."""
+    ops = tp.hip_ops()
+    n = 1 << 18
+    seed, off = 0x1234567890ABCDEF, (40000 << 16) | 3
+    idx = np.arange(n, dtype=np.uint64) + 7_000_000_000          # beyond 2^32: exercises the high index word
+    u = ops.rng_draw('uniform', seed, off, RS_TRAND, int(idx[0]), n, dev).cpu().numpy()
+    assert (u == po.rng_uniform(seed, off, RS_TRAND, idx)).all()
+    assert u.min() >= 0.0 and u.max() < 1.0
+    assert abs(u.mean() - 0.5) < 4 / np.sqrt(12 * n) and abs(u.var() - 1 / 12) < 1e-3
+    z = ops.rng_draw('normal', seed, off, RS_NOISE_F, int(idx[0]), n, dev).cpu().numpy()
+    zr = po.rng_normal(seed, off, RS_NOISE_F, idx)
+    assert np.isfinite(z).all() and np.abs(z - zr).max() < 2e-5
+    assert abs(z.mean()) < 4 / np.sqrt(n) and abs(z.std() - 1) < 5e-3
+    assert abs((z ** 3).mean()) < 0.03 and abs((z ** 4).mean() - 3) < 0.1
+    base = ops.rng_draw('uniform', seed, off, RS_U, 0, 4096, dev)
+    for s2, o2, st2, first in ((seed + 1, off, RS_U, 0), (seed ^ (1 << 40), off, RS_U, 0), (seed, off + 1, RS_U, 0),
+                               (seed, off ^ (1 << 36), RS_U, 0), (seed, off, RS_TRAND, 0), (seed, off, RS_U, 4096)):
+        other = ops.rng_draw('uniform', s2, o2, st2, first, 4096, dev)
+        assert float((other == base).float().mean()) < 0.01, (s2, o2, st2, first)
+    again = ops.rng_draw('uniform', seed, off, RS_U, 0, 4096, dev)
+    assert torch.equal(again, base)
+
+
+def _free_running_model(dev, n, seed_batch=5, scene='fern', nf=2, n_sparse=0, params_seed=6):
+    b = vo.synthetic_batch(n, seed_batch, scene=scene, nf=nf, n_sparse=n_sparse)
+    model, cfg = tp.make_model(dev, b['ndc'], vo.init_params(params_seed, scale=1.6), sparse=n_sparse > 0)
+    model.train()
+    return b, model, cfg
+
+
+def test_render_consumes_the_documented_streams(dev):
+    """A training-mode render with NO injected numbers (what bench.py and real training run) equals the same render fed
+    with the restatement's t_rand / u / noise for the module's (seed, offset): the kernels draw exactly those streams,
+    keyed by point index (ray*S + sample)."""
+    ops = tp.hip_ops()
+    n, Sc, Sf = 96, 64, 128
+    b, model, _ = _free_running_model(dev, n)
+    torch.manual_seed(1234)
+    it = 777
+    free = model(tp.ref_batch(b, dev, it))
+    seed, off = torch.initial_seed(), (it << 16)
+    t_rand = po.rng_uniform(seed, off, RS_TRAND, np.arange(n * Sc)).reshape(n, Sc)
+    u = po.rng_uniform(seed, off, RS_U, np.arange(n * Sf)).reshape(n, Sf)
+    nc = po.rng_normal(seed, off, RS_NOISE_C, np.arange(n * Sc)).reshape(n, Sc).astype(np.float32)
+    nf_ = po.rng_normal(seed, off, RS_NOISE_F, np.arange(n * (Sc + Sf))).reshape(n, Sc + Sf).astype(np.float32)
+    # stratified depths: bit-exact against the oracle fed with the restated uniforms
+    z_ref = vo.coarse_depths(b['near_ndc'], b['far_ndc'], Sc, torch.from_numpy(t_rand))
+    assert torch.equal(free['z_vals_coarse'].cpu(), z_ref)
+    # inverse-CDF draws: the stage op on the render's own coarse outputs with the restated u gives the render's samples
+    zf, inds, zs = ops.sample_fine(free['z_vals_coarse'].detach(), free['weights_coarse'].detach(), Sf, u=tp.cu(u, dev))
+    assert torch.equal(inds, model.last_extras['sample_inds']) and torch.equal(zs, model.last_extras['z_samples'])
+    assert torch.equal(zf, free['z_vals_fine'])
+    # sigma noise: injected restated draws reproduce the free-running outputs (float32 logf / cosf rounding only; the fine
+    # depths are the free run's, so that this rounding is not amplified by the ill-conditioned sampler)
+    model.injected_rng = {'t_rand': tp.cu(t_rand, dev), 'u': tp.cu(u, dev), 'noise_coarse': tp.cu(nc, dev), 'noise_fine': tp.cu(nf_, dev)}
+    model.injected_z_fine = free['z_vals_fine'].detach()
+    fed = model(tp.ref_batch(b, dev, it))
+    model.injected_rng = model.injected_z_fine = None
+    for k in ('raw_sigma_coarse', 'raw_sigma_fine', 'rgb_coarse', 'rgb_fine', 'visibility_fine'):
+        tp.assert_close(fed[k], free[k], rtol=1e-4, floor=1e-5, what=k)
+    assert float((free['raw_sigma_fine'] > 0).float().mean()) > 0.05          # the noise matters: densities are not all zero
+
+
+def test_rng_is_keyed_by_iteration_and_global_ray_index(dev):
+    """(a) the offset is a function of iter_num and of the call's index within the iteration (sub-batches), not of module
+    state a resumed run would lose; (b) rays [s, e) rendered alone with rng_ray_base = s -- or with explicit rng_ray_ids --
+    get the numbers they get inside the whole batch: R ranks draw what one process would."""
+    n = 256
+    b, model, _ = _free_running_model(dev, n)
+    torch.manual_seed(99)
+    rb = lambda it, **kw: dict(tp.ref_batch(b, dev, it), **kw)
+    a = model(rb(10))
+    sub2 = model(rb(10))                       # second call of the same iteration = the trainer's next sub-batch
+    nxt = model(rb(11))
+    rep = model(rb(10))                        # "resumed" at iteration 10: the first call's stream again
+    assert torch.equal(a['z_vals_coarse'], rep['z_vals_coarse']) and torch.equal(a['raw_sigma_fine'], rep['raw_sigma_fine'])
+    assert not torch.equal(a['z_vals_coarse'], sub2['z_vals_coarse']) and not torch.equal(a['z_vals_coarse'], nxt['z_vals_coarse'])
+    torch.manual_seed(100)
+    other_seed = model(rb(10))
+    assert not torch.equal(a['z_vals_coarse'], other_seed['z_vals_coarse'])
+    torch.manual_seed(99)
+
+    def part(sl, **kw):
+        model._last_iter = None
+        hb = {k: (v[sl] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == n else v) for k, v in rb(10).items()}
+        hb.update(kw)
+        return model(hb)
+    model._last_iter = None
+    whole = model(rb(10))
+    h0, h1 = part(slice(0, 96), rng_ray_base=0), part(slice(96, n), rng_ray_base=96)
+    for k in whole:
+        assert torch.equal(whole[k], torch.cat([h0[k], h1[k]], 0)), k
+    ids = torch.cat([torch.arange(0, 64), torch.arange(128, 192)]).to(dev)
+    picked = part(ids, rng_ray_ids=ids)
+    for k in whole:
+        assert torch.equal(whole[k][ids], picked[k]), k
+    wrong = part(slice(96, n))                 # without the base the shard would re-draw ray 0's numbers
+    assert not torch.equal(wrong['z_vals_coarse'], whole['z_vals_coarse'][96:])
+
+
+# ------------------------------------------------------------------------------------------------ stage exports
+@pytest.mark.parametrize('scene', ['fern', 'dtu'])
+def test_secondary_dirs_golden(dev, scene):
+    """compute_other_view_dirs (VipNeRF01.py:218-226) as the MLP kernels evaluate it, against the reference's F3 `dirs2`."""
+    ops = tp.hip_ops()
+    g = tp.load(f'f3_composite_{scene}')
+    ndc = bool(g['ndc'])
+    n, S = g['z'].shape
+    V = g['rays_o2'].shape[1]
+    cfg = ops.make_config(ndc, 64, 0, V, train=False)
+    vd = g['rays_d'] / np.linalg.norm(g['rays_d'], axis=-1, keepdims=True)
+    b = {'rays_o': tp.cu(g['rays_o'], dev), 'rays_d': tp.cu(g['rays_d'], dev), 'view_dirs': tp.cu(vd.astype(np.float32), dev),
+         'rays_o2': tp.cu(g['rays_o2'], dev)}
+    z = torch.zeros(n, device=dev)
+    if ndc:
+        b.update(rays_o_ndc=tp.cu(g['rays_o_ndc'], dev), rays_d_ndc=tp.cu(g['rays_d_ndc'], dev), near_ndc=z, far_ndc=z + 1)
+    else:
+        b.update(near=z, far=z + 1)
+    d2 = ops.secondary_dirs(cfg, b, tp.cu(g['z'], dev))
+    assert d2.shape == g['dirs2'].shape
+    np.testing.assert_allclose(d2.cpu().numpy(), g['dirs2'], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(np.linalg.norm(d2.cpu().numpy(), axis=-1), 1.0, rtol=0, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ config branches
+def _oracle_and_hip_step(dev, b, params, rng, cfg_model_updates, cfg_o, prec='fp32', iter_num=40000, sparse=False):
+    """One teacher-forced training step (oracle's fine depths and random numbers fed to the HIP module): returns
+    (oracle outputs, oracle losses, oracle params with .grad), (hip outputs, hip losses, hip model)."""
+    from loss_functions.LossComputerHip01 import LossComputerHip
+    p = vo.params_to_torch(params, requires_grad=True)
+    ref = vo.render_rays(p, b, cfg_o, rng, train=True, sec_views=True)
+    lcfg = [{'name': 'MSE01', 'weight': 1}, {'name': 'VisibilityLoss01', 'weight': 0.1},
+            {'name': 'VisibilityPriorLoss01', 'iter_weights': {'0': 0, '30000': 0.001}}]
+    if sparse:
+        lcfg.append({'name': 'SparseDepthMSE01', 'weight': 0.1})
+    lref = vo.total_loss(b, ref, lcfg, iter_num)
+    lref['TotalLoss'].backward()
+    model, cfg = tp.make_model(dev, b['ndc'], params, n_fine=cfg_o['n_fine'], sparse=sparse)
+    cfg['model'].update(cfg_model_updates)
+    cfg['model']['hip_precision'] = prec
+    cfg['model']['coarse_mlp']['num_samples'] = cfg_o['n_coarse']
+    model.train()
+    model.injected_rng = {k: v.to(dev) for k, v in rng.items()}
+    model.injected_z_fine = ref['z_vals_fine'].detach().to(dev)
+    rb = tp.ref_batch(b, dev, iter_num)
+    out = model(rb)
+    lh = LossComputerHip(cfg).compute_losses(rb, out)
+    lh['TotalLoss'].backward()
+    return (ref, lref, p), (out, lh, model)
+
+
+@pytest.mark.parametrize('case', ['v3_ndc', 'v3_white_lindisp', 'samples_32_96'])
+def test_rare_config_branches_vs_oracle(dev, case):
+    """nf = 4 (V = 3, shipped by the reference's demo configs), white_bkgd, lindisp and sample counts other than 64 + 128
+    -- branches the header says are honoured -- one training step against the oracle: outputs, losses, gradients."""
+    n = 48
+    if case == 'v3_ndc':
+        b = vo.synthetic_batch(n, 301, scene='fern', nf=4)
+        upd, nco, nfi = {}, 64, 128
+    elif case == 'v3_white_lindisp':
+        b = vo.synthetic_batch(n, 302, scene='dtu', nf=4)
+        upd, nco, nfi = {'white_bkgd': True, 'lindisp': True}, 64, 128
+    else:
+        b = vo.synthetic_batch(n, 303, scene='dtu', nf=3)
+        upd, nco, nfi = {}, 32, 96
+    params = vo.init_params(304, scale=1.6)
+    rng = vo.synthetic_rng(n, nco, nfi, 305)
+    cfg_o = {'ndc': b['ndc'], 'n_coarse': nco, 'n_fine': nfi, 'noise_std': 1.0, 'white_bkgd': upd.get('white_bkgd', False),
+             'lindisp': upd.get('lindisp', False)}
+    (ref, lref, p), (out, lh, model) = _oracle_and_hip_step(dev, b, params, rng, upd, cfg_o)
+    assert out['visibility2_fine'].shape == (n, int(b['num_frames']) - 1)
+    assert torch.equal(out['z_vals_coarse'].cpu(), ref['z_vals_coarse'])                 # incl. the lindisp spacing
+    for k in ref:
+        if k in out and k not in ('z_vals_coarse', 'z_vals_fine'):
+            tp.assert_close(out[k], ref[k], what=f'{case} {k}')
+    tp.assert_close(lh['TotalLoss'], lref['TotalLoss'], rtol=1e-4, floor=1e-6, what=f'{case} TotalLoss')
+    for k, t in model.named_parameters():
+        tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{case} grad {k}')
+
+
+def assert_close_few_outliers(a, b, rtol, what, floor=1e-5, max_frac=0.005, factor=100.0):
+    """assert_close for the per-ray depth statistics at 1024 rays: the MLP's density carries ~2e-8 ABSOLUTE error (fp32
+    rounding, any summation order), which is 1e-4 RELATIVE for a sample of density 1e-4; a ray whose whole (tiny) opacity
+    comes from such samples -- one or two in a thousand here -- therefore has depth / depth_var off by a few 1e-4
+    relative, in the reference's own fp32 arithmetic as much as here.  So: at most 0.5 % of the rays beyond the usual
+    tolerance, none beyond 100x it."""
+    a = a.detach().cpu().double().numpy().reshape(-1)
+    b = b.detach().cpu().double().numpy().reshape(-1)
+    assert np.isfinite(a).all(), what
+    tol = rtol * np.abs(b) + floor * max(np.abs(b).max(), 1e-30)
+    over = np.abs(a - b) / tol
+    assert (over > 1).mean() <= max_frac and over.max() <= factor, \
+        f'{what}: {(over > 1).sum()} / {over.size} beyond tolerance, worst {over.max():.1f}x'
+
+
+ARITH = {'fp32': (1e-4, 2e-3), 'fp16x3': (1e-4, 2e-3), 'bf16x6': (1e-4, 2e-3), 'bf16x3': (2e-4, 6e-3), 'fp16x3h': (1e-4, 2e-3)}
+
+
+@pytest.mark.parametrize('prec', list(ARITH))
+@pytest.mark.parametrize('scene', ['fern', 'realestate'])
+def test_train_step_vs_oracle_1024_rays(dev, prec, scene):
+    """HIP vs the CPU oracle on a 1024-ray training step (25x the golden fixtures' size; realestate = BASELINE configs[2]'s
+    layout: NDC, 3 views, 512 nerf + 512 sparse-depth rows) in every arithmetic: all outputs, the four losses, every
+    parameter gradient."""
+    nf, n_sparse = (2, 0) if scene == 'fern' else (3, 512)
+    n = 1024 - n_sparse
+    b = vo.synthetic_batch(n, 401, scene=scene, nf=nf, n_sparse=n_sparse)
+    params = vo.init_params(402, scale=1.6)
+    rng = vo.synthetic_rng(1024, 64, 128, 403)
+    cfg_o = {'ndc': b['ndc'], 'n_coarse': 64, 'n_fine': 128, 'noise_std': 1.0}
+    rtol, gtol = ARITH[prec]
+    (ref, lref, p), (out, lh, model) = _oracle_and_hip_step(dev, b, params, rng, {}, cfg_o, prec=prec, sparse=n_sparse > 0)
+    for k in ref:
+        if k in out and k not in ('z_vals_coarse', 'z_vals_fine'):
+            if k.startswith('depth'):
+                assert_close_few_outliers(out[k], ref[k], rtol, f'{prec} {scene} {k}')
+            else:
+                tp.assert_close(out[k], ref[k], rtol=rtol, what=f'{prec} {scene} {k}')
+    names = {'MSEHip01': 'MSE01', 'VisibilityLossHip01': 'VisibilityLoss01', 'VisibilityPriorLossHip01': 'VisibilityPriorLoss01',
+             'SparseDepthMSEHip01': 'SparseDepthMSE01', 'TotalLoss': 'TotalLoss'}
+    for k, v in lh.items():
+        val = v['loss_value'] if isinstance(v, dict) else v
+        tp.assert_close(val, lref[names[k]], rtol=1e-4, floor=1e-6, what=f'{prec} {scene} loss {k}')
+    worst = 0.0
+    for k, t in model.named_parameters():
+        tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{prec} {scene} grad {k}', l2_tol=gtol)
+        worst = max(worst, float((t.grad.cpu() - p[k].grad).norm() / p[k].grad.norm()))
+    print(f'{prec} {scene}: worst relative L2 gradient error over 48 tensors at 1024 rays: {worst:.2e}')
+
+
+def test_depth_var_cotangents_vs_oracle(dev):
+    """depth_var / depth_var_ndc are ordinary differentiable outputs in the reference (VipNeRF01.py:371-377): a loss on
+    them must reach the parameters."""
+    n = 40
+    for scene, nf in (('fern', 2), ('dtu', 3)):
+        b = vo.synthetic_batch(n, 501, scene=scene, nf=nf)
+        params = vo.init_params(502, scale=1.6)
+        rng = vo.synthetic_rng(n, 64, 128, 503)
+        p = vo.params_to_torch(params, requires_grad=True)
+        ref = vo.render_rays(p, b, {'ndc': b['ndc'], 'n_coarse': 64, 'n_fine': 128, 'noise_std': 1.0}, rng, train=True, sec_views=True)
+        model, _ = tp.make_model(dev, b['ndc'], params)
+        model.train()
+        model.injected_rng = {k: v.to(dev) for k, v in rng.items()}
+        model.injected_z_fine = ref['z_vals_fine'].detach().to(dev)
+        out = model(tp.ref_batch(b, dev, 0))
+        keys = ['depth_var'] + (['depth_var_ndc'] if b['ndc'] else [])
+        gen = torch.Generator().manual_seed(7)
+        tot_o = tot_h = 0
+        for lv in ('coarse', 'fine'):
+            for k in keys:
+                ct = torch.randn(n, generator=gen) / max(float(ref[f'{k}_{lv}'].abs().max()), 1e-6)
+                tot_o = tot_o + (ref[f'{k}_{lv}'] * ct).sum()
+                tot_h = tot_h + (out[f'{k}_{lv}'] * ct.to(dev)).sum()
+        tot_o.backward()
+        tot_h.backward()
+        for k, t in model.named_parameters():
+            if p[k].grad is None or float(p[k].grad.abs().max()) == 0:     # the view branch does not feed the density
+                assert t.grad is None or float(t.grad.abs().max()) == 0, k
+                continue
+            assert float(t.grad.abs().max()) > 0, k
+            tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{scene} depth_var grad {k}')
+
+
+# ------------------------------------------------------------------------------------------------ memory-bounded training
+@pytest.mark.parametrize('device_rng', [False, True])
+def test_rerendering_backward_equals_plain(dev, device_rng):
+    """A call whose training workspace exceeds the budget keeps no activations and re-renders ray chunks in backward
+    (the reference's `chunk` loop bounds eval memory only): same outputs bit for bit, same gradients to the rounding of a
+    different summation order -- with injected numbers and with the on-device generator (re-drawn by global ray index)."""
+    from loss_functions.LossComputerHip01 import LossComputerHip
+    n = 1024
+    b = vo.synthetic_batch(n - 256, 601, scene='realestate', nf=3, n_sparse=256)
+    params = vo.init_params(602, scale=1.6)
+    rng = {k: v.to(dev) for k, v in vo.synthetic_rng(n, 64, 128, 603).items()}
+    res = {}
+    for limit in (None, 1_600_000_000):                       # ~5.4 MB of workspace per ray: 1.6 GB -> 256-ray chunks
+        model, cfg = tp.make_model(dev, b['ndc'], params, sparse=True)
+        if limit:
+            cfg['model']['hip_max_workspace_bytes'] = limit
+        model.train()
+        torch.manual_seed(5)
+        model.injected_rng = None if device_rng else rng
+        rb = tp.ref_batch(b, dev, 40000)
+        out = model(rb)
+        LossComputerHip(cfg).compute_losses(rb, out)['TotalLoss'].backward()
+        res[limit] = ({k: v.detach().clone() for k, v in out.items()}, torch.cat([p.grad.flatten() for p in model.parameters()]))
+    from vipnerf_hip import autograd as ag, ops
+    c = ops.make_config(True, 64, 128, 2, train=True, save_acts=True)
+    ab, bb = ops.query_workspace(c, n)
+    assert ab + bb > 1_600_000_000 and ag._recompute_chunk(ag.RenderState(c, {}, None, None, 1_600_000_000), n, ab, bb, dev) == 256
+    for k in res[None][0]:
+        assert torch.equal(res[None][0][k], res[1_600_000_000][0][k]), k
+    d = float((res[None][1] - res[1_600_000_000][1]).norm() / res[None][1].norm())
+    assert d < 2e-6, d
+    with pytest.raises(RuntimeError, match='sub_batch_size'):
+        ag._recompute_chunk(ag.RenderState(c, {}, None, None, 100_000_000), n, ab, bb, dev)
+
+
+# ------------------------------------------------------------------------------------------------ the drop-in claim
+def _merge_chunks(chunks):
+    """What the reference's validation does with the per-chunk dicts (Trainer01.py:147-172): tensors with more than one
+    element are concatenated, one-element tensors averaged, nested dicts walked; anything else is an error."""
+    out = {}
+    for key in chunks[0]:
+        v = chunks[0][key]
+        if isinstance(v, torch.Tensor):
+            out[key] = torch.cat([c[key] for c in chunks], 0) if v.numel() > 1 else torch.mean(torch.stack([c[key] for c in chunks]))
+        elif isinstance(v, dict):
+            out[key] = _merge_chunks([c[key] for c in chunks])
+        else:
+            raise RuntimeError(f'{key}: {type(v)} cannot be merged')
+    return out
+
+
+def test_module_inside_the_reference_trainer_sequence(dev):
+    """VipNeRFHip wrapped in torch.nn.DataParallel (Trainer01.py:517), fed batches laid out as load_cached_next_batch
+    builds them (common_data tiled per GPU, :524-529), config carrying the reference's keys incl. chunk / netchunk /
+    sub_batch_size: train_one_iter's sequence (:78-104: zero_grad, per sub-batch forward -> compute_losses -> backward,
+    delete the dicts, step) and run_validation's (:189-226: eval, no_grad forward with retraw=True per chunk,
+    compute_losses with loss maps, drop keys, merge).  The trained parameters must equal the plain (unwrapped, single
+    batch) module's up to summation order, and the state dict must carry the reference's `module.` keys."""
+    from loss_functions.LossComputerHip01 import LossComputerHip
+    n = 256
+    b = vo.synthetic_batch(n - 64, 701, scene='realestate', nf=3, n_sparse=64)
+    params = vo.init_params(702, scale=1.6)
+    rng = vo.synthetic_rng(n, 64, 128, 703)
+
+    def build(wrap):
+        model, cfg = tp.make_model(dev, b['ndc'], params, sparse=True)
+        cfg.update({'sub_batch_size': 128, 'validation_chunk_size': 100, 'validation_save_loss_maps': True, 'device': [0]})
+        model = model.to(dev)
+        net = torch.nn.DataParallel(model, device_ids=[0]) if wrap else model
+        opt = torch.optim.Adam(list(net.parameters()), lr=5e-4, betas=(0.9, 0.999))
+        return model, net, cfg, opt
+
+    def batch(iter_num):
+        rb = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items() if k not in ('poses', 'ndc')}
+        rb['common_data'] = {'poses': b['poses'][None].repeat(1, 1, 1, 1).to(dev)}           # tiled num_gpus (= 1) times
+        rb['iter_num'] = iter_num
+        return rb
+
+    # -- training: the wrapped module driven in two sub-batches vs the plain module on the whole batch.  The nerf and
+    #    sparse-depth rows are interleaved so that every sub-batch holds both classes in the global proportion (each loss is
+    #    a mean over its own rows: equal class counts per sub-batch make the sum of sub-batch losses / 2 the batch loss)
+    perm = torch.cat([torch.stack([torch.arange(0, 96), torch.arange(96, 192)], 1).reshape(-1),
+                      torch.arange(192, 256)])
+    perm = torch.cat([perm[0:96], perm[192:224], perm[96:192], perm[224:256]])                 # 96 nerf + 32 sd | 96 + 32
+    results = {}
+    for wrap in (True, False):
+        model, net, cfg, opt = build(wrap)
+        lossc = LossComputerHip(cfg)
+        net.train()
+        input_batch = batch(40000)
+        input_batch = {k: (v[perm.to(v.device)] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == n else v)
+                       for k, v in input_batch.items()}
+        rr = {k: v[perm].to(dev) for k, v in rng.items()}
+        opt.zero_grad(set_to_none=True)
+        sub = cfg['sub_batch_size'] if wrap else n
+        logged = {}
+        for s in range(0, n, sub):
+            sb = {}
+            for k, v in input_batch.items():
+                sb[k] = v[s:s + sub] if isinstance(v, torch.Tensor) else (v.copy() if k == 'common_data' else v)
+            model.injected_rng = {k: v[s:s + sub] for k, v in rr.items()}
+            out = net(sb)
+            ld = lossc.compute_losses(sb, out)
+            (ld['TotalLoss'] * (sub / n)).backward() if wrap else ld['TotalLoss'].backward()
+            for k, v in ld.items():
+                v = v['loss_value'] if isinstance(v, dict) else v
+                logged[k] = logged.get(k, 0.0) + v.item() * (sub / n)
+            for d in (out, sb):
+                for k in list(d.keys()):
+                    del d[k]
+        grads = torch.cat([p.grad.flatten() for p in model.parameters()]).clone()
+        opt.step()
+        results[wrap] = (logged, torch.cat([p.detach().flatten() for p in model.parameters()]).clone(), net, grads)
+    for k in results[True][0]:
+        np.testing.assert_allclose(results[True][0][k], results[False][0][k], rtol=2e-5, atol=1e-8, err_msg=k)
+    d = float((results[True][3] - results[False][3]).norm() / results[False][3].norm())
+    assert d < 1e-5, f'accumulated sub-batch gradients vs whole-batch gradients: {d:.2e}'
+    d = float((results[True][1] - results[False][1]).abs().max())
+    assert d < 1.1e-3, d       # one Adam step of lr 5e-4 (an update whose gradient is at rounding level may flip sign)
+    sd = results[True][2].state_dict()
+    assert all(k.startswith('module.coarse_model.') or k.startswith('module.fine_model.') for k in sd) and len(sd) == 48
+
+    # -- validation: eval mode, no_grad, retraw=True, secondary views on, chunks of 100 rays, loss maps, merge
+    model, net, cfg, _ = build(True)
+    lossc = LossComputerHip(cfg)
+    lossc_maps = LossComputerHip(cfg)
+    net.eval()
+    whole = batch(40000)
+    outs, lds = [], []
+    for s in range(0, n, cfg['validation_chunk_size']):
+        e = s + cfg['validation_chunk_size']
+        cb = {k: (v[s:e] if isinstance(v, torch.Tensor) and v.shape[0] == n else (v.copy() if k == 'common_data' else v))
+              for k, v in whole.items()}
+        with torch.no_grad():
+            oc = net(cb, retraw=True, sec_views_vis=True)
+        lds.append(lossc_maps.compute_losses(cb, oc, return_loss_maps=True))
+        assert all(isinstance(v, torch.Tensor) for v in oc.values()), 'only tensors may live in the output dict'
+        for k in ('z_vals_coarse', 'raw_sigma_coarse', 'raw_rgb_coarse', 'raw_rgb_view_dependent_coarse', 'raw_visibility_coarse',
+                  'raw_visibility2_coarse', 'alpha_coarse', 'visibility_coarse', 'weights_coarse', 'z_vals_fine', 'raw_sigma_fine',
+                  'raw_rgb_fine', 'raw_rgb_view_dependent_fine', 'raw_visibility_fine', 'raw_visibility2_fine', 'alpha_fine',
+                  'visibility_fine', 'weights_fine'):
+            oc.pop(k, None)
+        outs.append(oc)
+    merged, mlosses = _merge_chunks(outs), _merge_chunks(lds)
+    assert merged['rgb_fine'].shape == (n, 3) and merged['visibility2_fine'].shape == (n, 2)
+    assert mlosses['TotalLoss'].numel() == 1 and torch.isfinite(mlosses['TotalLoss'])
+    maps = mlosses['MSEHip01']['loss_maps']
+    assert maps['MSEHip01_fine'].shape[0] == int(b['indices_mask_nerf'].sum())
+    # the eval render of the chunks == the eval render of the whole frame (ray independence), and == the oracle
+    with torch.no_grad():
+        full = net(batch(40000), retraw=True, sec_views_vis=True)
+    assert torch.equal(full['rgb_coarse'], merged['rgb_coarse']) and torch.equal(full['depth_fine'], merged['depth_fine'])
+
+
+def test_common_utils_device_glue(dev):
+    from utils.CommonUtilsHip01 import get_device, move_to_device
+    assert get_device([0, 1]) == torch.device('cuda:0') and get_device(0) == torch.device('cuda:0')
+    assert get_device(None) == torch.device('cpu') and get_device('') == torch.device('cpu')
+    moved = move_to_device({'a': torch.zeros(2), 'b': [torch.ones(1), 'text'], 'c': {'d': torch.zeros(1)}, 'e': 3}, dev)
+    assert moved['a'].device == dev and moved['b'][0].device == dev and moved['b'][1] == 'text' and moved['c']['d'].device == dev and moved['e'] == 3

@@ -139,6 +139,10 @@ static PointSrc ray_points(const vipnerf_config *cfg, const vipnerf_rays *r, int
     return s;
 }
 
+int launch_secondary_dirs(const PointSrc &s, float *out, hipStream_t st);
+int launch_philox(int64_t n, const uint32_t *ctr, const uint32_t *key, uint32_t *out, hipStream_t st);
+int launch_rng_draw(int kind, uint64_t seed, uint64_t offset, uint32_t stream, uint64_t first, int64_t n, float *out, hipStream_t st);
+
 struct LevelWs { size_t acts_off, bwd_off; };   // float offsets of the fine level inside the workspaces
 
 static size_t bwd_total(size_t P, int V, bool h16) { return bwd_layout(P, V, h16).total; }
@@ -200,7 +204,7 @@ int32_t vipnerf_coarse_depths(int64_t n_rays, int32_t n_samples, int32_t lindisp
     clear_stale_hip_error();
     if (!near || !far || !z_out) { set_error("coarse_depths: NULL argument"); return VIPNERF_E_ARG; }
     if (n_samples < 2) { set_error("coarse_depths: n_samples < 2"); return VIPNERF_E_UNSUPPORTED; }
-    return launch_coarse_z(n_rays, n_samples, lindisp, near, far, t_rand, 0, 0, 0, z_out, (hipStream_t)stream);
+    return launch_coarse_z(n_rays, n_samples, lindisp, near, far, t_rand, 0, 0, 0, 0, nullptr, z_out, (hipStream_t)stream);
 }
 
 int32_t vipnerf_sample_fine(int64_t n_rays, int32_t n_coarse, int32_t n_fine, const float *z_coarse,
@@ -271,13 +275,14 @@ int32_t vipnerf_render_forward(const vipnerf_config *cfg, const vipnerf_rays *ra
     if (N == 0) return VIPNERF_OK;
     const int Sc = cfg->n_coarse, Sf = cfg->n_fine, V = cfg->n_sec;
     const bool train = cfg->train != 0, perturb = cfg->perturb != 0;
-    const uint64_t seed = rng ? rng->seed : 0, offset = rng ? rng->offset : 0;
+    const uint64_t seed = rng ? rng->seed : 0, offset = rng ? rng->offset : 0, ray_base = rng ? rng->ray_base : 0;
+    const int64_t *ray_ids = rng ? rng->ray_ids : nullptr;
 
     // 1. coarse depths
     const float *t_rand = (perturb && rng) ? rng->t_rand : nullptr;
     {
         ProfScope ps("coarse_z", st);
-        rc = launch_coarse_z(N, Sc, cfg->lindisp, rays->near, rays->far, t_rand, perturb && !t_rand, seed, offset,
+        rc = launch_coarse_z(N, Sc, cfg->lindisp, rays->near, rays->far, t_rand, perturb && !t_rand, seed, offset, ray_base, ray_ids,
                              out->coarse.z_vals, st);
     }
     if (rc) return rc;
@@ -291,7 +296,7 @@ int32_t vipnerf_render_forward(const vipnerf_config *cfg, const vipnerf_rays *ra
             memset(&sa, 0, sizeof(sa));
             sa.N = N; sa.Sc = Sc; sa.Sf = Sf; sa.z_coarse = out->coarse.z_vals; sa.w_coarse = out->coarse.weights;
             sa.u = (perturb && rng) ? rng->u : nullptr;
-            sa.device_rng = perturb && !sa.u; sa.seed = seed; sa.offset = offset;
+            sa.device_rng = perturb && !sa.u; sa.seed = seed; sa.offset = offset; sa.ray_base = ray_base; sa.ray_ids = ray_ids;
             sa.z_fine = L.z_vals; sa.inds = out->sample_inds; sa.z_samples = out->z_samples;
             ProfScope ps("sample_fine", st);
             if ((rc = launch_sample_fine(sa, st))) return rc;
@@ -305,7 +310,7 @@ int32_t vipnerf_render_forward(const vipnerf_config *cfg, const vipnerf_rays *ra
             ma.ns.device_rng = !ma.ns.noise;
             ma.ns.std = cfg->noise_std;
             ma.ns.stream = lv ? RS_NOISE_F : RS_NOISE_C;
-            ma.ns.seed = seed; ma.ns.offset = offset;
+            ma.ns.seed = seed; ma.ns.offset = offset; ma.ns.idx_base = ray_base * (uint64_t)S; ma.ns.ray_ids = ray_ids;
         }
         ma.packed = (const float *)(lv ? packed_fine : packed_coarse);
         ma.sigma = L.raw_sigma; ma.rgb = L.raw_rgb; ma.vis = L.raw_vis; ma.vis2 = L.raw_vis2;
@@ -443,6 +448,30 @@ int32_t vipnerf_visibility_prior(const vipnerf_psv *psv, double *weights64, floa
     if (psv->height <= 0 || psv->width <= 0 || psv->n_planes <= 0 || !(psv->temperature > 0)) { set_error("visibility_prior: bad sizes"); return VIPNERF_E_ARG; }
     ProfScope ps("visibility_prior", (hipStream_t)stream);
     return launch_psv(psv, weights64, weights32, mask, (hipStream_t)stream);
+}
+
+int32_t vipnerf_secondary_dirs(const vipnerf_config *cfg, const vipnerf_rays *rays, int32_t n_samples, const float *z,
+                               float *dirs2, vipnerf_stream_t stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if ((rc = check_rays(cfg, rays))) return rc;
+    if (!z || !dirs2 || n_samples <= 0) { set_error("secondary_dirs: bad argument"); return VIPNERF_E_ARG; }
+    if (cfg->n_sec <= 0) { set_error("secondary_dirs: n_sec == 0"); return VIPNERF_E_ARG; }
+    const PointSrc s = ray_points(cfg, rays, n_samples, z);
+    return launch_secondary_dirs(s, dirs2, (hipStream_t)stream);
+}
+
+int32_t vipnerf_philox4x32_10(int64_t n, const uint32_t *counters, const uint32_t *keys, uint32_t *out, vipnerf_stream_t stream) {
+    clear_stale_hip_error();
+    if (n < 0 || (n > 0 && (!counters || !keys || !out))) { set_error("philox4x32_10: bad argument"); return VIPNERF_E_ARG; }
+    return launch_philox(n, counters, keys, out, (hipStream_t)stream);
+}
+
+int32_t vipnerf_rng_draw(int32_t kind, uint64_t seed, uint64_t offset, uint32_t stream_id, uint64_t first_idx, int64_t n,
+                         float *out, vipnerf_stream_t stream) {
+    clear_stale_hip_error();
+    if (n < 0 || (n > 0 && !out) || kind < 0 || kind > 1) { set_error("rng_draw: bad argument"); return VIPNERF_E_ARG; }
+    return launch_rng_draw(kind, seed, offset, stream_id, first_idx, n, out, (hipStream_t)stream);
 }
 
 int32_t vipnerf_profile_enable(int32_t on) {

@@ -63,13 +63,19 @@ __global__ void k_gen_rays(RayGenArgs a) {
         if (b.far_ndc) b.far_ndc[n] = a.g.far_ndc;
     }
     if (b.pixel_id) { b.pixel_id[3 * n] = f; b.pixel_id[3 * n + 1] = xi; b.pixel_id[3 * n + 2] = yi; }
+    // sparse-depth rows (DataPreprocessor01.py:544-563, :635-681): the same rays, but -1 where the nerf rows carry their
+    // colour / visibility prior, and the per-pixel sparse-depth tables where the nerf rows carry -1
+    const bool sd_row = a.g.row_is_sparse && a.g.row_is_sparse[n];
     if (b.target_rgb && a.g.images) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) b.target_rgb[3 * n + i] = a.g.images[3 * idx + i];
+        for (int i = 0; i < 3; ++i) b.target_rgb[3 * n + i] = sd_row ? -1.f : a.g.images[3 * idx + i];
     }
     const int V = a.g.n_frames - 1;
     if (b.prior && a.g.prior)                      // masks stored (n, n-1, h, w)
-        for (int v = 0; v < V; ++v) b.prior[n * V + v] = a.g.prior[((int64_t)f * V + v) * hw + rem];
+        for (int v = 0; v < V; ++v) b.prior[n * V + v] = sd_row ? -1.f : a.g.prior[((int64_t)f * V + v) * hw + rem];
+    if (b.sparse_depth_values) b.sparse_depth_values[n] = (sd_row && a.g.sparse_depths) ? a.g.sparse_depths[idx] : -1.f;
+    if (b.sparse_depth_errors) b.sparse_depth_errors[n] = (sd_row && a.g.sparse_errors) ? a.g.sparse_errors[idx] : -1.f;
+    if (b.sparse_depth_values_ndc) b.sparse_depth_values_ndc[n] = (sd_row && a.g.sparse_depths_ndc) ? a.g.sparse_depths_ndc[idx] : -1.f;
     if (b.rays_o2)                                 // centre of camera v + (v >= f)   (VipNeRF01.py:93-97)
         for (int v = 0; v < V; ++v) {
             const vipnerf_camera &c2 = a.g.cameras[v + (v >= f ? 1 : 0)];

@@ -25,7 +25,17 @@ struct NoiseSrc {
     int32_t device_rng;   // 1: draw N(0,1) from Philox when noise == NULL
     uint32_t stream;
     uint64_t seed, offset;
+    uint64_t idx_base;    // Philox index of point 0 (= vipnerf_rng::ray_base * S)
+    const int64_t *ray_ids;   // rays mode: explicit global row index per ray (vipnerf_rng::ray_ids) or NULL
 };
+
+#if defined(__HIPCC__)
+// Philox index of point p's sigma-noise draw: (global ray index) * S + sample
+__device__ __forceinline__ uint64_t noise_index(const NoiseSrc &ns, const PointSrc &s, int64_t p) {
+    if (ns.ray_ids && s.rays_mode) return (uint64_t)ns.ray_ids[p / s.S] * (uint64_t)s.S + (uint64_t)(p % s.S);
+    return ns.idx_base + (uint64_t)p;
+}
+#endif
 
 struct MlpFwdArgs {
     PointSrc src;

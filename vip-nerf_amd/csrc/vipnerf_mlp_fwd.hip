@@ -112,7 +112,7 @@ __global__ __launch_bounds__(MLP_WG) void k_mlp_fwd(MlpFwdArgs a) {
     {
         float nz = 0.f;
         if (a.ns.noise) nz = a.ns.noise[p];
-        else if (a.ns.device_rng) nz = rng_normal(a.ns.seed, a.ns.offset, a.ns.stream, (uint64_t)p);
+        else if (a.ns.device_rng) nz = rng_normal(a.ns.seed, a.ns.offset, a.ns.stream, noise_index(a.ns, a.src, p));
         const float sg = fmaxf(__fadd_rn(sigma_raw, __fmul_rn(nz, a.ns.std)), 0.f);
         if (valid && h == 0) a.sigma[p] = sg;
     }

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
     {
         float nz = 0.f;
         if (a.ns.noise) nz = a.ns.noise[p];
-        else if (a.ns.device_rng) nz = rng_normal(a.ns.seed, a.ns.offset, a.ns.stream, (uint64_t)p);
+        else if (a.ns.device_rng) nz = rng_normal(a.ns.seed, a.ns.offset, a.ns.stream, noise_index(a.ns, a.src, p));
         const float sgm = relu_lo<F16>(__fadd_rn(sigma_raw, __fmul_rn(nz, a.ns.std)), 0.f);
         if (valid && q == 0) a.sigma[p] = sgm;
     }

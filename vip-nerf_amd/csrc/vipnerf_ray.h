@@ -25,7 +25,8 @@ struct SampleArgs {
     int32_t Sc, Sf;
     const float *z_coarse, *w_coarse, *u;
     int32_t device_rng;
-    uint64_t seed, offset;
+    uint64_t seed, offset, ray_base;
+    const int64_t *ray_ids;
     float *z_fine;
     int32_t *inds;
     float *z_samples;
@@ -43,7 +44,8 @@ struct LossArgs {
 };
 
 int launch_coarse_z(int64_t N, int S, int lindisp, const float *near, const float *far, const float *t_rand,
-                    int device_rng, uint64_t seed, uint64_t offset, float *z_out, hipStream_t st);
+                    int device_rng, uint64_t seed, uint64_t offset, uint64_t ray_base, const int64_t *ray_ids, float *z_out,
+                    hipStream_t st);
 int launch_composite(const CompositeArgs &a, hipStream_t st);
 int launch_composite_bwd(const CompositeBwdArgs &a, hipStream_t st);
 int launch_sample_fine(const SampleArgs &a, hipStream_t st);

@@ -20,7 +20,8 @@ __device__ __forceinline__ float linspace01(int i, int n) {
 // ------------------------------------------------------------------------------------------- coarse depths
 // VipNeRF.get_z_vals_coarse (VipNeRF01.py:173-203)
 __global__ void k_coarse_z(int64_t N, int S, int lindisp, const float *near, const float *far,
-                           const float *t_rand, int device_rng, uint64_t seed, uint64_t offset, float *z_out) {
+                           const float *t_rand, int device_rng, uint64_t seed, uint64_t offset, uint64_t ray_base,
+                           const int64_t *ray_ids, float *z_out) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * S) return;
     const int64_t n = idx / S;
@@ -37,7 +38,7 @@ __global__ void k_coarse_z(int64_t N, int S, int lindisp, const float *near, con
         const float zl = k > 0 ? zk(k - 1) : z, zu = k < S - 1 ? zk(k + 1) : z;
         const float lo = k > 0 ? __fmul_rn(0.5f, __fadd_rn(z, zl)) : z;
         const float hi = k < S - 1 ? __fmul_rn(0.5f, __fadd_rn(zu, z)) : z;
-        const float t = t_rand ? t_rand[idx] : rng_uniform(seed, offset, RS_TRAND, (uint64_t)idx);
+        const float t = t_rand ? t_rand[idx] : rng_uniform(seed, offset, RS_TRAND, (ray_ids ? (uint64_t)ray_ids[n] : ray_base + (uint64_t)n) * (uint64_t)S + (uint64_t)k);
         z = __fadd_rn(lo, __fmul_rn(__fsub_rn(hi, lo), t));
     }
     z_out[idx] = z;
@@ -154,6 +155,7 @@ int launch_composite(const CompositeArgs &a, hipStream_t st) {
 // Backward of the compositing (SURVEY.md §9 "Compositing backward", extended to every differentiable output):
 //   G_k = dL/dw_k = gw_k + g_rgb.c_k (- sum g_rgb if white_bkgd) + g_acc + g_depth (zm_k - D)/(A+eps)
 //         + g_depth_ndc (z_k - D')/(A+eps) + sum_v g_vis2_v (v2_kv - V2_v)/(A+eps)
+//         + g_depth_var [(zm_k - D)^2 - 2 (zm_k - D)/(A+eps) sum_j w_j (zm_j - D)]  (same for depth_var_ndc on z)
 //   R_k = sum_{j>k} (G_j w_j + gT_j T_j)
 //   dL/dalpha_k = G_k T_k + galpha_k - R_k / (1 - alpha_k + 1e-10)
 //   dL/dsigma_k = dL/dalpha_k * delta_k * (1 - alpha_k)  (+ direct)
@@ -174,6 +176,8 @@ __global__ __launch_bounds__(RAY_WG) void k_composite_bwd(CompositeBwdArgs a) {
     const float g_acc = (g.acc ? g.acc[n] : 0.f) - (a.white_bkgd ? (g_rgb[0] + g_rgb[1] + g_rgb[2]) : 0.f);
     const float g_dep = g.depth ? g.depth[n] : 0.f;
     const float g_dnd = (g.depth_ndc && a.ndc) ? g.depth_ndc[n] : 0.f;
+    const float g_var = g.depth_var ? g.depth_var[n] : 0.f;
+    const float g_vnd = (g.depth_var_ndc && a.ndc) ? g.depth_var_ndc[n] : 0.f;
     const float Dm = a.lvl.depth[n];
     const float Ds = (a.ndc && a.lvl.depth_ndc) ? a.lvl.depth_ndc[n] : 0.f;
     for (int v = 0; v < V; ++v) { g_v2[v] = g.vis2 ? g.vis2[n * V + v] : 0.f; V2[v] = a.lvl.vis2[n * V + v]; }
@@ -185,6 +189,19 @@ __global__ __launch_bounds__(RAY_WG) void k_composite_bwd(CompositeBwdArgs a) {
     z[IPL] = __shfl_down(z[0], 1, 64);
     const float zlast = a.ndc ? 1.f : 1e10f;
     float lsum = 0.f;
+    // depth_var = sum_j w_j (zeta_j - D)^2 also depends on w_k through D = sum_j w_j zeta_j / (A + eps):
+    // d var / d w_k = (zeta_k - D)^2 - 2 (zeta_k - D)/(A + eps) * sum_j w_j (zeta_j - D)
+    float sm = 0.f, ss = 0.f;
+    if (g.depth_var || g.depth_var_ndc) {
+#pragma unroll
+        for (int i = 0; i < IPL; ++i)
+            if (act[i]) {
+                const float wv_ = a.lvl.weights[n * S + k0 + i];
+                sm += wv_ * ((a.ndc ? metric_depth(z[i], oz, dz) : z[i]) - Dm);
+                ss += wv_ * (z[i] - Ds);
+            }
+        sm = wave_sum(sm); ss = wave_sum(ss);
+    }
 #pragma unroll
     for (int i = 0; i < IPL; ++i) {
         Gw[i] = 0.f; Tt[i] = 0.f; ww[i] = 0.f; term[i] = 0.f;
@@ -197,6 +214,8 @@ __global__ __launch_bounds__(RAY_WG) void k_composite_bwd(CompositeBwdArgs a) {
             for (int c = 0; c < 3; ++c) G += g_rgb[c] * a.lvl.raw_rgb[3 * ps + c];
             G += g_dep * (zmv - Dm) / den;
             G += g_dnd * (z[i] - Ds) / den;
+            G += g_var * ((zmv - Dm) * (zmv - Dm) - 2.f * sm * (zmv - Dm) / den);
+            G += g_vnd * ((z[i] - Ds) * (z[i] - Ds) - 2.f * ss * (z[i] - Ds) / den);
             for (int v = 0; v < V; ++v) G += g_v2[v] * (a.lvl.raw_vis2[ps * V + v] - V2[v]) / den;
             Gw[i] = G;
             term[i] = G * ww[i] + (g.visibility ? g.visibility[ps] * Tt[i] : 0.f);
@@ -297,7 +316,7 @@ __global__ __launch_bounds__(RAY_WG) void k_sample_fine(SampleArgs a) {
     for (int jj = lane; jj < Sf; jj += 64) {
         float u;
         if (a.u) u = a.u[nn * Sf + jj];
-        else if (a.device_rng) u = rng_uniform(a.seed, a.offset, RS_U, (uint64_t)(nn * Sf + jj));
+        else if (a.device_rng) u = rng_uniform(a.seed, a.offset, RS_U, (a.ray_ids ? (uint64_t)a.ray_ids[nn] : a.ray_base + (uint64_t)nn) * (uint64_t)Sf + (uint64_t)jj);
         else u = linspace01(jj, Sf);
         int cnt = 0;                                           // searchsorted(cdf, u, right=True): #{cdf <= u}
         for (int k = 0; k < NB; ++k) cnt += (cdf[k] <= u) ? 1 : 0;
@@ -337,11 +356,12 @@ int launch_sample_fine(const SampleArgs &a, hipStream_t st) {
 }
 
 int launch_coarse_z(int64_t N, int S, int lindisp, const float *near, const float *far, const float *t_rand,
-                    int device_rng, uint64_t seed, uint64_t offset, float *z_out, hipStream_t st) {
+                    int device_rng, uint64_t seed, uint64_t offset, uint64_t ray_base, const int64_t *ray_ids, float *z_out,
+                    hipStream_t st) {
     if (N <= 0) return VIPNERF_OK;
     const int64_t tot = N * S;
     hipLaunchKernelGGL(k_coarse_z, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, S, lindisp, near, far,
-                       t_rand, device_rng, seed, offset, z_out);
+                       t_rand, device_rng, seed, offset, ray_base, ray_ids, z_out);
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;
 }

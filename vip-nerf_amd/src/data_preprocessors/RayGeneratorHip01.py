@@ -2,7 +2,10 @@
 
 Mirrors the parts of the reference's DataPreprocessor (src/data_preprocessors/DataPreprocessor01.py) that sit
 immediately before and after the hot path:
-  get_next_batch(iter_num)        <- load_cached_next_batch :498-529 (+ :566-615, :702-724) for given ray indices
+  BatchIndexScheduler.next(iter)  <- generate_indices :248-265 + select_batch_indices :532-563 (host-side index schedule:
+                                     shuffled ray ids, pre-crop, epoch reshuffle, the sparse-depth rows' own schedule)
+  get_next_batch(iter_num)        <- load_cached_next_batch :498-529 (+ :566-615 nerf rows, :635-681 sparse-depth rows,
+                                     :702-724 visibility prior) for given ray indices
   create_test_data(pose, ...)     <- :776-864 (already pre-processed poses; the pose normalisation of :906-946 is a
                                      once-per-scene host computation and stays on the host)
   retrieve_inference_outputs(out) <- :866-894
@@ -28,11 +31,76 @@ from vipnerf_hip import _lib as L
 from vipnerf_hip import ops
 
 
+class BatchIndexScheduler:
+    """The reference's per-iteration ray-index schedule, on the host like the reference's (a few hundred bytes per step):
+    a shuffled array of flat ray ids frame*h*w + y*w + x, consumed `num_rays` at a time and reshuffled when exhausted
+    (select_batch_indices, DataPreprocessor01.py:532-543), optionally restricted to the central crop for the first
+    `precrop_iterations` iterations (generate_indices :248-265), plus -- when sparse depth is on -- a second shuffled
+    array of the pixels that have a depth, consumed `num_rays_sparse` at a time and appended (:549-557).
+
+    All shuffles are numpy.random.shuffle on numpy's GLOBAL generator, in the reference's order (ray ids first, then the
+    sparse-depth ids, DataPreprocessor01.py:231,239), so that after numpy.random.seed(s) the schedule is the reference's,
+    index for index (golden F6b).  Two behaviours of the reference are kept on purpose because they shape the schedule:
+    the last batch of an epoch is short (the slice runs off the end), and at iter_num == precrop_iterations the reference
+    draws a fresh full-frame permutation but discards it (:536-537 ignores generate_indices' return value), so the
+    cropped ids stay in use; `keep_reference_precrop_quirk=False` switches to the full frame there instead."""
+
+    def __init__(self, n_frames: int, h: int, w: int, num_rays: int, precrop_fraction: float = None,
+                 precrop_iterations: int = 0, sparse_depths=None, num_rays_sparse: int = 0,
+                 keep_reference_precrop_quirk: bool = True):
+        self.n, self.h, self.w = int(n_frames), int(h), int(w)
+        self.num_rays, self.num_rays_sparse = int(num_rays), int(num_rays_sparse)
+        self.precrop_fraction, self.precrop_iterations = precrop_fraction, int(precrop_iterations or 0)
+        self.quirk = keep_reference_precrop_quirk
+        self.i_batch = self.i_batch_sparse = 0
+        self.indices = self._generate(0)
+        self.indices_sparse = None
+        if sparse_depths is not None:
+            d = numpy.asarray(sparse_depths, dtype=numpy.float32).reshape(-1)
+            self.indices_sparse = numpy.where(d > 0)[0]
+            numpy.random.shuffle(self.indices_sparse)
+
+    def _generate(self, iter_num: int):
+        idx = numpy.arange(self.n * self.h * self.w)
+        f = self.precrop_fraction
+        if f is not None and f < 1 and iter_num < self.precrop_iterations:
+            h1, h2 = int(round(self.h / 2 * (1 - f))), int(round(self.h / 2 * (1 + f)))
+            w1, w2 = int(round(self.w / 2 * (1 - f))), int(round(self.w / 2 * (1 + f)))
+            idx = idx.reshape(self.n, self.h, self.w)[:, h1:h2, w1:w2].ravel()
+        numpy.random.shuffle(idx)
+        return idx
+
+    def next(self, iter_num: int):
+        """-> (flat ray ids of this iteration's rows (int64), row_is_sparse (bool)): nerf rows first, then sparse-depth rows."""
+        if self.precrop_fraction is not None and iter_num == self.precrop_iterations:
+            fresh = self._generate(iter_num)
+            if not self.quirk:
+                self.indices, self.i_batch = fresh, 0
+        idx = self.indices[self.i_batch:self.i_batch + self.num_rays]
+        self.i_batch += self.num_rays
+        if self.i_batch >= self.indices.size:
+            numpy.random.shuffle(self.indices)
+            self.i_batch = 0
+        is_sparse = numpy.zeros(idx.shape[0], dtype=bool)
+        if self.indices_sparse is not None:
+            sd = self.indices_sparse[self.i_batch_sparse:self.i_batch_sparse + self.num_rays_sparse]
+            self.i_batch_sparse += self.num_rays_sparse
+            if self.i_batch_sparse >= self.indices_sparse.size:
+                numpy.random.shuffle(self.indices_sparse)
+                self.i_batch_sparse = 0
+            idx = numpy.concatenate([idx, sd])
+            is_sparse = numpy.concatenate([is_sparse, numpy.ones(sd.shape[0], dtype=bool)])
+        return idx.astype(numpy.int64), is_sparse
+
+
 class RayGeneratorHip:
     def __init__(self, resolution, intrinsics, poses, near, far, ndc: bool, device, near_ndc=0.0, far_ndc=1.0,
-                 images: torch.Tensor = None, visibility_prior: torch.Tensor = None):
+                 images: torch.Tensor = None, visibility_prior: torch.Tensor = None, sparse_depths=None, sparse_errors=None,
+                 sparse_depths_ndc=None):
         """intrinsics (n,3,3), poses (n,4,4) (already normalised, float32 as the reference keeps them); images
-        (n,h,w,3) float32 in [0,1]; visibility_prior (n,n-1,h,w) float32 (masks or weights)."""
+        (n,h,w,3) float32 in [0,1]; visibility_prior (n,n-1,h,w) float32 (masks or weights); sparse_depths / sparse_errors
+        (n,h,w) per-pixel sparse depth and reprojection error, -1 where unknown (preprocess_raw_sparse_depth_data,
+        DataPreprocessor01.py:161-184); sparse_depths_ndc: computed here like :431-436 when not given."""
         self.h, self.w = int(resolution[0]), int(resolution[1])
         self.ndc, self.device = bool(ndc), torch.device(device)
         self.near, self.far, self.near_ndc, self.far_ndc = float(near), float(far), float(near_ndc), float(far_ndc)
@@ -54,8 +122,32 @@ class RayGeneratorHip:
         self.poses = torch.from_numpy(self.poses_np).to(self.device)
         self.images = ops.f32c(images.to(self.device)) if images is not None else None
         self.prior = ops.f32c(visibility_prior.to(self.device)) if visibility_prior is not None else None
+        self.sparse_depths = self.sparse_errors = self.sparse_depths_ndc = None
+        if sparse_depths is not None:
+            sd = numpy.asarray(sparse_depths, dtype=numpy.float32).reshape(-1)
+            self.sparse_depths = torch.from_numpy(sd).to(self.device)
+            if sparse_errors is not None:
+                self.sparse_errors = torch.from_numpy(numpy.asarray(sparse_errors, dtype=numpy.float32).reshape(-1).copy()).to(self.device)
+            if self.ndc:
+                if sparse_depths_ndc is None:
+                    sparse_depths_ndc = self._depths_to_ndc(sd)
+                self.sparse_depths_ndc = torch.from_numpy(numpy.asarray(sparse_depths_ndc, dtype=numpy.float32).reshape(-1).copy()).to(self.device)
 
-    def _generate(self, n_rays, indices=None, first_index=0, want_targets=False, want_o2=False):
+    def _depths_to_ndc(self, depths: numpy.ndarray) -> numpy.ndarray:
+        """preprocess_sparse_depth_data / convert_depth_to_ndc (DataPreprocessor01.py:431-446) -- once per scene, on the
+        host in numpy float32 exactly as the reference evaluates it (near is hard-coded to 1 there), from the rays of
+        all n*h*w pixels as the device kernel generates them (bit-identical to the reference's ray cache)."""
+        full = self._generate(self.n * self.h * self.w)
+        oz = full['rays_o'][:, 2:].cpu().numpy()
+        dz = full['rays_d'][:, 2:].cpu().numpy()
+        d = depths.reshape(-1, 1)
+        tn = -(1 + oz) / dz
+        oz_prime = oz + tn * dz
+        out = 1 - oz_prime / (oz_prime + (d - tn) * dz)
+        out[d == -1] = -1
+        return out.astype(numpy.float32)
+
+    def _generate(self, n_rays, indices=None, first_index=0, want_targets=False, want_o2=False, row_is_sparse=None):
         lib = L.load()
         dev = self.device
         e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -69,6 +161,11 @@ class RayGeneratorHip:
             b['visibility_prior_masks'] = e(n_rays, self.n - 1)
         if want_o2 and self.n > 1:
             b['rays_o2'] = e(n_rays, self.n - 1, 3)
+        if row_is_sparse is not None:
+            b['sparse_depth_values'] = e(n_rays, 1)
+            b['sparse_depth_errors'] = e(n_rays, 1)
+            if self.ndc:
+                b['sparse_depth_values_ndc'] = e(n_rays, 1)
         g = L.RayGen()
         g.height, g.width, g.n_frames, g.ndc = self.h, self.w, self.n, int(self.ndc)
         g.near, g.far, g.near_ndc, g.far_ndc = self.near, self.far, self.near_ndc, self.far_ndc
@@ -79,23 +176,49 @@ class RayGeneratorHip:
         g.first_index = int(first_index)
         g.images = self.images.data_ptr() if self.images is not None else None
         g.prior = self.prior.data_ptr() if self.prior is not None else None
+        if row_is_sparse is not None:
+            row_is_sparse = row_is_sparse.to(device=dev, dtype=torch.uint8).contiguous()
+            g.row_is_sparse = row_is_sparse.data_ptr()
+            g.sparse_depths = self.sparse_depths.data_ptr() if self.sparse_depths is not None else None
+            g.sparse_errors = self.sparse_errors.data_ptr() if self.sparse_errors is not None else None
+            g.sparse_depths_ndc = self.sparse_depths_ndc.data_ptr() if self.sparse_depths_ndc is not None else None
         rb = L.RayBatch()
         names = {'visibility_prior_masks': 'prior'}
         for k, t in b.items():
             setattr(rb, names.get(k, k), t.data_ptr())
         if n_rays > 0:
-            L.check(lib.vipnerf_generate_rays(C.byref(g), n_rays, C.byref(rb), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                    'vipnerf_generate_rays')
+            with ops.on_device(*b.values(), self.cameras, indices, row_is_sparse) as d:
+                L.check(lib.vipnerf_generate_rays(C.byref(g), n_rays, C.byref(rb), ops._stream(d)), 'vipnerf_generate_rays')
         return b
 
     # ---- training side -----------------------------------------------------------------------------------
-    def get_next_batch(self, iter_num: int, indices: torch.Tensor):
-        """indices: flat ray ids (frame*h*w + y*w + x), e.g. a slice of the reference's shuffled index array."""
-        b = self._generate(indices.shape[0], indices=indices, want_targets=True)
+    def get_next_batch(self, iter_num: int, indices=None, row_is_sparse=None, scheduler: 'BatchIndexScheduler' = None):
+        """The training batch dict of load_cached_next_batch (DataPreprocessor01.py:498-529).  indices: flat ray ids
+        (frame*h*w + y*w + x) of the rows, nerf rows first; row_is_sparse: bool per row, True = sparse-depth row (:549-563);
+        or pass a BatchIndexScheduler and both come from its next(iter_num)."""
+        if indices is None:
+            if scheduler is None:
+                raise L.VipNerfHipError('get_next_batch needs either ray indices or a BatchIndexScheduler')
+            indices, row_is_sparse = scheduler.next(iter_num)
+        if isinstance(indices, numpy.ndarray):
+            indices = torch.from_numpy(indices)
+        indices = indices.to(self.device)
+        sparse_on = self.sparse_depths is not None
+        if row_is_sparse is None and sparse_on:
+            row_is_sparse = numpy.zeros(indices.shape[0], dtype=bool)
+        if row_is_sparse is not None:
+            if isinstance(row_is_sparse, numpy.ndarray):
+                row_is_sparse = torch.from_numpy(row_is_sparse)
+            row_is_sparse = row_is_sparse.to(self.device).bool()
+        b = self._generate(indices.shape[0], indices=indices, want_targets=True, row_is_sparse=row_is_sparse if sparse_on else None)
         b['iter_num'] = iter_num
         b['num_frames'] = self.n
         b['indices'] = indices
-        b['indices_mask_nerf'] = torch.ones(indices.shape[0], dtype=torch.bool, device=self.device)
+        if row_is_sparse is not None and sparse_on:
+            b['indices_mask_nerf'] = ~row_is_sparse
+            b['indices_mask_sparse_depth'] = row_is_sparse
+        else:
+            b['indices_mask_nerf'] = torch.ones(indices.shape[0], dtype=torch.bool, device=self.device)
         b['common_data'] = {'poses': self.poses[None]}
         return b
 
@@ -121,13 +244,14 @@ class RayGeneratorHip:
             res['depth_var_ndc'] = torch.empty(self.h, self.w, device=dev)
         keep = [ops.f32c(out[f'rgb{sfx}']), ops.f32c(out[f'depth{sfx}']), ops.f32c(out[f'depth_var{sfx}']),
                 ops.f32c(dn) if dn is not None else None, ops.f32c(dvn) if dvn is not None else None]
-        L.check(lib.vipnerf_postprocess_frame(hw, keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(),
-                                              keep[3].data_ptr() if keep[3] is not None else None,
-                                              keep[4].data_ptr() if keep[4] is not None else None,
-                                              image.data_ptr(), res['depth'].data_ptr(), res['depth_var'].data_ptr(),
-                                              res['depth_ndc'].data_ptr() if self.ndc else None,
-                                              res['depth_var_ndc'].data_ptr() if self.ndc else None,
-                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'vipnerf_postprocess_frame')
+        with ops.on_device(*keep, image):
+            L.check(lib.vipnerf_postprocess_frame(hw, keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(),
+                                                  keep[3].data_ptr() if keep[3] is not None else None,
+                                                  keep[4].data_ptr() if keep[4] is not None else None,
+                                                  image.data_ptr(), res['depth'].data_ptr(), res['depth_var'].data_ptr(),
+                                                  res['depth_ndc'].data_ptr() if self.ndc else None,
+                                                  res['depth_var_ndc'].data_ptr() if self.ndc else None,
+                                                  ops._stream(dev)), 'vipnerf_postprocess_frame')
         if f'visibility2{sfx}' in out:
             res['visibility2'] = out[f'visibility2{sfx}'].reshape(self.h, self.w, -1).permute(2, 0, 1).contiguous()
         return res

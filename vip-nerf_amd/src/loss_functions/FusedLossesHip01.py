@@ -1,6 +1,9 @@
 """Shared evaluation of the four ray losses on the GPU.  The first drop-in loss class asked for its value in an
 iteration runs ONE fused kernel (vipnerf_losses_forward) over the model's output dict and caches the eight
-loss scalars on that dict; the other classes read them.  Autograd sees a single node whose backward scales the
+loss scalars; the other classes read them.  The cache is an attribute of the `rgb_coarse` output tensor, NOT an entry of
+output_dict: the reference's trainer walks every key of the output dict (Trainer01.py:147-172 merge_output_batches_
+raises on anything that is not a Tensor or dict, and would torch.cat an (8,) vector across chunks as if it were per-ray
+data), so the dict must keep exactly the reference's key set.  Autograd sees a single node whose backward scales the
 kernel's precomputed gradient seeds by each loss's weight."""
 import os
 import sys
@@ -17,15 +20,17 @@ except ImportError:
 from vipnerf_hip import ops
 from vipnerf_hip.autograd import FusedLossFunction
 
-CACHE_KEY = '_vipnerf_hip_fused_losses'
+CACHE_ATTR = '_vipnerf_hip_fused_losses'     # attribute of output_dict['rgb_coarse']: (vector (8,), its unbind() tuple)
 
 
 def fused_loss_values(configs: dict, input_dict: dict, output_dict: dict):
     """-> 8 scalar tensors: [mse_c, mse_f, vis_c, vis_f, prior_c, prior_f, sparse_depth, 0] (unweighted).  They are
     the unbind() of the kernel's result vector, so that autograd sees one Unbind node instead of one Select node (a
     zeros + a copy kernel) per value a loss class picks."""
-    if CACHE_KEY in output_dict:
-        return output_dict[CACHE_KEY]
+    anchor = output_dict['rgb_coarse']
+    cached = getattr(anchor, CACHE_ATTR, None)
+    if cached is not None:
+        return cached[1]
     m = configs['model']
     fine = 'fine_mlp' in m
     n = output_dict['rgb_coarse'].shape[0]
@@ -49,13 +54,12 @@ def fused_loss_values(configs: dict, input_dict: dict, output_dict: dict):
                 output_dict.get(f'visibility2_{lv}'), output_dict[f'depth_{lv}'])
     vals = FusedLossFunction.apply(cfg, n, input_dict['target_rgb'], input_dict['indices_mask_nerf'], prior, mask_sd, sd,
                                    *level('coarse'), *(level('fine') if fine else (None,) * 5))
-    output_dict[CACHE_KEY + '_vector'] = vals
-    vals = vals.unbind(0)
-    output_dict[CACHE_KEY] = vals
-    return vals
+    parts = vals.unbind(0)
+    setattr(anchor, CACHE_ATTR, (vals, parts))
+    return parts
 
 
 def fused_loss_vector(configs: dict, input_dict: dict, output_dict: dict):
     """The same eight values as ONE tensor of shape (8,) (what a weighted total can be taken from with a single dot)."""
     fused_loss_values(configs, input_dict, output_dict)
-    return output_dict[CACHE_KEY + '_vector']
+    return getattr(output_dict['rgb_coarse'], CACHE_ATTR)[0]

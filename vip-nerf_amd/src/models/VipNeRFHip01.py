@@ -71,7 +71,8 @@ class VipNeRFHip(torch.nn.Module):
         self.predict_visibility = True
         self.coarse_model = MLPParams(configs, m['coarse_mlp'])
         self.fine_model = MLPParams(configs, m['fine_mlp']) if self.fine_mlp_needed else None
-        self._calls = 0
+        self._calls = 0                 # Philox offset when the caller supplies no iter_num
+        self._last_iter, self._sub = None, 0
         # parity hooks (tests): injected random numbers / teacher-forced fine depths for the next forward
         self.injected_rng = None
         self.injected_z_fine = None
@@ -83,6 +84,29 @@ class VipNeRFHip(torch.nn.Module):
                 if isinstance(input_batch['common_data'][key], torch.Tensor):
                     input_batch['common_data'][key] = input_batch['common_data'][key][0]
         return self.render_rays(input_batch, retraw or self.training, sec_views_vis or self.training)
+
+    def _rng_key(self, input_dict: dict, dev: torch.device):
+        """(seed, offset, ray_base) of this call's Philox streams (the reference draws torch.rand / torch.randn on the CPU
+        generator inside the loop, VipNeRF01.py:200,242,551).  seed = the process's torch seed; offset = a pure function of
+        `iter_num` and the index of the call within the iteration (the trainer's sub-batches, Trainer01.py:83-97), so a
+        resumed run continues the stream and nothing depends on module state that DataParallel replicas or checkpoints
+        would lose; ray_base = position of this call's ray 0 in the global batch (`rng_ray_base`, set by
+        vipnerf_hip.dist.shard_batch for ray-sharded ranks: R ranks draw what one process would draw for the whole batch)."""
+        seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+        if getattr(self, '_is_replica', False) and dev.index:      # thread-per-device nn.DataParallel replicas see only
+            seed = (seed ^ (dev.index * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF   # their slice: decorrelate by device
+        it = input_dict.get('iter_num')
+        if it is None:
+            offset = (1 << 62) | self._calls
+            self._calls += 1
+        else:
+            it = int(it)
+            if it == self._last_iter:
+                self._sub += 1
+            else:
+                self._last_iter, self._sub = it, 0
+            offset = (it << 16) | (self._sub & 0xFFFF)
+        return seed, offset, int(input_dict.get('rng_ray_base', 0))
 
     def render(self, input_dict: dict, retraw: bool, sec_views_vis: bool):
         return self.render_rays(input_dict, retraw, sec_views_vis)
@@ -127,10 +151,14 @@ class VipNeRFHip(torch.nn.Module):
         rng = None
         if train:
             rng = dict(self.injected_rng) if self.injected_rng is not None else {}
-            rng.setdefault('seed', torch.initial_seed() & 0xFFFFFFFFFFFFFFFF)
-            rng.setdefault('offset', self._calls)
-        self._calls += 1
-        state = RenderState(cfg, batch, rng, self.injected_z_fine)
+            seed, offset, ray_base = self._rng_key(input_dict, rays_o.device)
+            rng.setdefault('seed', seed)
+            rng.setdefault('offset', offset)
+            rng.setdefault('ray_base', ray_base)
+            if input_dict.get('rng_ray_ids') is not None:
+                rng.setdefault('ray_ids', input_dict['rng_ray_ids'])
+        max_ws = m.get('hip_max_workspace_bytes', os.environ.get('VIPNERF_MAX_WORKSPACE_BYTES'))
+        state = RenderState(cfg, batch, rng, self.injected_z_fine, None if max_ws is None else int(max_ws))
         params = self.coarse_model.ordered_params() + (self.fine_model.ordered_params() if self.fine_mlp_needed else [])
         outs = RenderFunction.apply(state, *params)
         d = dict(zip(state.keys, outs))

@@ -19,6 +19,7 @@ except ImportError:
         if cand and cand not in sys.path:
             sys.path.insert(0, cand)
 from vipnerf_hip import _lib as L
+from vipnerf_hip import ops
 
 
 class VisibilityWeightsComputerHip:
@@ -51,8 +52,9 @@ class VisibilityWeightsComputerHip:
         p.planes, p.frame1, p.frame2 = d_planes.data_ptr(), f1.data_ptr(), f2.data_ptr()
         w64 = torch.empty(h, w, dtype=torch.float64, device=self.device)
         mask = torch.empty(h, w, dtype=torch.uint8, device=self.device)
-        L.check(lib.vipnerf_visibility_prior(C.byref(p), w64.data_ptr(), None, mask.data_ptr(),
-                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'vipnerf_visibility_prior')
+        with ops.on_device(d_planes, f1, f2, w64, mask) as dev:
+            L.check(lib.vipnerf_visibility_prior(C.byref(p), w64.data_ptr(), None, mask.data_ptr(), ops._stream(dev)),
+                    'vipnerf_visibility_prior')
         return w64, mask
 
     def compute_weights(self, frame1, frame2, extrinsic1, extrinsic2, intrinsic1, intrinsic2, min_depth: float, max_depth: float):

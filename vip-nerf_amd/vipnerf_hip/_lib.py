@@ -8,7 +8,7 @@ import os
 
 VIPNERF_MAX_SEC = 3
 VIPNERF_N_PARAMS = 24
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VIPNERF_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libvipnerf_hip.so')
@@ -34,7 +34,7 @@ class Rays(C.Structure):
 
 class Rng(C.Structure):
     _fields_ = [('t_rand', c_f), ('u', c_f), ('noise_coarse', c_f), ('noise_fine', c_f),
-                ('seed', C.c_uint64), ('offset', C.c_uint64)]
+                ('seed', C.c_uint64), ('offset', C.c_uint64), ('ray_base', C.c_uint64), ('ray_ids', c_f)]
 
 
 class MlpParams(C.Structure):
@@ -58,7 +58,7 @@ class Outputs(C.Structure):
 
 
 LEVEL_GRAD_FIELDS = ['rgb', 'acc', 'depth', 'depth_ndc', 'vis2', 'visibility', 'weights', 'alpha', 'raw_sigma',
-                     'raw_rgb', 'raw_vis', 'raw_vis2']
+                     'raw_rgb', 'raw_vis', 'raw_vis2', 'depth_var', 'depth_var_ndc']
 
 
 class LevelGrads(C.Structure):
@@ -89,11 +89,13 @@ class Camera(C.Structure):
 class RayGen(C.Structure):
     _fields_ = [('height', C.c_int32), ('width', C.c_int32), ('n_frames', C.c_int32), ('ndc', C.c_int32),
                 ('near', C.c_float), ('far', C.c_float), ('near_ndc', C.c_float), ('far_ndc', C.c_float),
-                ('cameras', c_f), ('indices', c_f), ('first_index', C.c_int64), ('images', c_f), ('prior', c_f)]
+                ('cameras', c_f), ('indices', c_f), ('first_index', C.c_int64), ('images', c_f), ('prior', c_f),
+                ('row_is_sparse', c_f), ('sparse_depths', c_f), ('sparse_errors', c_f), ('sparse_depths_ndc', c_f)]
 
 
 RAY_BATCH_FIELDS = ['rays_o', 'rays_d', 'view_dirs', 'rays_o_ndc', 'rays_d_ndc', 'near', 'far', 'near_ndc', 'far_ndc',
-                    'pixel_id', 'target_rgb', 'prior', 'rays_o2']
+                    'pixel_id', 'target_rgb', 'prior', 'rays_o2', 'sparse_depth_values', 'sparse_depth_errors',
+                    'sparse_depth_values_ndc']
 
 
 class RayBatch(C.Structure):
@@ -134,6 +136,9 @@ SYMBOLS = {
     'vipnerf_generate_rays': (C.c_int32, [P(RayGen), C.c_int64, P(RayBatch), c_f]),
     'vipnerf_postprocess_frame': (C.c_int32, [C.c_int64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     'vipnerf_visibility_prior': (C.c_int32, [P(Psv), c_f, c_f, c_f, c_f]),
+    'vipnerf_secondary_dirs': (C.c_int32, [P(Config), P(Rays), C.c_int32, c_f, c_f, c_f]),
+    'vipnerf_philox4x32_10': (C.c_int32, [C.c_int64, c_f, c_f, c_f, c_f]),
+    'vipnerf_rng_draw': (C.c_int32, [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int64, c_f, c_f]),
     'vipnerf_profile_enable': (C.c_int32, [C.c_int32]),
     'vipnerf_profile_read': (C.c_int32, [P(ProfileEntry), C.c_int32, P(C.c_int32)]),
 }

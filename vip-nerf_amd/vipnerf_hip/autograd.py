@@ -11,14 +11,17 @@ from . import ops
 # outputs of one level, in the order RenderFunction returns them
 LEVEL_KEYS = ['z_vals', 'raw_sigma', 'raw_rgb', 'raw_vis', 'raw_vis2', 'alpha', 'visibility', 'weights', 'rgb',
               'acc', 'depth', 'depth_var', 'depth_ndc', 'depth_var_ndc', 'vis2']
-NON_DIFF = {'z_vals', 'depth_var', 'depth_var_ndc'}   # no loss of the reference differentiates these
+NON_DIFF = {'z_vals'}   # sample depths carry no gradient in the reference either (VipNeRF01.py:213 detaches the samples)
 
 
 class RenderState:
     """Per-call, non-tensor state handed through RenderFunction.apply."""
 
-    def __init__(self, cfg: L.Config, batch: Dict[str, torch.Tensor], rng: Optional[dict], z_fine=None):
+    def __init__(self, cfg: L.Config, batch: Dict[str, torch.Tensor], rng: Optional[dict], z_fine=None,
+                 max_workspace_bytes: Optional[int] = None):
         self.cfg, self.batch, self.rng, self.z_fine = cfg, batch, rng, z_fine
+        self.max_workspace_bytes = max_workspace_bytes   # None = what the device has free right now
+        self.recompute_chunk = 0                         # > 0: backward re-renders the batch in ray chunks of this size
         self.grad_enabled = torch.is_grad_enabled()     # captured outside Function.forward, where it is always off
         self.keys: List[str] = []        # '<key>_<level>' of every returned tensor, in order
         self.extras: dict = {}
@@ -39,8 +42,12 @@ class RenderFunction(torch.autograd.Function):
         acts = None
         n = state.batch['rays_o'].shape[0]
         if need_bwd:
-            ab, _ = ops.query_workspace(cfg, n)
-            acts = torch.empty(ab // 4, dtype=torch.float32, device=params[0].device)
+            ab, bb = ops.query_workspace(cfg, n)
+            state.recompute_chunk = _recompute_chunk(state, n, ab, bb, params[0].device)
+            if state.recompute_chunk:
+                cfg.save_acts = 0        # the activation store would not fit: backward re-renders chunk by chunk
+            else:
+                acts = torch.empty(ab // 4, dtype=torch.float32, device=params[0].device)
         coarse, fine, extras = ops.render_forward(cfg, state.batch, state.rng, pc, pf, acts, state.z_fine)
         state.extras = {k: v for k, v in extras.items() if not k.startswith('_')}
         outs, keys, nondiff = [], [], []
@@ -56,13 +63,19 @@ class RenderFunction(torch.autograd.Function):
         state.keys = keys
         ctx.mark_non_differentiable(*nondiff)
         ctx.set_materialize_grads(False)          # outputs no loss touches arrive as None (= NULL = zero in the ABI)
-        ctx.state, ctx.coarse, ctx.fine, ctx.acts, ctx.packed = state, coarse, fine, acts, (pc, pf)
+        # what backward needs of the outputs is kept as DETACHED aliases: the returned tensors carry this node as grad_fn, so
+        # holding them on ctx would be a reference cycle through C++ that only the cyclic GC frees (~50 MB of (N,S) outputs
+        # per 4096-ray step lingering for a nondeterministic time)
+        det = lambda d: None if d is None else {k: v.detach() for k, v in d.items()}
+        ctx.state, ctx.coarse, ctx.fine, ctx.acts, ctx.packed = state, det(coarse), det(fine), acts, (pc, pf)
         ctx.n_params = len(params)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gouts):
         state, cfg = ctx.state, ctx.state.cfg
+        if state.recompute_chunk:
+            return _chunked_backward(ctx, gouts)
         if ctx.acts is None:
             raise L.VipNerfHipError('backward called on a forward that did not save activations')
         gl = {'coarse': {}, 'fine': {}}
@@ -91,8 +104,95 @@ class RenderFunction(torch.autograd.Function):
         del views, flat
         ops.render_backward(cfg, state.batch, ctx.packed[0], ctx.packed[1], ctx.coarse, ctx.fine, gl['coarse'],
                             gl['fine'] if ctx.fine is not None else None, ctx.acts, bwd_ws, gc, gf)
-        ctx.acts = None
+        ctx.acts = ctx.coarse = ctx.fine = ctx.packed = None
         return (None, *gc, *(gf or []))
+
+
+def _recompute_chunk(state: RenderState, n: int, acts_bytes: int, bwd_bytes: int, dev) -> int:
+    """0 if the training workspace of an n-ray call (activation store + backward scratch, ~ 5 MB per ray) fits the
+    budget, else the ray-chunk size for a re-rendering backward.  The reference bounds memory with its `chunk` host loop
+    only in eval (every chunk's autograd graph stays alive in training, VipNeRF01.py:47-72); here a call that does not fit
+    keeps NO activations in the forward and its backward re-renders the rays chunk by chunk (one extra forward), with the
+    very same random numbers: the Philox streams are keyed by global ray index (vipnerf_rng.ray_base / ray_ids)."""
+    limit = state.max_workspace_bytes
+    if limit is None:
+        free, _ = torch.cuda.mem_get_info(dev)
+        cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        limit = int(0.8 * (free + cached))
+    if acts_bytes + bwd_bytes <= limit or n <= 256:
+        return 0
+    per_ray = (acts_bytes + bwd_bytes) / n
+    chunk = int(limit / per_ray) // 256 * 256
+    c = L.Config.from_buffer_copy(state.cfg)
+    c.save_acts = 1
+    while chunk >= 256 and sum(ops.query_workspace(c, chunk)) > limit:      # the scratch is not exactly linear in n
+        chunk -= 256
+    if chunk < 256:
+        raise L.VipNerfHipError(f'training workspace: {acts_bytes + bwd_bytes} bytes for {n} rays ({per_ray / 1e6:.1f} MB per ray) and '
+                                f'not even a 256-ray chunk fits the {limit} bytes available; lower configs["sub_batch_size"]')
+    return 0 if chunk >= n else chunk
+
+
+def _slice_rows(d: Optional[dict], n: int, s: int, e: int) -> Optional[dict]:
+    if d is None:
+        return None
+    return {k: (v[s:e] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == n else v) for k, v in d.items()}
+
+
+def _chunked_backward(ctx, gouts):
+    """Backward of a forward that kept no activations: per ray chunk, re-render WITH the activation store (same weights,
+    same random numbers, the forward's fine depths), run the fused backward, and add up the parameter gradients."""
+    state, cfg = ctx.state, ctx.state.cfg
+    n = state.batch['rays_o'].shape[0]
+    dev = ctx.coarse['rgb'].device
+    two = ctx.fine is not None
+    gl = {'coarse': {}, 'fine': {}}
+    for key, g in zip(state.keys, gouts):
+        if g is not None:
+            k, lv = key.rsplit('_', 1)
+            gl[lv][k] = g
+    sizes = [int(torch.Size(s).numel()) for s in ops.PARAM_SHAPES]
+    levels = 2 if two else 1
+
+    def flat_views():
+        flat = torch.empty(levels * sum(sizes), dtype=torch.float32, device=dev)
+        views, o = [], 0
+        for _ in range(levels):
+            for s, k in zip(ops.PARAM_SHAPES, sizes):
+                views.append(flat[o:o + k].view(s))
+                o += k
+        return flat, views
+
+    total, views = flat_views()
+    tmp, tviews = flat_views()
+    base = int(state.rng.get('ray_base', 0)) if state.rng else 0
+    chunk = state.recompute_chunk
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        c = L.Config.from_buffer_copy(cfg)
+        c.save_acts = 1
+        sub = _slice_rows(state.batch, n, s, e)
+        rng = None
+        if state.rng is not None:
+            rng = {k: (v.reshape(n, -1)[s:e] if k in ('t_rand', 'u', 'noise_coarse', 'noise_fine', 'ray_ids') and v is not None
+                       else v) for k, v in state.rng.items()}
+            if rng.get('ray_ids') is not None:
+                rng['ray_ids'] = rng['ray_ids'].reshape(-1)
+            rng['ray_base'] = base + s
+        ab, bb = ops.query_workspace(c, e - s)
+        acts = torch.empty(ab // 4, dtype=torch.float32, device=dev)
+        zf = ctx.fine['z_vals'][s:e] if two else None
+        coarse, fine, _ = ops.render_forward(c, sub, rng, ctx.packed[0], ctx.packed[1], acts, zf)
+        bwd_ws = torch.empty(bb // 4, dtype=torch.float32, device=dev)
+        dst = views if s == 0 else tviews
+        ops.render_backward(c, sub, ctx.packed[0], ctx.packed[1], coarse, fine, _slice_rows(gl['coarse'], n, s, e),
+                            _slice_rows(gl['fine'], n, s, e) if two else None, acts, bwd_ws, dst[:len(sizes)],
+                            dst[len(sizes):] if two else None)
+        if s > 0:
+            total.add_(tmp)
+        del acts, bwd_ws, coarse, fine
+    ctx.acts = ctx.coarse = ctx.fine = ctx.packed = None
+    return (None, *views)
 
 
 class FusedLossFunction(torch.autograd.Function):

@@ -102,6 +102,54 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0):
 
 
 def shard_rows(n_rows: int, rank: int, world: int):
-    """Equal contiguous shards (the caller keeps n_rows divisible by world so that loss means stay exact)."""
+    """Equal contiguous shards of ONE row class (the caller keeps n_rows divisible by world so that loss means stay
+    exact).  Batches that mix row classes go through shard_batch."""
+    if n_rows % world:
+        raise ValueError(f'{n_rows} rows do not split evenly over {world} ranks: every loss is a mean over its own rows, so '
+                         f'unequal shards would make the mean of the rank means differ from the global mean')
     per = n_rows // world
     return slice(rank * per, (rank + 1) * per)
+
+
+def shard_row_ids(batch: dict, rank: int, world: int) -> torch.Tensor:
+    """Global row indices of rank `rank`'s share of a batch with the reference's layout -- nerf rows, then sparse-depth
+    rows (select_batch_indices, DataPreprocessor01.py:544-563).  Each class is split separately into `world` equal
+    contiguous parts, so that every rank holds N_nerf/R + N_sd/R rows: MSE / VisibilityPrior average over the nerf rows
+    (MSE01.py:55-59, VisibilityPriorLoss01.py:74-80), SparseDepthMSE over the sparse-depth rows (SparseDepthMSE01.py:59-63)
+    and VisibilityLoss over all rows -- with equal per-class counts on every rank the mean of the rank means IS the global
+    mean and averaging the gradients is exact."""
+    n = batch['rays_o'].shape[0]
+    dev = batch['rays_o'].device
+    m_nerf = batch.get('indices_mask_nerf')
+    m_sd = batch.get('indices_mask_sparse_depth')
+    if m_sd is None and (m_nerf is None or bool(m_nerf.all())):
+        s = shard_rows(n, rank, world)
+        return torch.arange(s.start, s.stop, device=dev)
+    m_nerf = m_nerf.bool() if m_nerf is not None else torch.ones(n, dtype=torch.bool, device=dev)
+    m_sd = m_sd.bool() if m_sd is not None else torch.zeros(n, dtype=torch.bool, device=dev)
+    parts = []
+    for name, m in (('nerf', m_nerf & ~m_sd), ('sparse-depth', m_sd), ('unclassified', ~m_nerf & ~m_sd)):
+        ids = torch.nonzero(m, as_tuple=False)[:, 0]
+        if ids.numel() % world:
+            raise ValueError(f'{ids.numel()} {name} rows do not split evenly over {world} ranks')
+        per = ids.numel() // world
+        parts.append(ids[rank * per:(rank + 1) * per])
+    return torch.cat(parts)
+
+
+def shard_batch(batch: dict, rank: int, world: int) -> dict:
+    """This rank's shard of a global batch dict (row-class aware, see shard_row_ids).  Every tensor whose first dimension is
+    the row count is indexed; `common_data` and scalars are shared.  `rng_ray_ids` carries the rows' global indices so
+    that the on-device Philox streams of the R shards are exactly the streams one process would draw for the whole batch."""
+    n = batch['rays_o'].shape[0]
+    ids = shard_row_ids(batch, rank, world)
+    out = {}
+    for k, v in batch.items():
+        if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == n and k != 'common_data':
+            out[k] = v[ids.to(v.device)]
+        elif k == 'common_data':
+            out[k] = dict(v)
+        else:
+            out[k] = v
+    out['rng_ray_ids'] = ids if 'rng_ray_ids' not in batch else batch['rng_ray_ids'][ids.to(batch['rng_ray_ids'].device)]
+    return out

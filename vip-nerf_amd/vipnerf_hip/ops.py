@@ -15,8 +15,31 @@ PARAM_SHAPES = ([s for i in range(8) for s in ((256, 63 if i == 0 else (319 if i
                 [(128, 283), (128,), (1, 256), (1,), (256, 256), (256,), (4, 128), (4,)])
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(dev=None):
+    """hipStream_t of PyTorch's current stream ON THE DEVICE THE TENSORS LIVE ON (not on the thread's current device:
+    the reference builds `cuda:{device[0]}` without torch.cuda.set_device, Trainer01.py:58 / CommonUtils01.py:15-27)."""
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class on_device:
+    """`with on_device(t0, t1, ...) as dev:` -- makes the tensors' device the current HIP device for the enclosed ABI
+    calls (the library launches on the calling thread's current device) and rejects inputs on different devices."""
+
+    def __init__(self, *tensors):
+        devs = {t.device for t in tensors if isinstance(t, torch.Tensor)}
+        if len(devs) != 1:
+            raise L.VipNerfHipError(f'all tensors of one call must live on one GPU (got {sorted(str(d) for d in devs)})')
+        self.dev = devs.pop()
+        if self.dev.type != 'cuda':
+            raise L.VipNerfHipError(f'tensors must live on the GPU (got {self.dev}); there is no CPU fallback')
+        self.guard = torch.cuda.device(self.dev)
+
+    def __enter__(self):
+        self.guard.__enter__()
+        return self.dev
+
+    def __exit__(self, *exc):
+        return self.guard.__exit__(*exc)
 
 
 def _p(t: Optional[torch.Tensor], dtype=torch.float32, name='tensor'):
@@ -69,9 +92,10 @@ def pack_weights(params: List[torch.Tensor], out: Optional[torch.Tensor] = None,
         tc = f32c(t)
         keep.append(tc)
         mp.p[i] = _p(tc, name=PARAM_ORDER[i])
-    if out is None:
-        out = torch.empty(packed_bytes(precision) // 4, dtype=torch.float32, device=params[0].device)
-    L.check(lib.vipnerf_pack_weights_p(C.byref(mp), int(precision), _p(out), _stream()), 'vipnerf_pack_weights_p')
+    with on_device(*keep) as dev:
+        if out is None:
+            out = torch.empty(packed_bytes(precision) // 4, dtype=torch.float32, device=dev)
+        L.check(lib.vipnerf_pack_weights_p(C.byref(mp), int(precision), _p(out), _stream(dev)), 'vipnerf_pack_weights_p')
     return out
 
 
@@ -164,12 +188,20 @@ def render_forward(cfg: L.Config, batch: Dict[str, torch.Tensor], rng: Optional[
                 tc = f32c(rng[k])
                 keep.append(tc)
                 setattr(rs, k, _p(tc, name=k))
-        rs.seed = int(rng.get('seed', 0))
-        rs.offset = int(rng.get('offset', 0))
-    L.check(lib.vipnerf_render_forward(C.byref(cfg), C.byref(rays), C.byref(rs) if rs is not None else None,
-                                       _p(packed_coarse), _p(packed_fine) if packed_fine is not None else None,
-                                       C.byref(out), _p(acts) if acts is not None else None, _stream()),
-            'vipnerf_render_forward')
+        rs.seed = int(rng.get('seed', 0)) & 0xFFFFFFFFFFFFFFFF
+        rs.offset = int(rng.get('offset', 0)) & 0xFFFFFFFFFFFFFFFF
+        rs.ray_base = int(rng.get('ray_base', 0))
+        if rng.get('ray_ids') is not None:
+            ids = rng['ray_ids'].to(device=dev, dtype=torch.int64).contiguous()
+            if ids.numel() != n:
+                raise RuntimeError(f"render_forward: rng['ray_ids'] has {ids.numel()} elements, {n} expected")
+            keep.append(ids)
+            rs.ray_ids = _p(ids, torch.int64, name='ray_ids')
+    with on_device(*keep, packed_coarse, packed_fine, acts) as dev:
+        L.check(lib.vipnerf_render_forward(C.byref(cfg), C.byref(rays), C.byref(rs) if rs is not None else None,
+                                           _p(packed_coarse), _p(packed_fine) if packed_fine is not None else None,
+                                           C.byref(out), _p(acts) if acts is not None else None, _stream(dev)),
+                'vipnerf_render_forward')
     extras['_keep'] = keep
     return coarse, fine, extras
 
@@ -201,11 +233,12 @@ def render_backward(cfg: L.Config, batch, packed_coarse, packed_fine, coarse, fi
     if gparams_fine is not None:
         for i, t in enumerate(gparams_fine):
             gf.g[i] = _p(t, name=f'grad param {i}')
-    L.check(lib.vipnerf_render_backward(C.byref(cfg), C.byref(rays), _p(packed_coarse),
-                                        _p(packed_fine) if packed_fine is not None else None, C.byref(out),
-                                        C.byref(og), _p(acts), _p(bwd_ws), C.byref(gc),
-                                        C.byref(gf) if gparams_fine is not None else None, _stream()),
-            'vipnerf_render_backward')
+    with on_device(*keep, packed_coarse, packed_fine, acts, bwd_ws, *gparams_coarse) as dev:
+        L.check(lib.vipnerf_render_backward(C.byref(cfg), C.byref(rays), _p(packed_coarse),
+                                            _p(packed_fine) if packed_fine is not None else None, C.byref(out),
+                                            C.byref(og), _p(acts), _p(bwd_ws), C.byref(gc),
+                                            C.byref(gf) if gparams_fine is not None else None, _stream(dev)),
+                'vipnerf_render_backward')
     return keep
 
 
@@ -215,8 +248,9 @@ def coarse_depths(near, far, n_samples, t_rand=None, lindisp=False):
     near, far = f32c(near.reshape(n)), f32c(far.reshape(n))
     tr = f32c(t_rand) if t_rand is not None else None
     z = torch.empty(n, n_samples, dtype=torch.float32, device=near.device)
-    L.check(L.load().vipnerf_coarse_depths(n, n_samples, int(lindisp), _p(near), _p(far), _p(tr), _p(z), _stream()),
-            'vipnerf_coarse_depths')
+    with on_device(near, far, tr) as dev:
+        L.check(L.load().vipnerf_coarse_depths(n, n_samples, int(lindisp), _p(near), _p(far), _p(tr), _p(z), _stream(dev)),
+                'vipnerf_coarse_depths')
     return z
 
 
@@ -228,8 +262,9 @@ def sample_fine(z_coarse, w_coarse, n_fine, u=None):
     zf = torch.empty(n, sc + n_fine, dtype=torch.float32, device=dev)
     inds = torch.empty(n, n_fine, dtype=torch.int32, device=dev)
     zs = torch.empty(n, n_fine, dtype=torch.float32, device=dev)
-    L.check(L.load().vipnerf_sample_fine(n, sc, n_fine, _p(zc), _p(wc), _p(uu), _p(zf), _p(inds, torch.int32), _p(zs),
-                                         _stream()), 'vipnerf_sample_fine')
+    with on_device(zc, wc, uu) as dev:
+        L.check(L.load().vipnerf_sample_fine(n, sc, n_fine, _p(zc), _p(wc), _p(uu), _p(zf), _p(inds, torch.int32), _p(zs),
+                                             _stream(dev)), 'vipnerf_sample_fine')
     return zf, inds, zs
 
 
@@ -245,8 +280,9 @@ def mlp_forward(packed, pts, view_dirs, view_dirs2=None, noise=None, noise_std=1
     vis2 = e(P, V) if V > 0 else None
     if P == 0:
         return {'sigma': sigma, 'rgb': rgb, 'visibility': vis, 'visibility2': vis2}
-    L.check(L.load().vipnerf_mlp_forward_p(P, V, _p(pts), _p(vd), _p(vd2), _p(nz), float(noise_std), int(precision),
-                                           _p(packed), _p(sigma), _p(rgb), _p(vis), _p(vis2), _stream()), 'vipnerf_mlp_forward_p')
+    with on_device(pts, vd, vd2, nz, packed) as dev:
+        L.check(L.load().vipnerf_mlp_forward_p(P, V, _p(pts), _p(vd), _p(vd2), _p(nz), float(noise_std), int(precision),
+                                               _p(packed), _p(sigma), _p(rgb), _p(vis), _p(vis2), _stream(dev)), 'vipnerf_mlp_forward_p')
     return {'sigma': sigma, 'rgb': rgb, 'visibility': vis, 'visibility2': vis2}
 
 
@@ -260,8 +296,43 @@ def composite(cfg: L.Config, batch, z, sigma, rgb, vis2=None):
     if cfg.n_sec > 0:
         lvl['raw_vis2'] = f32c(vis2)
     lo = _level_struct(lvl)
-    L.check(L.load().vipnerf_composite(C.byref(cfg), C.byref(rays), S, C.byref(lo), _stream()), 'vipnerf_composite')
+    with on_device(*keep, *lvl.values()) as dev:
+        L.check(L.load().vipnerf_composite(C.byref(cfg), C.byref(rays), S, C.byref(lo), _stream(dev)), 'vipnerf_composite')
     return lvl
+
+
+def secondary_dirs(cfg: L.Config, batch, z):
+    """compute_other_view_dirs as the MLP kernels evaluate it: z (N,S) -> (N,S,V,3)."""
+    keep = []
+    rays = _rays_struct(cfg, batch, keep)
+    n, S = z.shape
+    zc = f32c(z)
+    out = torch.empty(n, S, cfg.n_sec, 3, dtype=torch.float32, device=zc.device)
+    with on_device(*keep, zc) as dev:
+        L.check(L.load().vipnerf_secondary_dirs(C.byref(cfg), C.byref(rays), S, _p(zc), _p(out), _stream(dev)),
+                'vipnerf_secondary_dirs')
+    return out
+
+
+def philox4x32_10(counters: torch.Tensor, keys: torch.Tensor) -> torch.Tensor:
+    """counters (n,4), keys (n,2) int32 bit patterns on the GPU -> (n,4) int32 bit patterns."""
+    n = counters.shape[0]
+    c, k = counters.contiguous(), keys.contiguous()
+    out = torch.empty(n, 4, dtype=torch.int32, device=c.device)
+    with on_device(c, k) as dev:
+        L.check(L.load().vipnerf_philox4x32_10(n, _p(c, torch.int32), _p(k, torch.int32), _p(out, torch.int32), _stream(dev)),
+                'vipnerf_philox4x32_10')
+    return out
+
+
+def rng_draw(kind: str, seed: int, offset: int, stream_id: int, first_idx: int, n: int, device) -> torch.Tensor:
+    """The production generator: n draws idx = first_idx.. of stream `stream_id` (1 t_rand, 2 u, 3 / 4 sigma noise)."""
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    with on_device(out) as dev:
+        L.check(L.load().vipnerf_rng_draw({'uniform': 0, 'normal': 1}[kind], seed & 0xFFFFFFFFFFFFFFFF,
+                                          offset & 0xFFFFFFFFFFFFFFFF, stream_id, first_idx, n, _p(out), _stream(dev)),
+                'vipnerf_rng_draw')
+    return out
 
 
 def losses_forward(cfg: L.Config, n_rays, target_rgb, mask_nerf, prior, mask_sparse, sparse_depth, coarse, fine):
@@ -300,8 +371,9 @@ def losses_forward(cfg: L.Config, n_rays, target_rgb, mask_nerf, prior, mask_spa
         for k, v in d.items():
             setattr(st, k, _p(v))
         seeds.append(d)
-    L.check(L.load().vipnerf_losses_forward(C.byref(cfg), n_rays, C.byref(li), C.byref(out), C.byref(lo), _stream()),
-            'vipnerf_losses_forward')
+    with on_device(*keep, vals) as dev:
+        L.check(L.load().vipnerf_losses_forward(C.byref(cfg), n_rays, C.byref(li), C.byref(out), C.byref(lo), _stream(dev)),
+                'vipnerf_losses_forward')
     return vals, seeds[0], seeds[1]
 
 

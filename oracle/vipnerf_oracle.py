@@ -250,10 +250,12 @@ def secondary_origins(poses: torch.Tensor, image_id: torch.Tensor, num_frames: i
 
 def render_rays(p: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], cfg: dict,
                 rng: Optional[Dict[str, torch.Tensor]], train: bool, sec_views: bool,
-                chunk: Optional[int] = None) -> Dict[str, torch.Tensor]:
+                chunk: Optional[int] = None, netchunk: Optional[int] = None) -> Dict[str, torch.Tensor]:
     """cfg: ndc, n_coarse, n_fine (0 = coarse only), depth, width(unused, implied by p), l_pts, l_view,
     noise_std, lindisp, white_bkgd.  rng: None in eval.  Returns the reference's training-mode key set
-    (callers drop what `retraw=False` would drop)."""
+    (callers drop what `retraw=False` would drop).  chunk / netchunk: the reference's host loops over ray chunks
+    (batchify_rays, VipNeRF01.py:47-72) and over point chunks of the MLP (batchify, :295-329); they change nothing
+    numerically except the GEMM blocking, and are what bench.py's cpu_baseline leg runs (structure-equivalent timing)."""
     if chunk is not None and batch['rays_o'].shape[0] > chunk:
         n = batch['rays_o'].shape[0]
         outs = []
@@ -261,7 +263,7 @@ def render_rays(p: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], cfg:
             sub = {k: (v[s:s + chunk] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == n else v)
                    for k, v in batch.items()}
             sub_rng = None if rng is None else {k: v[s:s + chunk] for k, v in rng.items()}
-            outs.append(render_rays(p, sub, cfg, sub_rng, train, sec_views, None))
+            outs.append(render_rays(p, sub, cfg, sub_rng, train, sec_views, None, netchunk))
         return {k: torch.cat([o[k] for o in outs], dim=0) for k in outs[0]}
 
     ndc = cfg['ndc']
@@ -287,7 +289,13 @@ def render_rays(p: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], cfg:
         vd2 = None
         if o2 is not None:
             vd2 = secondary_dirs(z, o, d, o2, ndc).reshape(n * s, -1, 3)
-        net = mlp_forward(p, level, pts, vd, vd2, None if noise is None else noise.reshape(-1), **kw)
+        nz = None if noise is None else noise.reshape(-1)
+        if netchunk is None or pts.shape[0] <= netchunk:
+            net = mlp_forward(p, level, pts, vd, vd2, nz, **kw)
+        else:
+            parts = [mlp_forward(p, level, pts[i:i + netchunk], vd[i:i + netchunk], None if vd2 is None else vd2[i:i + netchunk],
+                                 None if nz is None else nz[i:i + netchunk], **kw) for i in range(0, pts.shape[0], netchunk)]
+            net = {k: torch.cat([q[k] for q in parts], dim=0) for k in parts[0]}
         net = {k: v.reshape(n, s, *v.shape[1:]) for k, v in net.items()}
         comp = composite(net, z, d_s, ndc, o, d, cfg.get('white_bkgd', False))
         ret[f'z_vals_{level}'] = z

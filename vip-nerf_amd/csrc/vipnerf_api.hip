@@ -89,8 +89,22 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st);
 #ifndef VN_BF16_NARROW_DEFAULT
 #define VN_BF16_NARROW_DEFAULT 1
 #endif
+#ifndef VN_FP32_NARROW_DEFAULT
+#define VN_FP32_NARROW_DEFAULT 1
+#endif
 static bool bf16_narrow(int layout = VIPNERF_LAYOUT_DEFAULT, int precision = 0) {
     if (precision >= VIPNERF_PREC_FP16X3) return true;      // fp16 fragments exist in the narrow layout only
+    if (precision == VIPNERF_PREC_FP32) {                   // exact fp32: wide = v_mfma_f32_32x32x2_f32, one wave per SIMD;
+        if (layout == VIPNERF_LAYOUT_WIDE) return false;    // narrow = v_mfma_f32_16x16x4_f32, two waves per SIMD
+        if (layout == VIPNERF_LAYOUT_NARROW) return true;
+        static const int v32 = [] {
+            const char *e = getenv("VIPNERF_FP32_LAYOUT");
+            if (e && !strcmp(e, "narrow")) return 1;
+            if (e && !strcmp(e, "wide")) return 0;
+            return VN_FP32_NARROW_DEFAULT;
+        }();
+        return v32 != 0;
+    }
     if (layout == VIPNERF_LAYOUT_WIDE) return false;
     if (layout == VIPNERF_LAYOUT_NARROW) return true;
     static const int v = [] {
@@ -104,7 +118,7 @@ static bool bf16_narrow(int layout = VIPNERF_LAYOUT_DEFAULT, int precision = 0) 
 static size_t packed_floats_all(int precision) { return packed_total_floats(precision) + packed_narrow_floats(precision); }
 
 static int launch_mlp_fwd_any(MlpFwdArgs &a, int precision, hipStream_t st, int layout = VIPNERF_LAYOUT_DEFAULT) {
-    if (precision == VIPNERF_PREC_FP32) return launch_mlp_fwd(a, st);
+    if (precision == VIPNERF_PREC_FP32 && !bf16_narrow(layout, precision)) return launch_mlp_fwd(a, st);
     if (bf16_narrow(layout, precision)) {
         a.packed += packed_total_floats(precision);   // [fp32][wide] precede the narrow image
         return launch_mlp_fwd_bf16n(a, precision, st);
@@ -177,8 +191,8 @@ size_t vipnerf_packed_weights_bytes_p(int32_t precision) { return packed_floats_
 int32_t vipnerf_pack_weights_p(const vipnerf_mlp_params *params, int32_t precision, void *packed, vipnerf_stream_t stream) {
     if (precision < 0 || precision > VIPNERF_PREC_FP16X3H) { set_error("pack_weights: precision=%d unsupported", precision); return VIPNERF_E_UNSUPPORTED; }
     int rc = vipnerf_pack_weights(params, packed, stream);
-    if (rc || precision == VIPNERF_PREC_FP32) return rc;
-    if (precision < VIPNERF_PREC_FP16X3 &&
+    if (rc) return rc;
+    if (precision != VIPNERF_PREC_FP32 && precision < VIPNERF_PREC_FP16X3 &&
         (rc = launch_pack_bf16(params, precision, (float *)packed + PK_TOTAL_F, (hipStream_t)stream))) return rc;
     return launch_pack_bf16n(params, precision, (float *)packed + packed_total_floats(precision), (hipStream_t)stream);
 }
@@ -223,8 +237,20 @@ int32_t vipnerf_sample_fine(int64_t n_rays, int32_t n_coarse, int32_t n_fine, co
 int32_t vipnerf_mlp_forward(int64_t n_points, int32_t n_sec, const float *pts, const float *view_dirs,
                             const float *view_dirs2, const float *noise, float noise_std, const void *packed,
                             float *sigma, float *rgb, float *vis, float *vis2, vipnerf_stream_t stream) {
-    return vipnerf_mlp_forward_p(n_points, n_sec, pts, view_dirs, view_dirs2, noise, noise_std, VIPNERF_PREC_FP32, packed,
-                                 sigma, rgb, vis, vis2, stream);
+    // `packed` comes from vipnerf_pack_weights: the wide fp32 image only
+    clear_stale_hip_error();
+    if (n_points == 0) return VIPNERF_OK;
+    if (!pts || !view_dirs || !packed || !sigma || !rgb || !vis || (n_sec > 0 && (!view_dirs2 || !vis2))) {
+        set_error("mlp_forward: NULL argument"); return VIPNERF_E_ARG; }
+    if (n_sec < 0 || n_sec > VIPNERF_MAX_SEC) { set_error("mlp_forward: n_sec=%d unsupported", n_sec); return VIPNERF_E_UNSUPPORTED; }
+    MlpFwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src.P = n_points; a.src.S = 1; a.src.V = n_sec; a.src.rays_mode = 0;
+    a.src.pts = pts; a.src.dirs = view_dirs; a.src.dirs2 = view_dirs2;
+    a.ns.noise = noise; a.ns.std = noise_std;
+    a.packed = (const float *)packed;
+    a.sigma = sigma; a.rgb = rgb; a.vis = vis; a.vis2 = vis2;
+    return launch_mlp_fwd(a, (hipStream_t)stream);
 }
 
 int32_t vipnerf_mlp_forward_p(int64_t n_points, int32_t n_sec, const float *pts, const float *view_dirs,
@@ -382,7 +408,7 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
         mb.bwd = bw; mb.bl = bl;
         {
             ProfScope ps(lv ? "mlp_dgrad_fine" : "mlp_dgrad_coarse", st);
-            if (cfg->precision == VIPNERF_PREC_FP32) rc = launch_mlp_bwd(mb, st);
+            if (cfg->precision == VIPNERF_PREC_FP32 && !bf16_narrow(cfg->bf16_layout, cfg->precision)) rc = launch_mlp_bwd(mb, st);
             else if (bf16_narrow(cfg->bf16_layout, cfg->precision)) { mb.packed += packed_total_floats(cfg->precision); rc = launch_mlp_bwd_bf16n(mb, cfg->precision, st); }
             else { mb.packed += PK_TOTAL_F; rc = launch_mlp_bwd_bf16(mb, cfg->precision, st); }
             if (rc) return rc;

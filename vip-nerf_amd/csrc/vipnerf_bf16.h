@@ -114,6 +114,31 @@ __device__ __forceinline__ floatx4 mfma_bf(bf16x8 a, bf16x8 b, floatx4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// Exact-fp32 fragments for the narrow layout ("fp32 narrow": two waves per SIMD on v_mfma_f32_16x16x4_f32).  A "k-step"
+// of the narrow layout is 32 contraction indices, 8 per lane group q; in fp32 they are consumed by 8 consecutive MFMAs
+// (k = 4 each: lane (., q) supplies ONE float, the index (s, q, e) of MFMA e), so a lane's k-step operand is 8 floats =
+// two 16-byte parts -- the same bytes per lane, chunk geometry, stage sizes and register-chained layer structure as the
+// two-part fp16 / bf16 fragments, without any operand split and with one MFMA per product.
+struct f32q { floatx4 v; };
+static_assert(sizeof(f32q) == 16, "one 16-byte part");
+template <int NS>
+__device__ __forceinline__ void split8(const float (&x)[8], f32q (&out)[NS]) {
+    static_assert(NS == 2, "fp32 narrow fragments have two 4-float parts");
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e >> 2].v[e & 3] = x[e];
+}
+// MFMAs per (k-step, tile) cell
+template <typename FR, int NS> struct CellMfmas { static constexpr int value = NS * (NS + 1) / 2; };
+template <int NS> struct CellMfmas<f32q, NS> { static constexpr int value = 4 * NS; };
+template <int NS>
+__device__ __forceinline__ floatx4 mfma_split(const f32q (&a)[NS], const f32q (&b)[NS], floatx4 c) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].v[e], b[i].v[e], c, 0, 0, 0);
+    return c;
+}
+
 // acc[t] += A(k-step, tile) * B(k-step) over the significant cross terms; smallest terms first
 template <int NS, typename ACC, typename FR>
 __device__ __forceinline__ ACC mfma_split(const FR (&a)[NS], const FR (&b)[NS], ACC c) {
@@ -256,7 +281,7 @@ __device__ __forceinline__ void gemm_groups_bf(const float *base, ACC (&acc)[NT]
                                                FR (&fr)[NBUF][G][NS], WS &ws, MIDF &mid) {
     if constexpr (g < NG) {
         constexpr int R = (g + D < NG) ? G * NS : 0;           // ds_read_b128 in this group
-        constexpr int M = G * NS * (NS + 1) / 2;               // MFMAs in this group
+        constexpr int M = G * CellMfmas<FR, NS>::value;        // MFMAs in this group
         if (g + D < NG) {
 #pragma unroll
             for (int tt = 0; tt < G; ++tt)

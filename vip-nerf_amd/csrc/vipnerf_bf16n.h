@@ -92,8 +92,9 @@ struct BnPlan {
     static_assert(LDS_F * 4 <= 160 * 1024, "LDS budget");
 };
 
+// precision 0 (exact fp32): the fp32-narrow image (two 4-float parts per k-step: BnPlan<2>'s geometry) follows the wide fp32 one
 __host__ __device__ inline size_t packed_narrow_floats(int precision) {
-    return (precision == 1 || precision >= 3) ? BnPlan<2>::PK_TOTAL_F : (precision == 2 ? BnPlan<3>::PK_TOTAL_F : 0);
+    return precision == 2 ? BnPlan<3>::PK_TOTAL_F : BnPlan<2>::PK_TOTAL_F;
 }
 
 // "fp16x3" (VIPNERF_PREC_FP16X3): the narrow kernels with fp16 fragments, x = x0 + x1 with 11-bit parts, three cross
@@ -236,6 +237,7 @@ __device__ __forceinline__ void store_pair16h(float *base, int64_t p, int ld, in
     __builtin_nontemporal_store(b, (half4 *)(row + 16 * (2 * s + 1)));
 }
 __device__ __forceinline__ void store_pair16h(float *, int64_t, int, int, int, const bf16x8 &) {}   // never used
+__device__ __forceinline__ void store_pair16h(float *, int64_t, int, int, int, const f32q &) {}
 // VN_F16_PRESPLIT: both fp16 parts of the two tiles, in the fp32 array's own geometry: the 16 bytes a lane owns per tile
 // (4 features) hold [hi(f0,f1)] [hi(f2,f3)] [lo(f0,f1)] [lo(f2,f3)] -- the registers of the split as they are, one 16-byte
 // store per tile exactly like the fp32 store.
@@ -248,6 +250,16 @@ __device__ __forceinline__ void store_pair_split(float *base, int64_t p, int ld,
     __builtin_nontemporal_store(t1, (u4 *)(row + 16 * (2 * s + 1)));
 }
 __device__ __forceinline__ void store_pair_split(float *, int64_t, int, int, int, const bf16x8 &, const bf16x8 &) {}
+__device__ __forceinline__ void store_pair_split(float *, int64_t, int, int, int, const f32q &, const f32q &) {}
+
+// H16 == 3 (exact fp32, f32q operands): the k-step operand of the next GEMM IS the fp32 activation (part 0 = tile 2s, part 1 =
+// tile 2s + 1), so its plain fp32 stores can leave from the next layer's stages exactly like the pre-split fp16 ones
+__device__ __forceinline__ void store_pair_f32(float *base, int64_t p, int ld, int q, int s, const f32q &t0, const f32q &t1) {
+    store_tile16(base, p, ld, q, 2 * s, t0.v);
+    store_tile16(base, p, ld, q, 2 * s + 1, t1.v);
+}
+__device__ __forceinline__ void store_pair_f32(float *, int64_t, int, int, int, const bf16x8 &, const bf16x8 &) {}
+__device__ __forceinline__ void store_pair_f32(float *, int64_t, int, int, int, const half8 &, const half8 &) {}
 
 // two C/D tiles (2s, 2s+1) -> the NS-part B fragment of k-step s
 template <int NS, typename FR>
@@ -278,15 +290,17 @@ struct DeferredStores {
             for (int s = s0; s < s0 + 2; ++s) {
                 if (H16 == 1) store_pair16h(dst, p, 256, q, s, bin[s][0]);
                 if (H16 == 2) store_pair_split(dst, p, 256, q, s, bin[s][0], bin[s][1]);
+                if (H16 == 3) store_pair_f32(dst, p, 256, q, s, bin[s][0], bin[s][1]);
             }
         }
     }
 };
 
-template <bool F16> struct FragOf { typedef bf16x8 type; };
-template <> struct FragOf<true> { typedef half8 type; };
+template <bool F16, bool F32 = false> struct FragOf { typedef bf16x8 type; };
+template <> struct FragOf<true, false> { typedef half8 type; };
+template <> struct FragOf<false, true> { typedef f32q type; };
 #endif
 
-int launch_pack_bf16n(const vipnerf_mlp_params *p, int precision, void *packed_bn, hipStream_t st);   // precision 1, 2 or 3
+int launch_pack_bf16n(const vipnerf_mlp_params *p, int precision, void *packed_bn, hipStream_t st);   // precision 0 (fp32 narrow) .. 4
 
 }  // namespace vn

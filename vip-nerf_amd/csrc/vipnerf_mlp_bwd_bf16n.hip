@@ -4,6 +4,9 @@
 #include "vipnerf_bf16n.h"
 #include "vipnerf_mlp.h"
 
+#ifndef VN_F32_DEFER
+#define VN_F32_DEFER 1
+#endif
 #ifndef VN_ROTATE_DMA
 #define VN_ROTATE_DMA true
 #endif
@@ -49,10 +52,10 @@ __global__ void k_seed_absmax(MlpBwdArgs a, unsigned *slot) {
 // stored as the fp16 parts of the split that is made for the next GEMM anyway: 1 = high parts only (FP16X3H), 2 = high
 // and low parts in the fp32 slot (FP16X3, store_pair_split), sent from the next GEMM's weight stages (DEFER); with high
 // parts only, dY_5 additionally in fp32 for layer 5's gamma(x) GEMM; dY_0 stays fp32.
-template <int NS, bool F16, int H16 = 0>
+template <int NS, bool F16, int H16 = 0, bool F32 = false>
 __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) {
     typedef BnPlan<NS> PL;
-    typedef typename FragOf<F16>::type FR;
+    typedef typename FragOf<F16, F32>::type FR;
     constexpr float AU = F16 ? 1.f / F16_WSCALE : 1.f;
     constexpr bool DEFER = H16 != 0 && VN_DEFER_STORES;    // fp16-stored gradients leave from the next GEMM's stages (vipnerf_bf16n.h)
     constexpr int S_PER_STAGE = 8 / PL::ST_256;
@@ -155,6 +158,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
         split_pair<NS>(x0, x1, bin[s]);
         if (!DEFER && H16 == 1) store_pair16h(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0]);
         if (!DEFER && H16 == 2) store_pair_split(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0], bin[s][1]);
+        if (!DEFER && H16 == 3) store_pair_f32(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0], bin[s][1]);
     }
 
     // ---------------------------------------------------------------- feature layer, then layers 7..1
@@ -200,17 +204,18 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
                 split_pair<NS>(x[0], x[1], bin[s]);
                 if (!DEFER && H16 == 1) store_pair16h(dst, p, W, q, s, bin[s][0]);
                 if (!DEFER && H16 == 2) store_pair_split(dst, p, W, q, s, bin[s][0], bin[s][1]);
+                if (!DEFER && H16 == 3) store_pair_f32(dst, p, W, q, s, bin[s][0], bin[s][1]);
             }
         }
     }
     stream_end(ws);
 }
 
-template <int NS, bool F16 = false, int H16 = 0>
+template <int NS, bool F16 = false, int H16 = 0, bool F32 = false>
 static int launch_one_bwd_n(const MlpBwdArgs &a, unsigned grid, hipStream_t st) {
     const size_t lds = (size_t)BnPlan<NS>::LDS_F * sizeof(float);
-    VN_HIP(hipFuncSetAttribute((const void *)k_mlp_bwd_bf16n<NS, F16, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_mlp_bwd_bf16n<NS, F16, H16>), dim3(grid), dim3(BnPlan<NS>::WG), lds, st, a);
+    VN_HIP(hipFuncSetAttribute((const void *)k_mlp_bwd_bf16n<NS, F16, H16, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_mlp_bwd_bf16n<NS, F16, H16, F32>), dim3(grid), dim3(BnPlan<NS>::WG), lds, st, a);
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;
 }
@@ -218,6 +223,7 @@ static int launch_one_bwd_n(const MlpBwdArgs &a, unsigned grid, hipStream_t st) 
 int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
     if (a.src.P <= 0) return VIPNERF_OK;
     const unsigned grid = (unsigned)((a.src.P + MLP_PTS_PER_WG - 1) / MLP_PTS_PER_WG);
+    if (precision == 0) return launch_one_bwd_n<2, false, VN_F32_DEFER ? 3 : 0, true>(a, grid, st);
     if (precision == 1) return launch_one_bwd_n<2>(a, grid, st);
     if (precision == 2) return launch_one_bwd_n<3>(a, grid, st);
     if (precision == 3 || precision == 4) {

@@ -5,6 +5,9 @@
 #include "vipnerf_bf16n.h"
 #include "vipnerf_mlp.h"
 
+#ifndef VN_F32_DEFER
+#define VN_F32_DEFER 1       // exact-fp32 narrow kernels: activation / gradient stores leave from the next GEMM's stages (H16 = 3)
+#endif
 #ifndef VN_ROTATE_DMA
 #define VN_ROTATE_DMA true
 #endif
@@ -74,10 +77,12 @@ __device__ __forceinline__ void store_d16(float *row, int q, const float (&pd)[1
 // 1 = fp16 high parts only (FP16X3H); 2 = both fp16 parts in the 16 bytes a lane owns per tile (FP16X3, store_pair_split:
 // the same bytes as fp32, but already split).  With H16 != 0 the stores of a layer's output leave from the NEXT layer's
 // weight stages (DEFER; the stored form is that layer's B operand).  Everything else stays fp32.
-template <bool SAVE, int NS, bool F16, int H16 = 0>
+// F32: exact-fp32 fragments (f32q, vipnerf_bf16.h): v_mfma_f32_16x16x4_f32, one MFMA per product, no split, no scaling.
+template <bool SAVE, int NS, bool F16, int H16 = 0, bool F32 = false>
 __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) {
     typedef BnPlan<NS> PL;
-    typedef typename FragOf<F16>::type FR;
+    typedef typename FragOf<F16, F32>::type FR;
+    static_assert(!(F16 && F32) && (!F32 || (NS == 2 && (H16 == 0 || H16 == 3))) && (F32 || H16 != 3), "arithmetic");
     constexpr float XS = F16 ? F16_XSCALE : 1.f;           // B operands are split as XS * x
     constexpr float AU = F16 ? F16_ACC_UNSCALE : 1.f;
     constexpr bool DEFER = SAVE && H16 != 0 && VN_DEFER_STORES;   // h_1..h_8 leave from the next layer's stages (vipnerf_bf16n.h)
@@ -200,6 +205,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             split_pair<NS>(x[0], x[1], bin[s]);
             if (SAVE && !DEFER && H16 == 1 && layer < 8) store_pair16h(dst, p, W, q, s, bin[s][0]);
             if (SAVE && !DEFER && H16 == 2 && layer < 8) store_pair_split(dst, p, W, q, s, bin[s][0], bin[s][1]);
+            if (SAVE && !DEFER && H16 == 3 && layer < 8) store_pair_f32(dst, p, W, q, s, bin[s][0], bin[s][1]);
         }
         if (SAVE && layer < 8) *(uint2 *)(a.acts + a.al.hm[layer] + ((size_t)p * 4 + q) * 2) = make_uint2(mk0, mk1);
     }
@@ -284,11 +290,11 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
     }
 }
 
-template <bool SAVE, int NS, bool F16 = false, int H16 = 0>
+template <bool SAVE, int NS, bool F16 = false, int H16 = 0, bool F32 = false>
 static int launch_one_n(const MlpFwdArgs &a, unsigned grid, hipStream_t st) {
     const size_t lds = (size_t)BnPlan<NS>::LDS_F * sizeof(float);
-    VN_HIP(hipFuncSetAttribute((const void *)k_mlp_fwd_bf16n<SAVE, NS, F16, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_mlp_fwd_bf16n<SAVE, NS, F16, H16>), dim3(grid), dim3(BnPlan<NS>::WG), lds, st, a);
+    VN_HIP(hipFuncSetAttribute((const void *)k_mlp_fwd_bf16n<SAVE, NS, F16, H16, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_mlp_fwd_bf16n<SAVE, NS, F16, H16, F32>), dim3(grid), dim3(BnPlan<NS>::WG), lds, st, a);
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;
 }
@@ -297,6 +303,7 @@ static int launch_one_n(const MlpFwdArgs &a, unsigned grid, hipStream_t st) {
 int launch_mlp_fwd_bf16n(const MlpFwdArgs &a, int precision, hipStream_t st) {
     if (a.src.P <= 0) return VIPNERF_OK;
     const unsigned grid = (unsigned)((a.src.P + MLP_PTS_PER_WG - 1) / MLP_PTS_PER_WG);
+    if (precision == 0) return a.acts ? launch_one_n<true, 2, false, VN_F32_DEFER ? 3 : 0, true>(a, grid, st) : launch_one_n<false, 2, false, 0, true>(a, grid, st);
     if (precision == 1) return a.acts ? launch_one_n<true, 2>(a, grid, st) : launch_one_n<false, 2>(a, grid, st);
     if (precision == 2) return a.acts ? launch_one_n<true, 3>(a, grid, st) : launch_one_n<false, 3>(a, grid, st);
     if (precision == 3) return a.acts ? launch_one_n<true, 2, true, VN_F16_PRESPLIT ? 2 : 0>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);

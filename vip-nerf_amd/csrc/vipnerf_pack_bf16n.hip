@@ -28,9 +28,12 @@ __device__ __forceinline__ uint32_t pack2n(float w0, float w1, int part) {
     return (uint32_t)ua | ((uint32_t)ub << 16);
 }
 
-template <int NS, bool F16>
+// F32 (fp32-narrow image): a 32-bit cell is ONE weight -- element e = 4 part + (cell & 3) of the lane's 8-float k-step
+// operand (f32q parts, vipnerf_bf16.h) -- instead of two 16-bit parts of elements e0, e0 + 1.
+template <int NS, bool F16, bool F32 = false>
 __global__ void k_pack_bf16n(PackBnArgs a) {
     typedef BnPlan<NS> PL;
+    constexpr int NU = F32 ? 1 : 2;              // weights per 32-bit cell
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= PL::PK_TOTAL_F) return;
     uint32_t cell = 0;
@@ -39,16 +42,17 @@ __global__ void k_pack_bf16n(PackBnArgs a) {
         const size_t i0 = bwd ? idx - PL::PK_BWD : idx;
         const int s = (int)(i0 / PL::STAGE_F);
         const int w = (int)(i0 % PL::STAGE_F);
-        const int c = w / CHUNK_F, lane = (w % CHUNK_F) >> 2, e0 = 2 * (w & 3);
+        const int c = w / CHUNK_F, lane = (w % CHUNK_F) >> 2;
         const int q = lane >> 4, i = lane & 15;
         const int part = c % NS, cellno = c / NS;
+        const int e0 = F32 ? 4 * part + (w & 3) : 2 * (w & 3);
         float v[2] = {0.f, 0.f};
         if (!bwd) {
             if (s < PL::FS_L1 || (s >= PL::FS_L5PE && s < PL::FS_L6)) {            // gamma(x) columns of layer 0 / 5
                 const int layer = s < PL::FS_L1 ? 0 : SKIP_LAYER;
                 const int j = s < PL::FS_L1 ? s - PL::FS_L0PE : s - PL::FS_L5PE;
                 const int t = cellno % 16, ks = PL::KSB * j + cellno / 16;
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < NU; ++u) {
                     const int k = pe_feat16(ks, q, e0 + u);
                     v[u] = k >= 0 ? a.p.p[2 * layer][(size_t)(16 * t + i) * layer_in_dim(layer) + k] : 0.f;
                 }
@@ -62,16 +66,16 @@ __global__ void k_pack_bf16n(PackBnArgs a) {
                 const float *wp = layer < 8 ? a.p.p[2 * layer] : a.p.p[P_FW];
                 const int ld = layer < 8 ? layer_in_dim(layer) : W;
                 const int t = cellno % 16, ks = PL::KSB * j + cellno / 16;
-                for (int u = 0; u < 2; ++u) v[u] = wp[(size_t)(16 * t + i) * ld + koff + feat16(ks, q, e0 + u)];
+                for (int u = 0; u < NU; ++u) v[u] = wp[(size_t)(16 * t + i) * ld + koff + feat16(ks, q, e0 + u)];
             } else {                                                               // view layer, feature columns (8 tiles)
                 const int j = s - PL::FS_VIEW;
                 const int t = cellno % 8, ks = PL::KSV * j + cellno / 8;
-                for (int u = 0; u < 2; ++u) v[u] = a.p.p[P_VW][(size_t)(16 * t + i) * (W + DVE) + feat16(ks, q, e0 + u)];
+                for (int u = 0; u < NU; ++u) v[u] = a.p.p[P_VW][(size_t)(16 * t + i) * (W + DVE) + feat16(ks, q, e0 + u)];
             }
         } else {                                                                   // dgrad: A = W^T, 16 tiles of input features
             const int t = cellno % 16, ksl = cellno / 16;
             const int k = 16 * t + i;
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < NU; ++u) {
                 if (s < PL::BS_FEAT) {
                     const int r = feat16(PL::KSB * s + ksl, q, e0 + u);            // < 128: output feature of the view layer
                     v[u] = a.p.p[P_VW][(size_t)r * (W + DVE) + k];
@@ -86,18 +90,19 @@ __global__ void k_pack_bf16n(PackBnArgs a) {
                 }
             }
         }
-        cell = pack2n<F16>(v[0], v[1], part);
+        cell = F32 ? __float_as_uint(v[0]) : pack2n<F16>(v[0], v[1], part);
     } else {
         const int i0 = (int)(idx - PL::PK_RES);
         if (i0 < PL::R_DIRW_F) {                                                   // direction columns, chunk t * NS + part
-            const int c = i0 / CHUNK_F, lane = (i0 % CHUNK_F) >> 2, e0 = 2 * (i0 & 3);
+            const int c = i0 / CHUNK_F, lane = (i0 % CHUNK_F) >> 2;
             const int part = c % NS, t = c / NS, q = lane >> 4, i = lane & 15;
-            float v[2];
-            for (int u = 0; u < 2; ++u) {
+            const int e0 = F32 ? 4 * part + (i0 & 3) : 2 * (i0 & 3);
+            float v[2] = {0.f, 0.f};
+            for (int u = 0; u < NU; ++u) {
                 const int kk = dir_feat16(q, e0 + u);
                 v[u] = kk >= 0 ? a.p.p[P_VW][(size_t)(16 * t + i) * (W + DVE) + W + kk] : 0.f;
             }
-            cell = pack2n<F16>(v[0], v[1], part);
+            cell = F32 ? __float_as_uint(v[0]) : pack2n<F16>(v[0], v[1], part);
         } else if (i0 < PL::R_TOTAL) {                                             // fp32 biases / heads, natural order
             const int f = i0 - PL::R_F32;
             float v = 0.f;
@@ -122,7 +127,9 @@ int launch_pack_bf16n(const vipnerf_mlp_params *p, int precision, void *packed_b
     a.p = *p;
     a.out = (uint32_t *)packed_bn;
     const int bs = 256;
-    if (precision == 1) {
+    if (precision == 0) {
+        hipLaunchKernelGGL((k_pack_bf16n<2, false, true>), dim3((unsigned)((BnPlan<2>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);
+    } else if (precision == 1) {
         hipLaunchKernelGGL((k_pack_bf16n<2, false>), dim3((unsigned)((BnPlan<2>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);
     } else if (precision == 2) {
         hipLaunchKernelGGL((k_pack_bf16n<3, false>), dim3((unsigned)((BnPlan<3>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);

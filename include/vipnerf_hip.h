@@ -83,7 +83,13 @@ typedef struct vipnerf_config {
     int32_t precision;    /* VIPNERF_PREC_*: arithmetic of the MLP GEMMs */
     int32_t bf16_layout;  /* VIPNERF_LAYOUT_*: lane layout of the split-bf16 MLP kernels; 0 = library default
                              (environment VIPNERF_BF16_LAYOUT=wide|narrow overrides the built-in default) */
-    int32_t reserved[3];
+    /* MLP topology (coarse and fine alike), configs['model']['*_mlp'][netdepth, netwidth, points_/views_positional_encoding_degree]
+     * (VipNeRF01.py:458-470).  0 = the default.  The hand-written MFMA kernels are specialised on 8 / 256 / 10 / 4 -- what every
+     * shipped reference config uses; any other topology (netdepth <= 8, netwidth <= 256 and a multiple of 8, degrees <= 16 / 8;
+     * e.g. BASELINE configs[0]'s 4x64 network) runs the generic per-layer kernels (csrc/vipnerf_generic.hip), fp32 only. */
+    int32_t netdepth;     /* 0 -> 8 */
+    int32_t netwidth;     /* 0 -> 256 */
+    int32_t pe_degrees;   /* points degree | views degree << 8;  0 -> 10 | 4 << 8 */
 } vipnerf_config;
 
 /* One ray batch (render_rays' input_dict, src/models/VipNeRF01.py:74-98).  N = n_rays. */
@@ -223,10 +229,15 @@ int32_t vipnerf_pack_weights(const vipnerf_mlp_params *params, void *packed, vip
 /* Same for a given precision: the buffer holds the fp32 image followed by the split-bf16 image (if precision != FP32). */
 size_t  vipnerf_packed_weights_bytes_p(int32_t precision);
 int32_t vipnerf_pack_weights_p(const vipnerf_mlp_params *params, int32_t precision, void *packed, vipnerf_stream_t stream);
+/* The same by configuration: cfg->precision for the fused topology (== the _p calls); for any other topology the flat fp32
+ * parameter buffer of the generic kernels (unused slots of params may be NULL: layers >= netdepth). */
+size_t  vipnerf_packed_weights_bytes_c(const vipnerf_config *cfg);
+int32_t vipnerf_pack_weights_c(const vipnerf_config *cfg, const vipnerf_mlp_params *params, void *packed, vipnerf_stream_t stream);
 
 /* ---- workspace ------------------------------------------------------------------------------------------ */
 /* acts_bytes: per-call activation store written by render_forward when cfg.save_acts (0 otherwise), read by
- * render_backward.  bwd_bytes: scratch of render_backward.  Both cover coarse + fine. */
+ * render_backward.  bwd_bytes: scratch of render_backward.  Both cover coarse + fine.  The generic-topology kernels run
+ * layer by layer through HBM: for them acts_bytes is non-zero (and `acts` required) in eval calls as well. */
 int32_t vipnerf_query_workspace(const vipnerf_config *cfg, int64_t n_rays, size_t *acts_bytes, size_t *bwd_bytes);
 
 /* ---- the hot path --------------------------------------------------------------------------------------- */

@@ -59,6 +59,15 @@ def test_argument_validation_without_gpu():
     buf = C.create_string_buffer(256)
     lib.vipnerf_last_error(buf, 256)
     assert b'n_coarse' in buf.value
+    toy = ops.make_config(False, 64, 0, 1, False, topology=(4, 64, 10, 4))          # generic kernels: scratch even in eval
+    assert lib.vipnerf_query_workspace(C.byref(toy), 1024, C.byref(a), C.byref(b)) == 0
+    assert a.value >= 4 * 1024 * 64 * (63 + 5 * 64 + 2 * (27 + 32 + 4)) and b.value > 0
+    assert lib.vipnerf_packed_weights_bytes_c(C.byref(toy)) == 4 * (64 * 63 + 64 + 3 * (64 * 64 + 64) + 32 * 91 + 32 + 64 + 1 + 64 * 64 + 64 + 128 + 4)
+    assert lib.vipnerf_packed_weights_bytes_c(C.byref(cfg)) == lib.vipnerf_packed_weights_bytes_p(0)
+    toy.precision = 3
+    assert lib.vipnerf_query_workspace(C.byref(toy), 16, C.byref(a), C.byref(b)) == -2
+    lib.vipnerf_last_error(buf, 256)
+    assert b'fp32 only' in buf.value
     with pytest.raises(_lib.VipNerfHipError):
         _lib.check(lib.vipnerf_pack_weights(None, None, None), 'pack')
 
@@ -78,9 +87,19 @@ def test_product_path_has_no_cpu_fallback():
     z = torch.zeros(4, 3)
     with pytest.raises(_lib.VipNerfHipError):
         m({'rays_o': z, 'rays_d': z, 'view_dirs': z, 'near': torch.zeros(4, 1), 'far': torch.ones(4, 1)})
-    small = dict(mlp, netwidth=64, netdepth=4)
+    # other topologies are served by the generic kernels (BASELINE configs[0]: 4 x 64 coarse-only) ...
+    small = get_model({'data_loader': {'ndc': False}, 'model': {'name': 'VipNeRFHip01', 'coarse_mlp': dict(mlp, netwidth=64, netdepth=4)}}, None)
+    assert [k for k, _ in small.named_parameters()][-1] == 'coarse_model.views_output_linear.bias' and len(list(small.parameters())) == 16
+    assert small.coarse_model.pts_linears[3].weight.shape == (64, 64) and small.fine_model is None
+    six = get_model({'data_loader': {'ndc': False}, 'model': {'name': 'VipNeRFHip01', 'coarse_mlp': dict(mlp, netwidth=128, netdepth=6)}}, None)
+    assert six.coarse_model.pts_linears[5].weight.shape == (128, 128 + 63)          # gamma(x) re-enters after layer 4
+    # ... but not in a split arithmetic, and not what no config uses
     with pytest.raises(_lib.VipNerfHipError):
-        get_model({'data_loader': {'ndc': False}, 'model': {'name': 'VipNeRFHip01', 'coarse_mlp': small}}, None)
+        get_model({'data_loader': {'ndc': False}, 'model': {'name': 'VipNeRFHip01', 'hip_precision': 'fp16x3',
+                                                             'coarse_mlp': dict(mlp, netwidth=64, netdepth=4)}}, None)
+    for bad in (dict(mlp, netwidth=100), dict(mlp, netdepth=9), dict(mlp, use_view_dirs=False), dict(mlp, predict_visibility=False)):
+        with pytest.raises(_lib.VipNerfHipError):
+            get_model({'data_loader': {'ndc': False}, 'model': {'name': 'VipNeRFHip01', 'coarse_mlp': bad}}, None)
 
 
 def test_oracle_is_not_imported_by_the_product():

@@ -472,3 +472,97 @@ def test_common_utils_device_glue(dev):
     assert get_device(None) == torch.device('cpu') and get_device('') == torch.device('cpu')
     moved = move_to_device({'a': torch.zeros(2), 'b': [torch.ones(1), 'text'], 'c': {'d': torch.zeros(1)}, 'e': 3}, dev)
     assert moved['a'].device == dev and moved['b'][0].device == dev and moved['b'][1] == 'text' and moved['c']['d'].device == dev and moved['e'] == 3
+
+
+# ------------------------------------------------------------------------------------------------ other topologies
+def _generic_model(dev, ndc, params, depth, width, n_fine, sparse=False):
+    model, cfg = tp.make_model(dev, ndc, None, n_fine=n_fine, sparse=sparse)
+    from models.ModelFactory import get_model
+    for k in ('coarse_mlp', 'fine_mlp'):
+        if k in cfg['model']:
+            cfg['model'][k].update(netdepth=depth, netwidth=width)
+    model = get_model(cfg, None)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()}, strict=True)
+    return model.to(dev), cfg
+
+
+def test_toy_config_golden(dev):
+    """BASELINE configs[0] (4 x 64, coarse only, 64 x 64 toy scene) through the generic-topology kernels against golden F5-toy
+    captured from the reference: outputs, losses at iter 0 / 40000, parameter gradients, one Adam step."""
+    from loss_functions.LossComputerHip01 import LossComputerHip
+    g = tp.load('f5_train_toy')
+    depth, width = int(g['depth']), int(g['width'])
+    assert (depth, width, int(g['n_fine'])) == (4, 64, 0)
+    b = vo.synthetic_batch(int(g['n']), int(g['seed_batch']), scene=str(g['scene']), nf=int(g['nf']))
+    params = vo.init_params(int(g['seed_params']), depth=depth, width=width, levels=('coarse',), scale=float(g['scale_params']))
+    model, cfg = _generic_model(dev, b['ndc'], params, depth, width, 0)
+    model.train()
+    lossc = LossComputerHip(cfg)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.999))
+    model.injected_rng = {k[4:]: tp.cu(v, dev) for k, v in g.items() if k.startswith('rng_')}
+    out = model(tp.ref_batch(b, dev, 40000))
+    assert not any(k.endswith('_fine') for k in out)
+    for rk in tp.KEYMAP:
+        gk = f'out_{rk}_coarse'
+        if gk in g:
+            tp.assert_close(out[f'{rk}_coarse'], g[gk], what=f'toy {rk}')
+    names = {'MSEHip01': 'MSE01', 'VisibilityLossHip01': 'VisibilityLoss01', 'VisibilityPriorLossHip01': 'VisibilityPriorLoss01',
+             'TotalLoss': 'TotalLoss'}
+    l40k = lossc.compute_losses(tp.ref_batch(b, dev, 40000), out)
+    for k, v in l40k.items():
+        tp.assert_close(v['loss_value'] if isinstance(v, dict) else v, g[f'l40k_{names[k]}'], rtol=1e-4, floor=1e-6, what=f'toy loss {k}')
+    l0 = lossc.compute_losses(tp.ref_batch(b, dev, 0), dict(out))
+    tp.assert_close(l0['TotalLoss'], g['l0_TotalLoss'], rtol=1e-4, floor=1e-6, what='toy TotalLoss iter 0')
+    opt.zero_grad(set_to_none=True)
+    l40k['TotalLoss'].backward()
+    for k, p in model.named_parameters():
+        assert 'grad_' + k in g or 'gdig_' + k in g, k
+        if 'grad_' + k in g:
+            tp.grad_close(p.grad.cpu().numpy(), g['grad_' + k], f'toy grad of {k}')
+        np.testing.assert_allclose(float(p.grad.double().norm()), g['gdig_' + k][1], rtol=1e-3, atol=1e-9, err_msg=k)
+    opt.step()
+
+
+@pytest.mark.parametrize('depth,width,scene,nf', [(6, 128, 'fern', 2), (3, 32, 'dtu', 3), (8, 192, 'realestate', 3)])
+def test_other_topologies_vs_oracle(dev, depth, width, scene, nf):
+    """Topologies other than 8 x 256 -- with and without the skip connection (depth > 5), coarse + fine, NDC and not, V = 1, 2,
+    sparse-depth rows -- one teacher-forced training step of the generic kernels against the CPU oracle."""
+    from loss_functions.LossComputerHip01 import LossComputerHip
+    n_sparse = 16 if scene == 'realestate' else 0
+    n = 48
+    b = vo.synthetic_batch(n - n_sparse, 801, scene=scene, nf=nf, n_sparse=n_sparse)
+    params = vo.init_params(802, depth=depth, width=width, scale=1.6)
+    rng = vo.synthetic_rng(n, 64, 128, 803)
+    p = vo.params_to_torch(params, requires_grad=True)
+    cfg_o = {'ndc': b['ndc'], 'n_coarse': 64, 'n_fine': 128, 'noise_std': 1.0, 'depth': depth}
+    ref = vo.render_rays(p, b, cfg_o, rng, train=True, sec_views=True)
+    lcfg = [{'name': 'MSE01', 'weight': 1}, {'name': 'VisibilityLoss01', 'weight': 0.1},
+            {'name': 'VisibilityPriorLoss01', 'iter_weights': {'0': 0, '30000': 0.001}}] + \
+           ([{'name': 'SparseDepthMSE01', 'weight': 0.1}] if n_sparse else [])
+    lref = vo.total_loss(b, ref, lcfg, 40000)
+    lref['TotalLoss'].backward()
+    model, cfg = _generic_model(dev, b['ndc'], params, depth, width, 128, sparse=n_sparse > 0)
+    model.train()
+    model.injected_rng = {k: v.to(dev) for k, v in rng.items()}
+    model.injected_z_fine = ref['z_vals_fine'].detach().to(dev)
+    rb = tp.ref_batch(b, dev, 40000)
+    out = model(rb)
+    for k in ref:
+        if k in out and k not in ('z_vals_coarse', 'z_vals_fine'):
+            if k.startswith('depth'):            # per-ray depth statistics of nearly empty rays: see assert_close_few_outliers
+                assert_close_few_outliers(out[k], ref[k], 1e-4, f'{depth}x{width} {k}', max_frac=0.05)
+            else:
+                tp.assert_close(out[k], ref[k], what=f'{depth}x{width} {k}')
+    lh = LossComputerHip(cfg).compute_losses(rb, out)
+    tp.assert_close(lh['TotalLoss'], lref['TotalLoss'], rtol=1e-4, floor=1e-6, what='TotalLoss')
+    lh['TotalLoss'].backward()
+    for k, t in model.named_parameters():
+        tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{depth}x{width} grad {k}')
+    # eval mode (no activation store requested: the generic kernels still get their scratch) == the oracle's eval render
+    model.eval()
+    model.injected_rng = model.injected_z_fine = None
+    with torch.no_grad():
+        ev = model(tp.ref_batch(b, dev, 0))
+    ro = vo.render_rays(vo.params_to_torch(params), b, cfg_o, None, train=False, sec_views=False)
+    tp.assert_close(ev['rgb_coarse'], ro['rgb_coarse'], what='eval rgb_coarse')
+    assert torch.isfinite(ev['rgb_fine']).all() and float((ev['rgb_fine'].cpu() - ro['rgb_fine']).abs().max()) < 5e-3

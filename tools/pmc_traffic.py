@@ -1,6 +1,6 @@
-"""profiles/r01_pmc_traffic.json from the per-counter summaries tools/profile_round.sh leaves (tools/pmc_summary.py
-tables): HBM bytes per training step and stage, MFMA-pipe busy fraction per kernel.
-    python tools/pmc_traffic.py gpurun_out/round fp16x3 profiles/r01_pmc_traffic.json"""
+"""profiles/r02_pmc_traffic_<prec>.json from the per-counter summaries tools/profile_round.sh leaves (tools/pmc_summary.py
+tables): HBM bytes per training step and stage, MFMA-pipe busy fraction and shader clock per kernel.
+    python tools/pmc_traffic.py gpurun_out/round fp32 profiles/r02_pmc_traffic_fp32.json"""
 import json
 import sys
 
@@ -29,16 +29,16 @@ def main(d, prec, out):
         per[st] = {'read': int(rd), 'written': int(wr), 'total': int(rd + wr)}
     busy = {}
     for k, (calls, us, cyc) in m.items():
-        if 'vn::k_mlp' in k or 'k_wgrad_split16_256' in k or 'k_wgrad_bf16x3_256' in k or 'k_wgrad_h16_256' in k:
+        if 'vn::k_mlp' in k or 'k_wgrad_split16_256' in k or 'k_wgrad_bf16x3_256' in k or 'k_wgrad_h16_256' in k or 'k_wgrad<2, 8, 4>' in k:
             bus = b.get(k)
             if not bus:
                 continue
             clk_ghz = bus[2] / bus[1] / 32 / 1e3            # SQ_BUSY_CYCLES is summed over the 32 shader engines
             busy[k] = {'sclk_ghz': round(clk_ghz, 2), 'mfma_busy_frac': round(cyc / (1024 * us * 1e-6 * clk_ghz * 1e9), 3)}
     res = {
-        'workload': {'rays_per_gpu': 4096, 'precision': prec, 'bf16_layout': 'narrow', 'steps_profiled': steps_profiled},
+        'workload': {'rays_per_gpu': 4096, 'precision': prec, 'layout': 'narrow', 'steps_profiled': steps_profiled},
         'source': 'rocprofv3 --kernel-trace --pmc <COUNTER> (one counter per pass, tools/profile_round.sh) of `python bench.py --steps 3 '
-                  '--warmup 1`; profiles/r01_pmc_<COUNTER>_%s.txt' % prec,
+                  '--warmup 1 --precision %s`; profiles/r02_pmc_<COUNTER>_%s.txt' % (prec, prec),
         'corrections': 'FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md '
                        'HBM section); WRITE_SIZE taken as is (k_pack_bf16n, whose output size is known, reads 1.00x)',
         'bytes_per_step': per,

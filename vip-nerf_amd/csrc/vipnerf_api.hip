@@ -12,6 +12,7 @@
 #include <cstring>
 #include "vipnerf_bf16n.h"
 #include "vipnerf_camera.h"
+#include "vipnerf_generic.h"
 #include "vipnerf_mlp.h"
 #include "vipnerf_prof.h"
 #include "vipnerf_ray.h"
@@ -74,8 +75,21 @@ static int check_cfg(const vipnerf_config *cfg) {
         set_error("precision=%d unsupported", cfg->precision); return VIPNERF_E_UNSUPPORTED; }
     if (cfg->bf16_layout < VIPNERF_LAYOUT_DEFAULT || cfg->bf16_layout > VIPNERF_LAYOUT_NARROW) {
         set_error("bf16_layout=%d unsupported", cfg->bf16_layout); return VIPNERF_E_UNSUPPORTED; }
+    const int dpt = cfg->netdepth ? cfg->netdepth : D, wid = cfg->netwidth ? cfg->netwidth : W;
+    const int lp = cfg->pe_degrees ? (cfg->pe_degrees & 0xff) : LP, lv = cfg->pe_degrees ? ((cfg->pe_degrees >> 8) & 0xff) : LV;
+    if (dpt < 1 || dpt > D || wid < 8 || wid > W || wid % 8 || lp < 0 || lp > 16 || lv < 0 || lv > 8) {
+        set_error("MLP topology netdepth=%d netwidth=%d degrees %d/%d unsupported (depth 1..8, width 8..256 multiple of 8, degrees <= 16 / 8)",
+                  dpt, wid, lp, lv); return VIPNERF_E_UNSUPPORTED; }
+    if (!gen_is_fused_topology(gen_topo(dpt, wid, lp, lv)) && cfg->precision != VIPNERF_PREC_FP32) {
+        set_error("the generic-topology kernels (netdepth=%d netwidth=%d) are fp32 only; precision=%d", dpt, wid, cfg->precision);
+        return VIPNERF_E_UNSUPPORTED; }
     return VIPNERF_OK;
 }
+static GenTopo cfg_topo(const vipnerf_config *cfg) {
+    return gen_topo(cfg->netdepth ? cfg->netdepth : D, cfg->netwidth ? cfg->netwidth : W, cfg->pe_degrees ? (cfg->pe_degrees & 0xff) : LP,
+                    cfg->pe_degrees ? ((cfg->pe_degrees >> 8) & 0xff) : LV);
+}
+static bool cfg_generic(const vipnerf_config *cfg) { return !gen_is_fused_topology(cfg_topo(cfg)); }
 
 int launch_mlp_fwd_bf16(const MlpFwdArgs &a, int precision, hipStream_t st);
 int launch_mlp_bwd_bf16(const MlpBwdArgs &a, int precision, hipStream_t st);
@@ -197,12 +211,34 @@ int32_t vipnerf_pack_weights_p(const vipnerf_mlp_params *params, int32_t precisi
     return launch_pack_bf16n(params, precision, (float *)packed + packed_total_floats(precision), (hipStream_t)stream);
 }
 
+size_t vipnerf_packed_weights_bytes_c(const vipnerf_config *cfg) {
+    if (check_cfg(cfg)) return 0;
+    return cfg_generic(cfg) ? gen_params(cfg_topo(cfg)).total * sizeof(float) : vipnerf_packed_weights_bytes_p(cfg->precision);
+}
+
+int32_t vipnerf_pack_weights_c(const vipnerf_config *cfg, const vipnerf_mlp_params *params, void *packed, vipnerf_stream_t stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (!cfg_generic(cfg)) return vipnerf_pack_weights_p(params, cfg->precision, packed, stream);
+    if (!params || !packed) { set_error("pack_weights: NULL argument"); return VIPNERF_E_ARG; }
+    return launch_gen_pack(cfg_topo(cfg), params, (float *)packed, (hipStream_t)stream);
+}
+
 int32_t vipnerf_query_workspace(const vipnerf_config *cfg, int64_t n_rays, size_t *acts_bytes, size_t *bwd_bytes) {
     int rc = check_cfg(cfg);
     if (rc) return rc;
     if (n_rays < 0) { set_error("n_rays < 0"); return VIPNERF_E_ARG; }
     const size_t Pc = (size_t)n_rays * cfg->n_coarse;
     const size_t Pf = cfg->n_fine > 0 ? (size_t)n_rays * (cfg->n_coarse + cfg->n_fine) : 0;
+    if (cfg_generic(cfg)) {
+        const GenTopo t = cfg_topo(cfg);
+        if (acts_bytes) *acts_bytes = (gen_acts(Pc, cfg->n_sec, t).total + (Pf ? gen_acts(Pf, cfg->n_sec, t).total : 0)) * sizeof(float);
+        if (bwd_bytes) {
+            const size_t a = gen_bwd(Pc, cfg->n_sec, t).total, b = Pf ? gen_bwd(Pf, cfg->n_sec, t).total : 0;
+            *bwd_bytes = (a > b ? a : b) * sizeof(float);
+        }
+        return VIPNERF_OK;
+    }
     if (acts_bytes)
         *acts_bytes = cfg->save_acts ? (act_layout(Pc, cfg->n_sec).total + (Pf ? act_layout(Pf, cfg->n_sec).total : 0)) * sizeof(float) : 0;
     if (bwd_bytes) {
@@ -296,6 +332,8 @@ int32_t vipnerf_render_forward(const vipnerf_config *cfg, const vipnerf_rays *ra
     if ((rc = check_level(cfg, &out->coarse, "coarse"))) return rc;
     if (cfg->n_fine > 0 && (rc = check_level(cfg, &out->fine, "fine"))) return rc;
     if (cfg->save_acts && !acts) { set_error("render_forward: save_acts set but acts is NULL"); return VIPNERF_E_ARG; }
+    const bool generic = cfg_generic(cfg);
+    if (generic && !acts) { set_error("render_forward: the generic-topology kernels need the `acts` workspace (vipnerf_query_workspace)"); return VIPNERF_E_ARG; }
     hipStream_t st = (hipStream_t)stream;
     const int64_t N = rays->n_rays;
     if (N == 0) return VIPNERF_OK;
@@ -345,7 +383,12 @@ int32_t vipnerf_render_forward(const vipnerf_config *cfg, const vipnerf_rays *ra
             ma.al = act_layout((size_t)N * S, V);
             ma.acts = (float *)acts + (lv ? act_layout(Pc, V).total : 0);
         }
-        {
+        if (generic) {
+            const GenTopo t = cfg_topo(cfg);
+            float *ga = (float *)acts + (lv ? gen_acts((size_t)N * Sc, V, t).total : 0);
+            ProfScope ps(lv ? "mlp_fwd_fine" : "mlp_fwd_coarse", st);
+            if ((rc = launch_gen_fwd(t, ma.src, ma.ns, ma.packed, ma.sigma, ma.rgb, ma.vis, ma.vis2, ga, st))) return rc;
+        } else {
             ProfScope ps(lv ? "mlp_fwd_fine" : "mlp_fwd_coarse", st);
             if ((rc = launch_mlp_fwd_any(ma, cfg->precision, st, cfg->bf16_layout))) return rc;
         }
@@ -378,14 +421,33 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
         const vipnerf_level_out &L = lv ? out->fine : out->coarse;
         const vipnerf_mlp_grads *G = lv ? grads_fine : grads_coarse;
         for (int i = 0; i < VIPNERF_N_PARAMS; ++i)
-            if (!G->g[i]) { set_error("render_backward: grad pointer %d is NULL", i); return VIPNERF_E_ARG; }
+            if (!G->g[i] && gen_param_numel(cfg_topo(cfg), i)) { set_error("render_backward: grad pointer %d is NULL", i); return VIPNERF_E_ARG; }
         if (N == 0) {
             continue;
         }
         const int S = lv ? Sc + Sf : Sc;
         const size_t P = (size_t)N * S;
-        const BwdLayout bl = bwd_layout(P, V, cfg->precision == VIPNERF_PREC_FP16X3H);
         float *bw = (float *)bwd_ws;
+        if (cfg_generic(cfg)) {
+            const GenTopo t = cfg_topo(cfg);
+            const GenBwd gb = gen_bwd(P, V, t);
+            CompositeBwdArgs cb;
+            memset(&cb, 0, sizeof(cb));
+            cb.N = N; cb.S = S; cb.V = V; cb.ndc = cfg->ndc; cb.white_bkgd = cfg->white_bkgd;
+            cb.rays_o = rays->rays_o; cb.rays_d = rays->rays_d; cb.rays_d_s = rays->rays_d_s; cb.lvl = L;
+            cb.g = lv ? gout->fine : gout->coarse;
+            cb.dsig = bw + gb.dsig; cb.drgb = bw + gb.drgb; cb.dvis = bw + gb.dvis; cb.dvis2 = bw + gb.dvis2;
+            {
+                ProfScope ps("composite_bwd", st);
+                if ((rc = launch_composite_bwd(cb, st))) return rc;
+            }
+            const PointSrc src = ray_points(cfg, rays, S, L.z_vals);
+            const float *ga = (const float *)acts + (lv ? gen_acts((size_t)N * Sc, V, t).total : 0);
+            ProfScope ps(lv ? "mlp_bwd_generic_fine" : "mlp_bwd_generic_coarse", st);
+            if ((rc = launch_gen_bwd(t, src, (const float *)(lv ? packed_fine : packed_coarse), L.raw_sigma, ga, bw, gb, G, st))) return rc;
+            continue;
+        }
+        const BwdLayout bl = bwd_layout(P, V, cfg->precision == VIPNERF_PREC_FP16X3H);
         // 1. compositing backward -> dLoss/d(raw network outputs)
         CompositeBwdArgs cb;
         memset(&cb, 0, sizeof(cb));

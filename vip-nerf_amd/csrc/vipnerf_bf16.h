@@ -178,7 +178,7 @@ struct WStreamT {
     static constexpr int PER_WAVE = ROTATE ? CH : CH / WAVES;
     static_assert(CH % WAVES == 0 && (NBUF == 2 || PER_WAVE * (NBUF - 2) <= 63), "vmcnt is a 6-bit counter");
     __device__ __forceinline__ void fetch() {
-#if defined(VN_EXP) && VN_EXP == 5
+#if defined(VN_EXP) && (VN_EXP == 5 || VN_EXP == 18)
         if (n_left < -1000)                       // timing experiment only: no weight DMA
 #endif
         if (ROTATE) {
@@ -232,7 +232,9 @@ struct WStreamT {
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
             }
             cturn = cturn + 1 == WAVES ? 0 : cturn + 1;
-            __builtin_amdgcn_s_barrier();
+#if !(defined(VN_EXP) && (VN_EXP == 16 || VN_EXP == 18))
+            __builtin_amdgcn_s_barrier();         // (timing experiments 16 / 18 race without it)
+#endif
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         } else if (NBUF == 2) {

@@ -202,6 +202,9 @@ __device__ __forceinline__ unsigned push_nibble(unsigned word, unsigned nib) { r
 // point P - 1 (clamped index, same inputs, same arithmetic) and so writes the very bytes the lane that owns P - 1 writes
 // -- a benign duplicate in place of a branch around each of the 16 tile stores of a layer.
 __device__ __forceinline__ void store_tile16(float *base, int64_t p, int ld, int q, int T, const floatx4 &v) {
+#if defined(VN_EXP) && VN_EXP == 1
+    return;                                   // timing experiment only: no activation / gradient tile stores
+#endif
     typedef float f4 __attribute__((ext_vector_type(4)));
     f4 val = {v[0], v[1], v[2], v[3]};
     __builtin_nontemporal_store(val, (f4 *)(base + (size_t)p * ld + 16 * T + 4 * q));

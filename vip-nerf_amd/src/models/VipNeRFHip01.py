@@ -27,26 +27,32 @@ from vipnerf_hip import _lib as L
 from vipnerf_hip import ops
 from vipnerf_hip.autograd import RenderFunction, RenderState
 
-_SUPPORTED = {'netdepth': 8, 'netwidth': 256, 'points_positional_encoding_degree': 10,
-              'views_positional_encoding_degree': 4, 'use_view_dirs': True, 'view_dependent_rgb': True,
-              'predict_visibility': True}
+_REQUIRED = {'use_view_dirs': True, 'view_dependent_rgb': True, 'predict_visibility': True}
 
 
 class MLPParams(torch.nn.Module):
-    """Parameter container with MLP's layout (reference VipNeRF01.py:451-492).  No forward of its own: the
-    network is evaluated inside the fused kernels."""
+    """Parameter container with MLP's layout (reference VipNeRF01.py:451-492: netdepth trunk layers of netwidth, gamma(x)
+    re-injected after layer 4 -- `self.skips = [4]` --, netwidth/2-wide view layer, rgb + visibility head).  No forward of
+    its own: the network is evaluated inside the HIP kernels -- the fused MFMA ones for the topology every shipped reference
+    config uses (8 x 256, degrees 10 / 4), the generic per-layer ones for any other (e.g. BASELINE configs[0]'s 4 x 64)."""
 
     def __init__(self, configs, mlp_configs):
         super().__init__()
-        for k, v in _SUPPORTED.items():
+        for k, v in _REQUIRED.items():
             if mlp_configs.get(k) != v:
-                raise L.VipNerfHipError(f"VipNeRFHip supports only {k}={v} (got {mlp_configs.get(k)!r}): the HIP kernels are "
-                                        f"specialised on the one topology every shipped reference config uses")
+                raise L.VipNerfHipError(f"VipNeRFHip supports only {k}={v} (got {mlp_configs.get(k)!r}): no shipped reference "
+                                        f"config or BASELINE config uses another value")
         self.configs, self.mlp_configs = configs, mlp_configs
-        W, d_pts, d_view = 256, 63, 27
+        D, W = int(mlp_configs['netdepth']), int(mlp_configs['netwidth'])
+        lp, lv = int(mlp_configs['points_positional_encoding_degree']), int(mlp_configs['views_positional_encoding_degree'])
+        if not (1 <= D <= 8 and 8 <= W <= 256 and W % 8 == 0 and 0 <= lp <= 16 and 0 <= lv <= 8):
+            raise L.VipNerfHipError(f'VipNeRFHip: netdepth={D} netwidth={W} degrees {lp}/{lv} unsupported (depth 1..8, width 8..256 and '
+                                    f'a multiple of 8, degrees <= 16 / 8)')
+        self.topology = (D, W, lp, lv)
+        d_pts, d_view = 3 + 6 * lp, 3 + 6 * lv
         self.pts_linears = torch.nn.ModuleList(
             [torch.nn.Linear(d_pts, W)] +
-            [torch.nn.Linear(W, W) if i != 4 else torch.nn.Linear(W + d_pts, W) for i in range(7)])
+            [torch.nn.Linear(W, W) if i != 4 else torch.nn.Linear(W + d_pts, W) for i in range(D - 1)])
         self.views_linears = torch.nn.ModuleList([torch.nn.Linear(d_view + W, W // 2)])
         self.pts_output_linear = torch.nn.Linear(W, 1)
         self.feature_linear = torch.nn.Linear(W, W)
@@ -55,7 +61,7 @@ class MLPParams(torch.nn.Module):
 
     def ordered_params(self):
         sd = dict(self.named_parameters())
-        return [sd[n] for n in ops.PARAM_ORDER]
+        return [sd[n] for n in ops.param_order(self.topology[0])]
 
 
 class VipNeRFHip(torch.nn.Module):
@@ -71,6 +77,13 @@ class VipNeRFHip(torch.nn.Module):
         self.predict_visibility = True
         self.coarse_model = MLPParams(configs, m['coarse_mlp'])
         self.fine_model = MLPParams(configs, m['fine_mlp']) if self.fine_mlp_needed else None
+        if self.fine_model is not None and self.fine_model.topology != self.coarse_model.topology:
+            raise L.VipNerfHipError('VipNeRFHip: coarse and fine MLP must share one topology '
+                                    f'({self.coarse_model.topology} vs {self.fine_model.topology})')
+        self.topology = self.coarse_model.topology
+        if self.topology != ops.DEFAULT_TOPOLOGY and m.get('hip_precision', 'fp32') != 'fp32':
+            raise L.VipNerfHipError(f"hip_precision={m.get('hip_precision')!r}: the generic-topology kernels (netdepth/netwidth/degrees "
+                                    f"{self.topology}) are fp32 only")
         self._calls = 0                 # Philox offset when the caller supplies no iter_num
         self._last_iter, self._sub = None, 0
         # parity hooks (tests): injected random numbers / teacher-forced fine depths for the next forward
@@ -147,7 +160,7 @@ class VipNeRFHip(torch.nn.Module):
         cfg = ops.make_config(self.ndc, m['coarse_mlp']['num_samples'], n_fine, V, train=train, noise_std=noise_std,
                               lindisp=m.get('lindisp', False), white_bkgd=m.get('white_bkgd', False), perturb=perturb,
                               precision=ops.PRECISIONS[m.get('hip_precision', 'fp32')],
-                              bf16_layout=ops.LAYOUTS[m.get('hip_bf16_layout', 'default')])
+                              bf16_layout=ops.LAYOUTS[m.get('hip_bf16_layout', 'default')], topology=self.topology)
         rng = None
         if train:
             rng = dict(self.injected_rng) if self.injected_rng is not None else {}

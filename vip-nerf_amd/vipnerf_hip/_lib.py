@@ -24,7 +24,7 @@ class Config(C.Structure):
     _fields_ = [('ndc', C.c_int32), ('n_coarse', C.c_int32), ('n_fine', C.c_int32), ('n_sec', C.c_int32),
                 ('train', C.c_int32), ('lindisp', C.c_int32), ('white_bkgd', C.c_int32), ('save_acts', C.c_int32),
                 ('noise_std', C.c_float), ('given_z_fine', C.c_int32), ('perturb', C.c_int32), ('precision', C.c_int32), ('bf16_layout', C.c_int32),
-                ('reserved', C.c_int32 * 3)]
+                ('netdepth', C.c_int32), ('netwidth', C.c_int32), ('pe_degrees', C.c_int32)]
 
 
 class Rays(C.Structure):
@@ -121,6 +121,8 @@ SYMBOLS = {
     'vipnerf_pack_weights': (C.c_int32, [P(MlpParams), c_f, c_f]),
     'vipnerf_packed_weights_bytes_p': (C.c_size_t, [C.c_int32]),
     'vipnerf_pack_weights_p': (C.c_int32, [P(MlpParams), C.c_int32, c_f, c_f]),
+    'vipnerf_packed_weights_bytes_c': (C.c_size_t, [P(Config)]),
+    'vipnerf_pack_weights_c': (C.c_int32, [P(Config), P(MlpParams), c_f, c_f]),
     'vipnerf_mlp_forward_p': (C.c_int32, [C.c_int64, C.c_int32, c_f, c_f, c_f, c_f, C.c_float, C.c_int32, c_f, c_f, c_f,
                                           c_f, c_f, c_f]),
     'vipnerf_query_workspace': (C.c_int32, [P(Config), C.c_int64, P(C.c_size_t), P(C.c_size_t)]),

@@ -35,8 +35,9 @@ class RenderFunction(torch.autograd.Function):
     def forward(ctx, state: RenderState, *params):
         cfg = state.cfg
         two = cfg.n_fine > 0
-        pc = ops.pack_weights(list(params[:L.VIPNERF_N_PARAMS]), precision=cfg.precision)
-        pf = ops.pack_weights(list(params[L.VIPNERF_N_PARAMS:]), precision=cfg.precision) if two else None
+        n_mlp = len(ops.param_order(ops.topology_of(cfg)[0]))        # tensors per MLP (24 for the default topology)
+        pc = ops.pack_weights(list(params[:n_mlp]), cfg=cfg)
+        pf = ops.pack_weights(list(params[n_mlp:]), cfg=cfg) if two else None
         need_bwd = state.grad_enabled and any(ctx.needs_input_grad)   # grad mode as seen by the caller of apply()
         cfg.save_acts = int(need_bwd)
         acts = None
@@ -47,6 +48,10 @@ class RenderFunction(torch.autograd.Function):
             if state.recompute_chunk:
                 cfg.save_acts = 0        # the activation store would not fit: backward re-renders chunk by chunk
             else:
+                acts = torch.empty(ab // 4, dtype=torch.float32, device=params[0].device)
+        if acts is None:
+            ab, _ = ops.query_workspace(cfg, n)     # non-zero without save_acts for the generic-topology kernels only: their
+            if ab:                                   # layers run through HBM
                 acts = torch.empty(ab // 4, dtype=torch.float32, device=params[0].device)
         coarse, fine, extras = ops.render_forward(cfg, state.batch, state.rng, pc, pf, acts, state.z_fine)
         state.extras = {k: v for k, v in extras.items() if not k.startswith('_')}
@@ -91,12 +96,13 @@ class RenderFunction(torch.autograd.Function):
         # all parameter gradients of the call live in ONE buffer, in parameter order (coarse, then fine): with
         # .grad = None beforehand autograd adopts the views as they are (no per-tensor fill / add / copy), and
         # dist.FlatGradBucket reduces the buffer with a single collective
-        sizes = [int(torch.Size(s).numel()) for s in ops.PARAM_SHAPES]
+        shapes = ops.param_shapes(ops.topology_of(cfg))
+        sizes = [int(torch.Size(s).numel()) for s in shapes]
         levels = 2 if ctx.fine is not None else 1
         flat = torch.empty(levels * sum(sizes), dtype=torch.float32, device=dev)
         views, o = [], 0
         for _ in range(levels):
-            for s, k in zip(ops.PARAM_SHAPES, sizes):
+            for s, k in zip(shapes, sizes):
                 views.append(flat[o:o + k].view(s))
                 o += k
         gc = views[:len(sizes)]
@@ -151,14 +157,15 @@ def _chunked_backward(ctx, gouts):
         if g is not None:
             k, lv = key.rsplit('_', 1)
             gl[lv][k] = g
-    sizes = [int(torch.Size(s).numel()) for s in ops.PARAM_SHAPES]
+    shapes = ops.param_shapes(ops.topology_of(cfg))
+    sizes = [int(torch.Size(s).numel()) for s in shapes]
     levels = 2 if two else 1
 
     def flat_views():
         flat = torch.empty(levels * sum(sizes), dtype=torch.float32, device=dev)
         views, o = [], 0
         for _ in range(levels):
-            for s, k in zip(ops.PARAM_SHAPES, sizes):
+            for s, k in zip(shapes, sizes):
                 views.append(flat[o:o + k].view(s))
                 o += k
         return flat, views

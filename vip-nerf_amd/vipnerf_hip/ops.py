@@ -7,12 +7,33 @@ import torch
 
 from . import _lib as L
 
-PARAM_ORDER = ([f'pts_linears.{i}.{wb}' for i in range(8) for wb in ('weight', 'bias')] +
-               ['views_linears.0.weight', 'views_linears.0.bias', 'pts_output_linear.weight',
-                'pts_output_linear.bias', 'feature_linear.weight', 'feature_linear.bias',
-                'views_output_linear.weight', 'views_output_linear.bias'])
-PARAM_SHAPES = ([s for i in range(8) for s in ((256, 63 if i == 0 else (319 if i == 5 else 256)), (256,))] +
-                [(128, 283), (128,), (1, 256), (1,), (256, 256), (256,), (4, 128), (4,)])
+TAIL_PARAMS = ['views_linears.0.weight', 'views_linears.0.bias', 'pts_output_linear.weight', 'pts_output_linear.bias',
+               'feature_linear.weight', 'feature_linear.bias', 'views_output_linear.weight', 'views_output_linear.bias']
+DEFAULT_TOPOLOGY = (8, 256, 10, 4)            # netdepth, netwidth, points / views positional-encoding degree
+
+
+def param_order(depth: int = 8):
+    """Parameter names of one MLP in the reference's construction order (VipNeRF01.py:472-491)."""
+    return [f'pts_linears.{i}.{wb}' for i in range(depth) for wb in ('weight', 'bias')] + TAIL_PARAMS
+
+
+def param_slots(depth: int = 8):
+    """vipnerf_mlp_params slot of each entry of param_order(depth): trunk layer i -> 2i, 2i+1; the rest -> 16..23."""
+    return list(range(2 * depth)) + list(range(16, 24))
+
+
+def param_shapes(topology=DEFAULT_TOPOLOGY):
+    depth, width, l_pts, l_view = topology
+    dp, dv = 3 + 6 * l_pts, 3 + 6 * l_view
+    trunk = []
+    for i in range(depth):
+        k = dp if i == 0 else (width + dp if (i == 5 and depth > 5) else width)
+        trunk += [(width, k), (width,)]
+    return trunk + [(width // 2, width + dv), (width // 2,), (1, width), (1,), (width, width), (width,), (4, width // 2), (4,)]
+
+
+PARAM_ORDER = param_order(8)
+PARAM_SHAPES = param_shapes(DEFAULT_TOPOLOGY)
 
 
 def _stream(dev=None):
@@ -59,8 +80,10 @@ def f32c(t: torch.Tensor) -> torch.Tensor:
 
 
 def make_config(ndc, n_coarse, n_fine, n_sec, train, noise_std=0.0, lindisp=False, white_bkgd=False,
-                save_acts=False, perturb=None, precision=0, bf16_layout=0) -> L.Config:
+                save_acts=False, perturb=None, precision=0, bf16_layout=0, topology=DEFAULT_TOPOLOGY) -> L.Config:
     c = L.Config()
+    c.netdepth, c.netwidth = int(topology[0]), int(topology[1])
+    c.pe_degrees = int(topology[2]) | (int(topology[3]) << 8)
     c.precision = int(precision)
     c.bf16_layout = int(bf16_layout)
     c.perturb = int(bool(train if perturb is None else perturb))
@@ -78,24 +101,37 @@ def packed_bytes(precision: int = 0) -> int:
     return L.load().vipnerf_packed_weights_bytes_p(int(precision))
 
 
-def pack_weights(params: List[torch.Tensor], out: Optional[torch.Tensor] = None, precision: int = 0) -> torch.Tensor:
-    """params: the 24 tensors of one MLP in PARAM_ORDER."""
+def topology_of(cfg: L.Config):
+    return (cfg.netdepth or 8, cfg.netwidth or 256, (cfg.pe_degrees & 0xff) if cfg.pe_degrees else 10,
+            ((cfg.pe_degrees >> 8) & 0xff) if cfg.pe_degrees else 4)
+
+
+def pack_weights(params: List[torch.Tensor], out: Optional[torch.Tensor] = None, precision: int = 0,
+                 cfg: Optional[L.Config] = None) -> torch.Tensor:
+    """params: the tensors of one MLP in param_order(depth) (24 for the default topology).  With `cfg` the image is the one
+    cfg's kernels consume (cfg.precision; the flat fp32 buffer of the generic kernels for a non-default topology)."""
     lib = L.load()
-    if len(params) != L.VIPNERF_N_PARAMS:
-        raise L.VipNerfHipError(f'expected {L.VIPNERF_N_PARAMS} parameter tensors, got {len(params)}')
+    if cfg is None:
+        cfg = make_config(True, 64, 0, 0, False, precision=precision)
+    topo = topology_of(cfg)
+    names, slots, shapes = param_order(topo[0]), param_slots(topo[0]), param_shapes(topo)
+    if len(params) != len(names):
+        raise L.VipNerfHipError(f'expected {len(names)} parameter tensors for netdepth {topo[0]}, got {len(params)}')
     mp = L.MlpParams()
     keep = []
-    for i, (t, shp) in enumerate(zip(params, PARAM_SHAPES)):
+    for t, name, slot, shp in zip(params, names, slots, shapes):
         if tuple(t.shape) != shp:
-            raise L.VipNerfHipError(f'parameter {PARAM_ORDER[i]} has shape {tuple(t.shape)}, the HIP path supports only '
-                                    f'the 8x256 topology ({shp})')
+            raise L.VipNerfHipError(f'parameter {name} has shape {tuple(t.shape)}, expected {shp} for topology {topo}')
         tc = f32c(t)
         keep.append(tc)
-        mp.p[i] = _p(tc, name=PARAM_ORDER[i])
+        mp.p[slot] = _p(tc, name=name)
     with on_device(*keep) as dev:
+        nbytes = lib.vipnerf_packed_weights_bytes_c(C.byref(cfg))
+        if nbytes == 0:
+            L.check(-2, 'vipnerf_packed_weights_bytes_c')
         if out is None:
-            out = torch.empty(packed_bytes(precision) // 4, dtype=torch.float32, device=dev)
-        L.check(lib.vipnerf_pack_weights_p(C.byref(mp), int(precision), _p(out), _stream(dev)), 'vipnerf_pack_weights_p')
+            out = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        L.check(lib.vipnerf_pack_weights_c(C.byref(cfg), C.byref(mp), _p(out), _stream(dev)), 'vipnerf_pack_weights_c')
     return out
 
 
@@ -228,11 +264,12 @@ def render_backward(cfg: L.Config, batch, packed_coarse, packed_fine, coarse, fi
     fill(og.coarse, grads_coarse)
     fill(og.fine, grads_fine)
     gc, gf = L.MlpGrads(), L.MlpGrads()
-    for i, t in enumerate(gparams_coarse):
-        gc.g[i] = _p(t, name=f'grad param {i}')
+    slots = param_slots(topology_of(cfg)[0])
+    for s, t in zip(slots, gparams_coarse):
+        gc.g[s] = _p(t, name=f'grad param slot {s}')
     if gparams_fine is not None:
-        for i, t in enumerate(gparams_fine):
-            gf.g[i] = _p(t, name=f'grad param {i}')
+        for s, t in zip(slots, gparams_fine):
+            gf.g[s] = _p(t, name=f'grad param slot {s}')
     with on_device(*keep, packed_coarse, packed_fine, acts, bwd_ws, *gparams_coarse) as dev:
         L.check(lib.vipnerf_render_backward(C.byref(cfg), C.byref(rays), _p(packed_coarse),
                                             _p(packed_fine) if packed_fine is not None else None, C.byref(out),

@@ -11,7 +11,7 @@ fine 8x256 MLP, fp32): forward -> fused losses (MSE 1, Visibility 0.1, Visibilit
 [RCCL all-reduce of the flat gradient bucket] -> Adam.  Batches are generated and resident in HBM before the timed region;
 the random numbers of a step are drawn on the device (Philox) inside it.  Rank 0 prints ONE JSON line.
 
-`value` / `dtype` are the EXACT-fp32 MFMA arithmetic (v_mfma_f32_32x32x2_f32), as configs[1] says; the faster split
+`value` / `dtype` are the EXACT-fp32 MFMA arithmetic (v_mfma_f32_16x16x4_f32 / 32x32x2_f32), as configs[1] says; the faster split
 arithmetics are timed by the same procedure (W warm-up + K timed steps each) and reported beside it (`value_fp16x3`, ...),
 each with its own `roofline` block (MFMA-bound path, algorithmic 630,272 MAC/point against the dense MFMA peak
 of the operand dtype).  `--scaling strong` runs BASELINE configs[3]'s statement (65,536 rays per iteration split over the
@@ -43,13 +43,19 @@ PEAK_CLOCK_MHZ = 2400.0         # the clock both peaks assume
 HBM_PEAK_GBS = 8000.0
 # arithmetic -> (dtype string, dense MFMA peak of the operand dtype, MFMAs issued per multiply-add, note)
 ARITH = {
-    'fp32': ('f32', FP32_MFMA_PEAK_TFLOPS, 1, 'exact fp32: v_mfma_f32_32x32x2_f32, bit-equivalent to an fmaf chain'),
+    'fp32': ('f32', FP32_MFMA_PEAK_TFLOPS, 1, 'exact fp32 operands, products and accumulation: v_mfma_f32_16x16x4_f32 in the MLP kernels (two '
+             'waves per SIMD), v_mfma_f32_32x32x2_f32 in the weight-gradient GEMMs; one MFMA per product'),
     'fp16x3': ('f32 emulated: operands split into 2 fp16 parts, 3 fp16 MFMAs per product, fp32 accumulate (22-bit operands, '
                'fp16 exponent range with power-of-two scaling; fp32-grade error on the goldens)', F16_MFMA_PEAK_TFLOPS, 3, ''),
     'bf16x6': ('f32 emulated: operands split into 3 bf16 parts, 6 bf16 MFMAs per product, fp32 accumulate', F16_MFMA_PEAK_TFLOPS, 6, ''),
     'bf16x3': ('f32 emulated: 2 bf16 parts, 3 bf16 MFMAs per product (~5e-6 relative error)', F16_MFMA_PEAK_TFLOPS, 3, ''),
     'fp16x3h': ('mixed: fp16x3 forward / data gradients; activations and gradients stored as fp16 for the weight gradients '
                 '(1 fp16 MFMA per product there)', F16_MFMA_PEAK_TFLOPS, 3, ''),
+    'fp16': ('f16 operands (rounded once, power-of-two scaling), ONE fp16 MFMA per product, fp32 accumulate; trunk activations / '
+             'gradients stored as fp16; fp32 master weights, encodings, heads, compositing, losses (BASELINE configs[4]-style mixed '
+             'precision; ~1e-3 relative gradient error)', F16_MFMA_PEAK_TFLOPS, 1, ''),
+    'bf16': ('bf16 operands (rounded once), ONE bf16 MFMA per product in the forward / data-gradient GEMMs, fp32 accumulate and '
+             'storage (BASELINE configs[4]-style mixed precision; ~1e-2 relative gradient error)', F16_MFMA_PEAK_TFLOPS, 1, ''),
 }
 STAGE_GROUPS = {'mlp_fwd': ('mlp_fwd_coarse', 'mlp_fwd_fine'), 'mlp_dgrad': ('mlp_dgrad_coarse', 'mlp_dgrad_fine'),
                 'wgrad': ('wgrad_256x256', 'wgrad_small')}
@@ -76,7 +82,7 @@ def make_batch(vo, n_rays, seed, dev, iter_num=40000):
 
 
 # ---------------------------------------------------------------------------------------------------- CPU baseline
-def cpu_baseline(vo, n_rays=4096, warm=2, timed=3, sweep=(16, 32, 64, 128), sweep_rays=1024):
+def cpu_baseline(vo, n_rays=4096, warm=2, timed=3, sweep=(8, 16, 24, 32, 48, 64, 128), sweep_rays=1024):
     """The CPU oracle (a PyTorch-eager restatement pinned to the reference, kind='port'; structure-equivalent incl. the
     reference's chunk = 4096 / netchunk = 16384 host loops) doing the SAME training step on the host cores (SURVEY.md 8d:
     the 4096-ray batch, 2 warm-ups -- the first steps are page-fault bound --, >= 3 timed).  The thread count is chosen by
@@ -104,10 +110,12 @@ def cpu_baseline(vo, n_rays=4096, warm=2, timed=3, sweep=(16, 32, 64, 128), swee
     for i in range(2):
         step(sweep_rays, i)                          # process-level warm-up (allocator growth, page faults)
     rates = {}
-    for t in cands:
+    for t in cands:                                  # ascending; stop once more threads clearly lose (each probe costs seconds)
         torch.set_num_threads(t)
         step(sweep_rays, 10)
         rates[t] = sweep_rays / min(step(sweep_rays, 11), step(sweep_rays, 12))
+        if rates[t] < 0.75 * max(rates.values()):
+            break
     best = max(rates, key=rates.get)
     torch.set_num_threads(best)
     for i in range(warm):
@@ -215,7 +223,7 @@ def main():
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--global-rays', type=int, default=65536, help='rays per step over all GPUs (strong scaling: BASELINE configs[3])')
     ap.add_argument('--precision', default='fp32', choices=list(ARITH), help='arithmetic of `value` (BASELINE configs[1] says fp32)')
-    ap.add_argument('--also', default='fp16x3', help='comma list of further arithmetics timed the same way ("" = none, "all")')
+    ap.add_argument('--also', default='fp16x3,fp16', help='comma list of further arithmetics timed the same way ("" = none, "all")')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-rays', type=int, default=4096)
     ap.add_argument('--no-render', action='store_true')

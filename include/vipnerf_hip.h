@@ -53,6 +53,14 @@ extern "C" {
  * of 4) and those GEMMs run single fp16 MFMAs: 8 GB less HBM traffic per 4096-ray step, parameter gradients at ~2e-4
  * relative error instead of fp32 grade.  A separate accuracy class (BASELINE configs[4] style mixed precision). */
 #define VIPNERF_PREC_FP16X3H 4
+/* Single-pass 16-bit modes (BASELINE configs[4] style mixed precision): ONE MFMA per product in the forward and
+ * data-gradient GEMMs, operands rounded once to fp16 (11-bit significand; power-of-two scaling as in FP16X3) or bf16
+ * (8 bits, fp32's range), fp32 accumulation, fp32 master weights / biases / encodings / heads / compositing / losses.
+ * FP16 also stores the trunk activations and gradients as fp16 and runs the 256x256 weight-gradient GEMMs as single fp16
+ * MFMAs (as FP16X3H); BF16 keeps them in fp32 (weight gradients: bf16 hi/lo, 3 MFMAs).  Errors ~1e-3 (fp16) / ~1e-2 (bf16)
+ * relative -- a separate accuracy class from everything above. */
+#define VIPNERF_PREC_FP16   5
+#define VIPNERF_PREC_BF16   6
 
 /* Lane layout of the BF16X3 / BF16X6 kernels (same arithmetic, same stored activations):
  * WIDE: 32-point waves on 32x32x16 MFMA, one wave per SIMD; NARROW: 16-point waves on 16x16x32, two waves per SIMD. */

@@ -240,3 +240,59 @@ def test_fp16x3_range(dev):
     big = run(10.0, 'fp16x3')
     assert torch.isfinite(run(10.0, 'fp32')['sigma']).all()
     assert not torch.isfinite(big['sigma']).all() and not torch.isfinite(big['rgb']).all()
+
+
+# ------------------------------------------------------------------------------------------------ single-MFMA 16-bit modes
+# 'fp16' / 'bf16' (VIPNERF_PREC_FP16 / BF16): operands rounded ONCE to 16 bits, one MFMA per product -- BASELINE configs[4]'s
+# mixed precision, a separate accuracy class: (output rtol, output floor relative to the tensor's max, gradient rel. L2).
+# Measured on the goldens (tools/prec_diag.py, tools/grad_diag.py): fp16 rgb 3e-5 abs, sigma 3e-4 of max, gradients 1e-3
+# median / 2.6e-2 worst tensor; bf16 2.6e-4, 2.4e-3, 1.6e-2 / 8.4e-2.
+SINGLE = {'fp16': (5e-3, 2e-3, 6e-2), 'bf16': (4e-2, 1.5e-2, 0.2)}
+
+
+@pytest.mark.parametrize('prec', list(SINGLE))
+@pytest.mark.parametrize('V', [1, 2])
+def test_single_mfma_mlp_forward_golden(dev, prec, V):
+    ops = tp.hip_ops()
+    rtol, floor, _ = SINGLE[prec]
+    g = tp.load(f'f2_mlp_v{V}')
+    params = vo.init_params(int(g['seed']), levels=('coarse',))
+    pr = ops.PRECISIONS[prec]
+    pk = ops.pack_weights([tp.cu(params[f'coarse_model.{n}'], dev) for n in ops.PARAM_ORDER], precision=pr)
+    for mode, noise in (('train', g['noise']), ('eval', None)):
+        o = ops.mlp_forward(pk, tp.cu(g['pts'], dev), tp.cu(g['view_dirs'], dev), tp.cu(g['view_dirs2'], dev),
+                            tp.cu(noise, dev) if noise is not None else None, 1.0, precision=pr)
+        for k, gk in (('sigma', 'sigma'), ('rgb', 'rgb'), ('visibility', 'vis'), ('visibility2', 'vis2')):
+            tp.assert_close(o[k], g[f'{gk}_{mode}'], rtol=rtol, floor=floor, what=f'{prec} {k} {mode}')
+
+
+@pytest.mark.parametrize('prec', list(SINGLE))
+@pytest.mark.parametrize('tag', ['llff', 'realestate', 'dtu'])
+def test_single_mfma_train_step_golden(dev, prec, tag):
+    from loss_functions.LossComputerHip01 import LossComputerHip
+    rtol, floor, gtol = SINGLE[prec]
+    g = tp.load(f'f5_train_{tag}')
+    n_sparse = int(g['n_sparse'])
+    b = vo.synthetic_batch(int(g['n']), int(g['seed_batch']), scene=str(g['scene']), nf=int(g['nf']), n_sparse=n_sparse)
+    params = vo.init_params(int(g['seed_params']), scale=float(g['scale_params']))
+    model, cfg = make_model(dev, b['ndc'], params, prec, sparse=n_sparse > 0)
+    model.train()
+    lossc = LossComputerHip(cfg)
+    model.injected_rng = {k[4:]: tp.cu(v, dev) for k, v in g.items() if k.startswith('rng_')}
+    model.injected_z_fine = tp.cu(g['out_z_vals_fine'], dev)
+    out = model(tp.ref_batch(b, dev, 40000))
+    for lv in ('coarse', 'fine'):
+        for rk in ('rgb', 'acc', 'visibility2', 'raw_sigma', 'raw_rgb', 'raw_visibility', 'raw_visibility2', 'weights', 'visibility'):
+            gk = f'out_{rk}_{lv}'
+            if gk in g:
+                tp.assert_close(out[f'{rk}_{lv}'], g[gk], rtol=rtol, floor=floor, what=f'{prec} {tag} {rk}_{lv}')
+    l40k = lossc.compute_losses(tp.ref_batch(b, dev, 40000), out)
+    tp.assert_close(l40k['TotalLoss'], g['l40k_TotalLoss'], rtol=4 * rtol, floor=1e-6, what=f'{prec} {tag} TotalLoss')
+    l40k['TotalLoss'].backward()
+    worst = 0.0
+    for k, p in model.named_parameters():
+        assert torch.isfinite(p.grad).all(), k
+        if 'grad_' + k in g:
+            tp.grad_close(p.grad.cpu().numpy(), g['grad_' + k], f'{prec} {tag} grad of {k}', l2_tol=gtol)
+            worst = max(worst, float(np.linalg.norm(p.grad.cpu().numpy() - g['grad_' + k]) / max(np.linalg.norm(g['grad_' + k]), 1e-30)))
+    print(f'{prec} {tag}: worst rel L2 error over the fully stored gradient tensors {worst:.2e}')

@@ -9,7 +9,7 @@ dev = torch.device('cuda:0')
 for tag in ('llff', 'dtu'):
     g = tp.load(f'f5_train_{tag}')
     n_sparse = int(g['n_sparse'])
-    for prec in ('fp32', 'bf16x6', 'fp16x3', 'fp16x3h', 'bf16x3'):
+    for prec in ('fp32', 'bf16x6', 'fp16x3', 'fp16x3h', 'bf16x3', 'fp16', 'bf16'):
         b = vo.synthetic_batch(int(g['n']), int(g['seed_batch']), scene=str(g['scene']), nf=int(g['nf']), n_sparse=n_sparse)
         params = vo.init_params(int(g['seed_params']), scale=float(g['scale_params']))
         model, cfg = tp.make_model(dev, b['ndc'], params, sparse=n_sparse > 0)

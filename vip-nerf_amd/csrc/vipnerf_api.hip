@@ -71,7 +71,7 @@ static int check_cfg(const vipnerf_config *cfg) {
         set_error("n_fine=%d unsupported (n_coarse+n_fine multiple of 32, <= 256)", cfg->n_fine); return VIPNERF_E_UNSUPPORTED; }
     if (cfg->n_sec < 0 || cfg->n_sec > VIPNERF_MAX_SEC) {
         set_error("n_sec=%d unsupported (0..%d)", cfg->n_sec, VIPNERF_MAX_SEC); return VIPNERF_E_UNSUPPORTED; }
-    if (cfg->precision < 0 || cfg->precision > VIPNERF_PREC_FP16X3H) {
+    if (cfg->precision < 0 || cfg->precision > VIPNERF_PREC_BF16) {
         set_error("precision=%d unsupported", cfg->precision); return VIPNERF_E_UNSUPPORTED; }
     if (cfg->bf16_layout < VIPNERF_LAYOUT_DEFAULT || cfg->bf16_layout > VIPNERF_LAYOUT_NARROW) {
         set_error("bf16_layout=%d unsupported", cfg->bf16_layout); return VIPNERF_E_UNSUPPORTED; }
@@ -203,7 +203,7 @@ int32_t vipnerf_pack_weights(const vipnerf_mlp_params *params, void *packed, vip
 size_t vipnerf_packed_weights_bytes_p(int32_t precision) { return packed_floats_all(precision) * sizeof(float); }
 
 int32_t vipnerf_pack_weights_p(const vipnerf_mlp_params *params, int32_t precision, void *packed, vipnerf_stream_t stream) {
-    if (precision < 0 || precision > VIPNERF_PREC_FP16X3H) { set_error("pack_weights: precision=%d unsupported", precision); return VIPNERF_E_UNSUPPORTED; }
+    if (precision < 0 || precision > VIPNERF_PREC_BF16) { set_error("pack_weights: precision=%d unsupported", precision); return VIPNERF_E_UNSUPPORTED; }
     int rc = vipnerf_pack_weights(params, packed, stream);
     if (rc) return rc;
     if (precision != VIPNERF_PREC_FP32 && precision < VIPNERF_PREC_FP16X3 &&
@@ -242,7 +242,7 @@ int32_t vipnerf_query_workspace(const vipnerf_config *cfg, int64_t n_rays, size_
     if (acts_bytes)
         *acts_bytes = cfg->save_acts ? (act_layout(Pc, cfg->n_sec).total + (Pf ? act_layout(Pf, cfg->n_sec).total : 0)) * sizeof(float) : 0;
     if (bwd_bytes) {
-        const bool h16 = cfg->precision == VIPNERF_PREC_FP16X3H;       // the only mode with an fp32 copy of dY_5 in the workspace
+        const bool h16 = cfg->precision == VIPNERF_PREC_FP16X3H || cfg->precision == VIPNERF_PREC_FP16;       // the only mode with an fp32 copy of dY_5 in the workspace
         const size_t a = bwd_total(Pc, cfg->n_sec, h16), b = Pf ? bwd_total(Pf, cfg->n_sec, h16) : 0;
         *bwd_bytes = (a > b ? a : b) * sizeof(float);       // levels run one after the other
     }
@@ -294,7 +294,7 @@ int32_t vipnerf_mlp_forward_p(int64_t n_points, int32_t n_sec, const float *pts,
                               const void *packed, float *sigma, float *rgb, float *vis, float *vis2,
                               vipnerf_stream_t stream) {
     clear_stale_hip_error();
-    if (precision < 0 || precision > VIPNERF_PREC_FP16X3H) { set_error("mlp_forward: precision=%d unsupported", precision); return VIPNERF_E_UNSUPPORTED; }
+    if (precision < 0 || precision > VIPNERF_PREC_BF16) { set_error("mlp_forward: precision=%d unsupported", precision); return VIPNERF_E_UNSUPPORTED; }
     if (n_points == 0) return VIPNERF_OK;
     if (!pts || !view_dirs || !packed || !sigma || !rgb || !vis || (n_sec > 0 && (!view_dirs2 || !vis2))) {
         set_error("mlp_forward: NULL argument"); return VIPNERF_E_ARG; }
@@ -447,7 +447,7 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
             if ((rc = launch_gen_bwd(t, src, (const float *)(lv ? packed_fine : packed_coarse), L.raw_sigma, ga, bw, gb, G, st))) return rc;
             continue;
         }
-        const BwdLayout bl = bwd_layout(P, V, cfg->precision == VIPNERF_PREC_FP16X3H);
+        const BwdLayout bl = bwd_layout(P, V, cfg->precision == VIPNERF_PREC_FP16X3H || cfg->precision == VIPNERF_PREC_FP16);
         // 1. compositing backward -> dLoss/d(raw network outputs)
         CompositeBwdArgs cb;
         memset(&cb, 0, sizeof(cb));
@@ -477,7 +477,7 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
         }
         // 3. weight gradients: dW = dY^T H as MFMA GEMMs over the point axis
         if ((rc = launch_wgrad(P, V, mb.acts, mb.al, bw, bl, G, cfg->precision, st,
-                               cfg->precision >= VIPNERF_PREC_FP16X3 ? (const unsigned *)(bw + bl.gmax) : nullptr))) return rc;
+                               (cfg->precision >= VIPNERF_PREC_FP16X3 && cfg->precision <= VIPNERF_PREC_FP16) ? (const unsigned *)(bw + bl.gmax) : nullptr))) return rc;
     }
     return VIPNERF_OK;
 }

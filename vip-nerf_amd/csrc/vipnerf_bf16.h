@@ -142,14 +142,16 @@ __device__ __forceinline__ floatx4 mfma_split(const f32q (&a)[NS], const f32q (&
 // acc[t] += A(k-step, tile) * B(k-step) over the significant cross terms; smallest terms first
 template <int NS, typename ACC, typename FR>
 __device__ __forceinline__ ACC mfma_split(const FR (&a)[NS], const FR (&b)[NS], ACC c) {
-    if (NS == 3) {
+    if constexpr (NS == 3) {
         c = mfma_bf(a[1], b[1], c);
         c = mfma_bf(a[2], b[0], c);
         c = mfma_bf(a[0], b[2], c);
     }
-    c = mfma_bf(a[1], b[0], c);
-    c = mfma_bf(a[0], b[1], c);
-    c = mfma_bf(a[0], b[0], c);
+    if constexpr (NS >= 2) {
+        c = mfma_bf(a[1], b[0], c);
+        c = mfma_bf(a[0], b[1], c);
+    }
+    c = mfma_bf(a[0], b[0], c);               // NS == 1: the single-MFMA 16-bit modes (VIPNERF_PREC_FP16 / BF16)
     return c;
 }
 
@@ -333,8 +335,10 @@ __device__ __forceinline__ void gemm_stage_bf(const float *stage, int lane, ACC 
                                               const FR (&B)[NB][NS], int ks0, WS &ws, MIDF &mid) {
     // narrow layout (floatx4 accumulators, 256 registers per wave) in bf16x6: one tile per group, two groups ahead
     constexpr bool TIGHT = sizeof(ACC) == 16 && NS == 3;
-    constexpr int G = TIGHT ? 1 : 2;
-    constexpr int D = (NS == 2 || TIGHT) ? 2 : 1;
+    // single-MFMA modes (NS == 1): a cell is ONE 16-cycle MFMA, so groups of four tiles, two groups (128 cycles of this wave's
+    // MFMAs, twice that with its SIMD partner's in between) ahead of the LDS latency
+    constexpr int G = TIGHT ? 1 : (NS == 1 ? 4 : 2);
+    constexpr int D = (NS == 2 || TIGHT || NS == 1) ? 2 : 1;
     constexpr int NBUF = D + 1;
     constexpr int NG = NKS * NT / G;
     static_assert(NT % G == 0 && NG >= D, "group shape");

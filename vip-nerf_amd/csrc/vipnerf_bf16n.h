@@ -28,7 +28,7 @@ __host__ __device__ constexpr int feat16(int s, int q, int e) { return 16 * (2 *
 //               (q,e) = (0,6) -> d[0], (0,7) -> d[1], (1,6) -> d[2]; other slots unused
 // -1 = unused slot (zero weight column).
 __host__ __device__ constexpr int pe_feat16(int s, int q, int e) {
-    return 8 * s + e < 15 ? 3 + 15 * q + 8 * s + e : (q < 3 ? q : -1);
+    return s >= 2 ? -1 : (8 * s + e < 15 ? 3 + 15 * q + 8 * s + e : (q < 3 ? q : -1));   // k-steps >= 2: padding (single-MFMA plan)
 }
 __host__ __device__ constexpr int dir_feat16(int q, int e) {
     return e < 6 ? 3 + 6 * q + e : (q == 0 ? e - 6 : (q == 1 && e == 6 ? 2 : -1));
@@ -48,12 +48,15 @@ struct BnPlan {
     static constexpr int WG = 64 * WAVES;
     static constexpr int NT = 16;                            // 16-feature tiles of a 256-wide layer
     static constexpr bool SKEW = NS == 2 && VN_SKEW;
-    static constexpr int KSB = SKEW ? 1 : (NS == 2 ? 2 : 1); // k-steps (of 32) per stage for a 16-tile layer
+    // k-steps (of 32) per stage for a 16-tile layer.  NS == 1 (single-MFMA fp16 / bf16 modes): 4, so that a stage is still
+    // 64 KiB; gamma(x) (2 k-steps) is then padded to one whole stage with zero weight columns (pe_feat16 -> -1).
+    static constexpr int KSB = SKEW ? 1 : (NS == 2 ? 2 : (NS == 1 ? 4 : 1));
+    static constexpr int PE_KS = KSB > 2 ? KSB : 2;          // k-steps the gamma(x) operand occupies (>= 2, whole stages)
     static constexpr int CH = KSB * NT * NS;                 // chunks (1 KiB) per stage: 64 (NS=2) / 48 (NS=3) / 32 (skew)
     static constexpr int STAGE_F = CH * CHUNK_F;
     static constexpr int NBUF = SKEW ? 3 : 2;
     static constexpr int ST_256 = 8 / KSB;                   // 256-deep contraction = 8 k-steps
-    static constexpr int ST_PE = 2 / KSB;                    // gamma(x): K = 64 -> 2 k-steps
+    static constexpr int ST_PE = PE_KS / KSB;                // gamma(x): K = 64 -> 2 k-steps (padded to a stage when KSB = 4)
     static constexpr int KSV = 2 * KSB;                      // k-steps per stage when a stage spans 8 tiles
     static constexpr int ST_VIEW_F = 8 / KSV;                // view layer forward: 8 tiles x 8 k-steps
     static constexpr int ST_VIEW_B = 4 / KSB;                // view layer dgrad: 16 tiles x 4 k-steps (K = 128)
@@ -94,7 +97,7 @@ struct BnPlan {
 
 // precision 0 (exact fp32): the fp32-narrow image (two 4-float parts per k-step: BnPlan<2>'s geometry) follows the wide fp32 one
 __host__ __device__ inline size_t packed_narrow_floats(int precision) {
-    return precision == 2 ? BnPlan<3>::PK_TOTAL_F : BnPlan<2>::PK_TOTAL_F;
+    return precision == 2 ? BnPlan<3>::PK_TOTAL_F : (precision >= 5 ? BnPlan<1>::PK_TOTAL_F : BnPlan<2>::PK_TOTAL_F);
 }
 
 // "fp16x3" (VIPNERF_PREC_FP16X3): the narrow kernels with fp16 fragments, x = x0 + x1 with 11-bit parts, three cross
@@ -280,7 +283,7 @@ __device__ __forceinline__ void split_pair(const floatx4 &lo, const floatx4 &hi,
 #ifndef VN_STORE_GROUP_B
 #define VN_STORE_GROUP_B 12
 #endif
-template <int H16, int NS, typename FR>
+template <int H16, int NS, typename FR, int NSTEP = 2>
 struct DeferredStores {
     float *dst; int64_t p; int q, wave, s0;
     const FR (*bin)[NS];
@@ -290,10 +293,10 @@ struct DeferredStores {
     __device__ __forceinline__ void at() const {
         if (H16 == 1 || (g == VN_STORE_GROUP_A) == (wave < 4)) {
 #pragma unroll
-            for (int s = s0; s < s0 + 2; ++s) {
+            for (int s = s0; s < s0 + NSTEP; ++s) {
                 if (H16 == 1) store_pair16h(dst, p, 256, q, s, bin[s][0]);
-                if (H16 == 2) store_pair_split(dst, p, 256, q, s, bin[s][0], bin[s][1]);
-                if (H16 == 3) store_pair_f32(dst, p, 256, q, s, bin[s][0], bin[s][1]);
+                if (H16 == 2) store_pair_split(dst, p, 256, q, s, bin[s][0], bin[s][NS > 1 ? 1 : 0]);
+                if (H16 == 3) store_pair_f32(dst, p, 256, q, s, bin[s][0], bin[s][NS > 1 ? 1 : 0]);
             }
         }
     }

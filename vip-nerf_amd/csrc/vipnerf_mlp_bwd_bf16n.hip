@@ -157,8 +157,8 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
         }
         split_pair<NS>(x0, x1, bin[s]);
         if (!DEFER && H16 == 1) store_pair16h(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0]);
-        if (!DEFER && H16 == 2) store_pair_split(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0], bin[s][1]);
-        if (!DEFER && H16 == 3) store_pair_f32(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0], bin[s][1]);
+        if (!DEFER && H16 == 2) store_pair_split(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0], bin[s][NS > 1 ? 1 : 0]);
+        if (!DEFER && H16 == 3) store_pair_f32(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0], bin[s][NS > 1 ? 1 : 0]);
     }
 
     // ---------------------------------------------------------------- feature layer, then layers 7..1
@@ -176,8 +176,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
             const float *st = jj == 0 ? ws.template wait<DEFER ? 2 * S_PER_STAGE : 16, DEFER ? 0 : 16>(it == 0)
                                       : ws.template wait<DEFER ? 2 * S_PER_STAGE : 0>();
             if (DEFER) {                                 // bin = the fp16 parts of the gradient this GEMM consumes
-                static_assert(!DEFER || S_PER_STAGE == 2, "DeferredStores sends two k-steps (four stores) per stage");
-                DeferredStores<H16, NS, FR> ds{a.bwd + (it == 0 ? a.bl.dyf : a.bl.dy[layer + 1]), p, q, wave, S_PER_STAGE * jj, bin};
+                DeferredStores<H16, NS, FR, S_PER_STAGE> ds{a.bwd + (it == 0 ? a.bl.dyf : a.bl.dy[layer + 1]), p, q, wave, S_PER_STAGE * jj, bin};
                 gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws, ds);
             } else {
                 gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
@@ -203,8 +202,8 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
             if (it < 7) {
                 split_pair<NS>(x[0], x[1], bin[s]);
                 if (!DEFER && H16 == 1) store_pair16h(dst, p, W, q, s, bin[s][0]);
-                if (!DEFER && H16 == 2) store_pair_split(dst, p, W, q, s, bin[s][0], bin[s][1]);
-                if (!DEFER && H16 == 3) store_pair_f32(dst, p, W, q, s, bin[s][0], bin[s][1]);
+                if (!DEFER && H16 == 2) store_pair_split(dst, p, W, q, s, bin[s][0], bin[s][NS > 1 ? 1 : 0]);
+                if (!DEFER && H16 == 3) store_pair_f32(dst, p, W, q, s, bin[s][0], bin[s][NS > 1 ? 1 : 0]);
             }
         }
     }
@@ -226,7 +225,8 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
     if (precision == 0) return launch_one_bwd_n<2, false, VN_F32_DEFER ? 3 : 0, true>(a, grid, st);
     if (precision == 1) return launch_one_bwd_n<2>(a, grid, st);
     if (precision == 2) return launch_one_bwd_n<3>(a, grid, st);
-    if (precision == 3 || precision == 4) {
+    if (precision == 6) return launch_one_bwd_n<1>(a, grid, st);
+    if (precision == 3 || precision == 4 || precision == 5) {
         // the level's largest seed first (one pass over 5+V floats per point)
         unsigned *slot = (unsigned *)(a.bwd + a.bl.gmax);
         VN_HIP(hipMemsetAsync(slot, 0, sizeof(unsigned), st));
@@ -235,6 +235,7 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
         VN_HIP(hipGetLastError());
         MlpBwdArgs b = a;
         b.gmax = slot;
+        if (precision == 5) return launch_one_bwd_n<1, true, 1>(b, grid, st);
         return precision == 4 ? launch_one_bwd_n<2, true, 1>(b, grid, st) : launch_one_bwd_n<2, true, VN_F16_PRESPLIT ? 2 : 0>(b, grid, st);
     }
     set_error("mlp_bwd_bf16n: precision %d", precision);

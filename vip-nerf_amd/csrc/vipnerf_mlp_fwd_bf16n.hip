@@ -144,8 +144,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
                 // the mask store when the tiles are deferred); later stages: the deferred stores behind the stage before
                 const float *st = jj == 0 ? ws.template wait<DEFER ? 1 : EPI_STORES>() : ws.template wait<DEFER ? 2 * S_PER_STAGE : 0>();
                 if (DEFER) {                             // bin = the fp16 parts of h_layer, the output of layer - 1
-                    static_assert(!DEFER || S_PER_STAGE == 2, "DeferredStores sends two k-steps (four stores) per stage");
-                    DeferredStores<H16, NS, FR> ds{a.acts + a.al.h[layer - 1], p, q, wave, S_PER_STAGE * jj, bin};
+                    DeferredStores<H16, NS, FR, S_PER_STAGE> ds{a.acts + a.al.h[layer - 1], p, q, wave, S_PER_STAGE * jj, bin};
                     gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws, ds);
                 } else {
                     gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
@@ -153,9 +152,14 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             }
         }
         if (layer == 0 || layer == SKIP_LAYER) {         // gamma(x) columns last: bin is dead, its registers hold bpe
-            FR bpe[2][NS];
+            FR bpe[PL::PE_KS][NS];
 #pragma unroll
             for (int s = 0; s < 2; ++s) split8<NS>(pe[s], bpe[s]);
+#pragma unroll
+            for (int s = 2; s < PL::PE_KS; ++s) {            // padding k-steps of the single-MFMA plan (zero weight columns)
+                const float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                split8<NS>(zero, bpe[s]);
+            }
 #pragma unroll
             for (int jj = 0; jj < PL::ST_PE; ++jj) {
                 const float *st = ws.wait();
@@ -204,8 +208,8 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             if (F16) { x[0] *= XS; x[1] *= XS; }
             split_pair<NS>(x[0], x[1], bin[s]);
             if (SAVE && !DEFER && H16 == 1 && layer < 8) store_pair16h(dst, p, W, q, s, bin[s][0]);
-            if (SAVE && !DEFER && H16 == 2 && layer < 8) store_pair_split(dst, p, W, q, s, bin[s][0], bin[s][1]);
-            if (SAVE && !DEFER && H16 == 3 && layer < 8) store_pair_f32(dst, p, W, q, s, bin[s][0], bin[s][1]);
+            if (SAVE && !DEFER && H16 == 2 && layer < 8) store_pair_split(dst, p, W, q, s, bin[s][0], bin[s][NS > 1 ? 1 : 0]);
+            if (SAVE && !DEFER && H16 == 3 && layer < 8) store_pair_f32(dst, p, W, q, s, bin[s][0], bin[s][NS > 1 ? 1 : 0]);
         }
         if (SAVE && layer < 8) *(uint2 *)(a.acts + a.al.hm[layer] + ((size_t)p * 4 + q) * 2) = make_uint2(mk0, mk1);
     }
@@ -308,6 +312,8 @@ int launch_mlp_fwd_bf16n(const MlpFwdArgs &a, int precision, hipStream_t st) {
     if (precision == 2) return a.acts ? launch_one_n<true, 3>(a, grid, st) : launch_one_n<false, 3>(a, grid, st);
     if (precision == 3) return a.acts ? launch_one_n<true, 2, true, VN_F16_PRESPLIT ? 2 : 0>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);
     if (precision == 4) return a.acts ? launch_one_n<true, 2, true, 1>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);
+    if (precision == 5) return a.acts ? launch_one_n<true, 1, true, 1>(a, grid, st) : launch_one_n<false, 1, true>(a, grid, st);
+    if (precision == 6) return a.acts ? launch_one_n<true, 1>(a, grid, st) : launch_one_n<false, 1>(a, grid, st);
     set_error("mlp_fwd_bf16n: precision %d", precision);
     return VIPNERF_E_ARG;
 }

@@ -135,6 +135,10 @@ int launch_pack_bf16n(const vipnerf_mlp_params *p, int precision, void *packed_b
         hipLaunchKernelGGL((k_pack_bf16n<3, false>), dim3((unsigned)((BnPlan<3>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);
     } else if (precision == 3 || precision == 4) {
         hipLaunchKernelGGL((k_pack_bf16n<2, true>), dim3((unsigned)((BnPlan<2>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);
+    } else if (precision == 5) {
+        hipLaunchKernelGGL((k_pack_bf16n<1, true>), dim3((unsigned)((BnPlan<1>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);
+    } else if (precision == 6) {
+        hipLaunchKernelGGL((k_pack_bf16n<1, false>), dim3((unsigned)((BnPlan<1>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);
     } else {
         set_error("pack_bf16n: precision %d", precision);
         return VIPNERF_E_ARG;

@@ -1170,7 +1170,8 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
               chunk_single = chunk_pts / WGRAD_SINGLE_SPLIT;
     float *partial = bwd + bl.partial;
     // storage of the 256x256 class's operands: 0 = fp32, 1 = fp16 high parts (FP16X3H), 2 = fp16 hi + lo planes (FP16X3)
-    const int halves = precision == VIPNERF_PREC_FP16X3H ? 1 : (precision == VIPNERF_PREC_FP16X3 && VN_F16_PRESPLIT ? 2 : 0);
+    const int halves = (precision == VIPNERF_PREC_FP16X3H || precision == VIPNERF_PREC_FP16) ? 1
+                       : (precision == VIPNERF_PREC_FP16X3 && VN_F16_PRESPLIT ? 2 : 0);
 
     WgArgs c88, c82, c48, c41, c18, c14;       // classes by (M tiles, K tiles)
     WgReduceArgs red;

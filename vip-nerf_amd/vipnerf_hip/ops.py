@@ -93,7 +93,7 @@ def make_config(ndc, n_coarse, n_fine, n_sec, train, noise_std=0.0, lindisp=Fals
     return c
 
 
-PRECISIONS = {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2, 'fp16x3': 3, 'fp16x3h': 4}
+PRECISIONS = {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2, 'fp16x3': 3, 'fp16x3h': 4, 'fp16': 5, 'bf16': 6}
 LAYOUTS = {'default': 0, 'wide': 1, 'narrow': 2}
 
 

@@ -17,7 +17,7 @@ def to_dev(b, it):
 for scene, nf, n, n_sparse in (('realestate', 3, 2048, 2048), ('dtu', 3, 4096, 0)):
     b = vo.synthetic_batch(n, 7, scene=scene, nf=nf, n_sparse=n_sparse)
     res = {}
-    for prec in ('fp32', 'fp16x3', 'fp16x3h'):
+    for prec in ('fp32', 'fp16x3', 'fp16x3h', 'fp16', 'bf16'):
         cfg = bench.model_configs(); cfg['model']['hip_precision'] = prec
         cfg['data_loader']['ndc'] = bool(b['ndc'])
         if n_sparse:

@@ -114,6 +114,9 @@ class RenderFunction(torch.autograd.Function):
         return (None, *gc, *(gf or []))
 
 
+MAX_RECOMPUTE_CHUNK = 8192
+
+
 def _recompute_chunk(state: RenderState, n: int, acts_bytes: int, bwd_bytes: int, dev) -> int:
     """0 if the training workspace of an n-ray call (activation store + backward scratch, ~ 5 MB per ray) fits the
     budget, else the ray-chunk size for a re-rendering backward.  The reference bounds memory with its `chunk` host loop
@@ -124,11 +127,13 @@ def _recompute_chunk(state: RenderState, n: int, acts_bytes: int, bwd_bytes: int
     if limit is None:
         free, _ = torch.cuda.mem_get_info(dev)
         cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-        limit = int(0.8 * (free + cached))
+        limit = int(0.7 * (free + cached))      # one allocation (activation store + scratch) must fit next to what lives already
     if acts_bytes + bwd_bytes <= limit or n <= 256:
         return 0
     per_ray = (acts_bytes + bwd_bytes) / n
-    chunk = int(limit / per_ray) // 256 * 256
+    # chunks of at most 8192 rays (~42 GB): large enough to run the kernels at full efficiency, small enough that the caching
+    # allocator keeps one such block from step to step (allocating and releasing 200 GB per step costs seconds)
+    chunk = min(int(limit / per_ray), MAX_RECOMPUTE_CHUNK) // 256 * 256
     c = L.Config.from_buffer_copy(state.cfg)
     c.save_acts = 1
     while chunk >= 256 and sum(ops.query_workspace(c, chunk)) > limit:      # the scratch is not exactly linear in n
@@ -174,6 +179,16 @@ def _chunked_backward(ctx, gouts):
     tmp, tviews = flat_views()
     base = int(state.rng.get('ray_base', 0)) if state.rng else 0
     chunk = state.recompute_chunk
+    # ONE workspace for all chunks (activation store + backward scratch of the largest chunk), allocated after handing the
+    # allocator's cached blocks back: tens of GB each, and a stale block of the wrong size would otherwise count twice
+    cmax = L.Config.from_buffer_copy(cfg)
+    cmax.save_acts = 1
+    ab_max, bb_max = ops.query_workspace(cmax, min(chunk, n))
+    try:
+        ws = torch.empty((ab_max + bb_max) // 4, dtype=torch.float32, device=dev)
+    except torch.OutOfMemoryError:
+        torch.cuda.empty_cache()                 # cached blocks of other sizes (a smaller earlier batch's workspace, ...)
+        ws = torch.empty((ab_max + bb_max) // 4, dtype=torch.float32, device=dev)
     for s in range(0, n, chunk):
         e = min(n, s + chunk)
         c = L.Config.from_buffer_copy(cfg)
@@ -187,10 +202,9 @@ def _chunked_backward(ctx, gouts):
                 rng['ray_ids'] = rng['ray_ids'].reshape(-1)
             rng['ray_base'] = base + s
         ab, bb = ops.query_workspace(c, e - s)
-        acts = torch.empty(ab // 4, dtype=torch.float32, device=dev)
+        acts, bwd_ws = ws[:ab // 4], ws[ab_max // 4:ab_max // 4 + bb // 4]
         zf = ctx.fine['z_vals'][s:e] if two else None
         coarse, fine, _ = ops.render_forward(c, sub, rng, ctx.packed[0], ctx.packed[1], acts, zf)
-        bwd_ws = torch.empty(bb // 4, dtype=torch.float32, device=dev)
         dst = views if s == 0 else tviews
         ops.render_backward(c, sub, ctx.packed[0], ctx.packed[1], coarse, fine, _slice_rows(gl['coarse'], n, s, e),
                             _slice_rows(gl['fine'], n, s, e) if two else None, acts, bwd_ws, dst[:len(sizes)],
@@ -198,6 +212,7 @@ def _chunked_backward(ctx, gouts):
         if s > 0:
             total.add_(tmp)
         del acts, bwd_ws, coarse, fine
+    del ws
     ctx.acts = ctx.coarse = ctx.fine = ctx.packed = None
     return (None, *views)
 

@@ -307,18 +307,17 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             elapsed = float(t.item())
-        sclk = None
-        if rank == 0:
-            try:
-                with ClockSampler(dev) as cs:
-                    for i in range(max(4, args.steps // 2)):
-                        step(i)
-                    torch.cuda.synchronize()
-                sclk = cs.median()
-            except Exception:
-                sclk = None
+        # shader clock under load: EVERY rank runs the extra steps (they contain the collective); rank 0 samples
+        cs = ClockSampler(dev) if rank == 0 else None
+        if cs is not None:
+            cs.__enter__()
+        for i in range(max(4, args.steps // 2)):
+            step(i)
+        torch.cuda.synchronize()
+        if cs is not None:
+            cs.__exit__(None, None, None)
         barrier()
-        return elapsed, prof, sclk
+        return elapsed, prof, (cs.median() if cs is not None else None)
 
     elapsed, prof, sclk = timed_run(args.precision)
     also = [] if (args.no_other_precisions or world > 1) else \

@@ -84,3 +84,28 @@ def test_two_hip_ranks_on_one_gpu_equal_one_process():
         assert np.array_equal(ret[f'z{r}'], zf[ret[f'ids{r}']]), f'rank {r}: fine depths differ from the single-process run'
     err = np.linalg.norm(ret[0] - ref) / np.linalg.norm(ref)
     assert err < 1e-5, f'averaged rank gradients vs single-process gradients: {err:.2e}'
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """The driver's N > 1 launch line (torch.distributed.run, one rank per GPU) with two ranks sharing this GPU over gloo:
+    bench.py must come back with ONE JSON line from rank 0 -- every rank has to take part in every collective of the
+    timed region AND of the clock-sampling steps behind it."""
+    import json
+    import subprocess
+    env = dict(os.environ, VIPNERF_DIST_BACKEND='gloo')
+    port = 32000 + (os.getpid() % 2000)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--rays', '1024']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['scaling'] == 'weak' and res['value'] > 0 and res['config']['global_rays'] == 2048
+    assert res['dtype'] == 'f32' and res['roofline']['bound'] == 'mfma' and 0 < res['roofline']['frac'] < 1
+    # strong scaling: configs[3]'s 65,536 rays would not leave room for two ranks on one GPU; the flag itself with a small total
+    cmd2 = cmd[:-2] + ['--scaling', 'strong', '--global-rays', '2048']
+    r = subprocess.run(cmd2, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    assert res['scaling'] == 'strong' and res['config']['rays_per_gpu'] == 1024 and res['config']['global_rays'] == 2048

@@ -1,0 +1,124 @@
+"""A compact trainer around the HIP path with the reference trainer's sequence (reference src/Trainer01.py):
+
+    train()           :265-311  per iteration: learning-rate decay -> train_one_iter -> [validation] -> [checkpoint]
+    train_one_iter()  :61-107   next batch -> zero_grad -> per sub-batch: forward, compute_losses, TotalLoss.backward -> step
+    run_validation()  :109-263  eval-mode render of whole frames (here: camera -> uint8 image on the GPU, predict_frame)
+    save / load_model :352-381  the reference's checkpoint files (CheckpointHip01)
+    learning rate     src/lr_decayers/NeRFLearningRateDecayer01.py:14-24   lr_init * 0.1 ** (iter / (lr_decay * 1000))
+
+The reference's Trainer is a Python harness around tensorboard / skimage / its dataset loaders and stays what it is inside the
+reference tree (the model and loss classes drop into it by name).  This file is the same loop for use WITHOUT
+that tree: batches come from RayGeneratorHip + BatchIndexScheduler (on-device ray generation, the reference's index schedule),
+several GPUs are one process each with vipnerf_hip.dist (row-class-aware shards, one all-reduce of the flat gradient bucket),
+and nothing of the per-iteration work runs on the host.  No CPU fallback anywhere.
+"""
+import os
+import sys
+from pathlib import Path
+
+import numpy
+import torch
+
+try:
+    import vipnerf_hip  # noqa: F401
+except ImportError:
+    for cand in (os.environ.get('VIPNERF_HIP_ROOT'), str(Path(__file__).resolve().parents[1])):
+        if cand and cand not in sys.path:
+            sys.path.insert(0, cand)
+from vipnerf_hip import dist as vdist
+
+import CheckpointHip01 as ckpt
+from data_preprocessors.RayGeneratorHip01 import BatchIndexScheduler, RayGeneratorHip, predict_frame
+from loss_functions.LossComputerHip01 import LossComputerHip
+from models.ModelFactory import get_model
+
+
+class TrainerHip:
+    def __init__(self, configs: dict, ray_generator: RayGeneratorHip, scheduler: BatchIndexScheduler, output_dirpath=None,
+                 rank: int = 0, world: int = 1):
+        """configs: the reference's config dict (`model`, `losses`, `data_loader.ndc`, `optimizer.{lr_initial, lr_decay, beta1,
+        beta2}`, `num_iterations`, optional `sub_batch_size`, `validation_interval`, `model_save_interval`)."""
+        self.configs, self.gen, self.scheduler = configs, ray_generator, scheduler
+        self.rank, self.world = rank, world
+        self.device = ray_generator.device
+        self.output_dirpath = Path(output_dirpath) if output_dirpath is not None else None
+        self.model = get_model(configs, None).to(self.device)
+        vdist.broadcast_parameters(self.model)
+        self.loss_computer = LossComputerHip(configs)
+        oc = configs.get('optimizer', {})
+        self.lr_init, self.lr_decay_steps = float(oc.get('lr_initial', 5e-4)), float(oc.get('lr_decay', 250)) * 1000
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self.lr_init,
+                                          betas=(oc.get('beta1', 0.9), oc.get('beta2', 0.999)), fused=True)
+        self.bucket = vdist.FlatGradBucket(self.model.parameters())
+
+    def learning_rate(self, iter_num: int) -> float:
+        return self.lr_init * (0.1 ** (iter_num / self.lr_decay_steps))
+
+    def train_one_iter(self, iter_num: int) -> dict:
+        batch = self.gen.get_next_batch(iter_num, scheduler=self.scheduler)
+        if self.world > 1:
+            batch = vdist.shard_batch(batch, self.rank, self.world)
+        self.bucket.release()                                # = optimizer.zero_grad(set_to_none=True)
+        n = batch['rays_o'].shape[0]
+        sub = int(self.configs.get('sub_batch_size', n)) or n
+        logged = {}
+        for s in range(0, n, sub):
+            sb = {k: (v[s:s + sub] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == n else v) for k, v in batch.items()}
+            sb['common_data'] = dict(batch['common_data'])
+            if 'rng_ray_ids' not in sb:
+                sb['rng_ray_base'] = s                       # sub-batches draw the rows' own numbers of the batch's streams
+            out = self.model(sb)
+            losses = self.loss_computer.compute_losses(sb, out)
+            losses['TotalLoss'].backward()
+            for k, v in losses.items():
+                v = v['loss_value'] if isinstance(v, dict) else v
+                logged[k] = logged.get(k, 0.0) + float(v.detach()) if isinstance(v, torch.Tensor) else logged.get(k, 0.0) + float(v)
+        self.bucket.all_reduce_mean()
+        self.optimizer.step()
+        return logged
+
+    def run_validation(self, frames=None) -> dict:
+        """Eval-mode render of the generator's cameras; PSNR against their images when the generator holds them."""
+        self.model.eval()
+        res = {}
+        for f in (range(self.gen.n) if frames is None else frames):
+            r = predict_frame(self.model, self.gen, frame=f)
+            if self.gen.images is not None:
+                ref = self.gen.images[f]
+                mse = torch.mean((r['image'].float() / 255 - ref) ** 2)
+                r['psnr'] = float(-10 * torch.log10(mse.clamp_min(1e-12)))
+            res[f] = r
+        self.model.train()
+        return res
+
+    def save_model(self, iter_num: int):
+        if self.rank == 0 and self.output_dirpath is not None:
+            return ckpt.save_model(self.model, self.optimizer, iter_num, self.output_dirpath)
+
+    def load_model(self) -> int:
+        latest = None if self.output_dirpath is None else self.output_dirpath / 'saved_models' / 'Model_Latest.tar'
+        if latest is None or not latest.exists():
+            return 0
+        return ckpt.load_model(self.model, latest, self.optimizer, map_location=self.device)
+
+    def train(self, log_every: int = 0) -> list:
+        total = int(self.configs['num_iterations'])
+        val_int = int(self.configs.get('validation_interval', 0))
+        save_int = int(self.configs.get('model_save_interval', 0))
+        start = self.load_model()
+        history = []
+        self.model.train()
+        for iter_num in range(start, total):
+            lr = self.learning_rate(iter_num)
+            for g in self.optimizer.param_groups:
+                g['lr'] = lr
+            losses = self.train_one_iter(iter_num)
+            losses['lr'] = lr
+            history.append(losses)
+            if log_every and self.rank == 0 and (iter_num + 1) % log_every == 0:
+                print(f"iter {iter_num + 1}: " + ' '.join(f'{k} {v:.5f}' for k, v in losses.items()), flush=True)
+            if val_int and (iter_num + 1) % val_int == 0:
+                losses['validation_psnr'] = float(numpy.mean([v.get('psnr', float('nan')) for v in self.run_validation().values()]))
+            if save_int and (iter_num + 1) % save_int == 0:
+                self.save_model(iter_num + 1)
+        return history

@@ -566,3 +566,54 @@ def test_other_topologies_vs_oracle(dev, depth, width, scene, nf):
     ro = vo.render_rays(vo.params_to_torch(params), b, cfg_o, None, train=False, sec_views=False)
     tp.assert_close(ev['rgb_coarse'], ro['rgb_coarse'], what='eval rgb_coarse')
     assert torch.isfinite(ev['rgb_fine']).all() and float((ev['rgb_fine'].cpu() - ro['rgb_fine']).abs().max()) < 5e-3
+
+
+# ------------------------------------------------------------------------------------------------ ragged / tiny batches
+@pytest.mark.parametrize('prec', ['fp32', 'fp16x3', 'fp16'])
+@pytest.mark.parametrize('n,n_sparse', [(1, 0), (37, 0), (5, 7), (0, 3)])
+def test_ragged_and_tiny_batches(dev, prec, n, n_sparse):
+    """The reference's loader hands over short batches at every epoch end (golden F6b: 24 and 47 rows), and a batch may hold
+    a single ray or no nerf row at all: sizes that are not multiples of anything, against the oracle (fp32-grade modes) or for
+    finiteness and agreement at the mode's tolerance (fp16)."""
+    from loss_functions.LossComputerHip01 import LossComputerHip
+    tot = n + n_sparse
+    b = vo.synthetic_batch(n, 901, scene='realestate', nf=3, n_sparse=n_sparse)
+    if n_sparse == 0:
+        b.pop('indices_mask_sparse_depth', None)
+    params = vo.init_params(902, scale=1.6)
+    rng = vo.synthetic_rng(tot, 64, 128, 903)
+    p = vo.params_to_torch(params, requires_grad=True)
+    ref = vo.render_rays(p, b, {'ndc': True, 'n_coarse': 64, 'n_fine': 128, 'noise_std': 1.0}, rng, train=True, sec_views=True)
+    lcfg = [{'name': 'MSE01', 'weight': 1}, {'name': 'VisibilityLoss01', 'weight': 0.1},
+            {'name': 'VisibilityPriorLoss01', 'iter_weights': {'0': 0, '30000': 0.001}}] + ([{'name': 'SparseDepthMSE01', 'weight': 0.1}] if n_sparse else [])
+    lref = vo.total_loss(b, ref, lcfg, 40000)
+    lref['TotalLoss'].backward()
+    model, cfg = tp.make_model(dev, True, params, sparse=n_sparse > 0)
+    cfg['model']['hip_precision'] = prec
+    model.train()
+    model.injected_rng = {k: v.to(dev) for k, v in rng.items()}
+    model.injected_z_fine = ref['z_vals_fine'].detach().to(dev)
+    rb = tp.ref_batch(b, dev, 40000)
+    out = model(rb)
+    lh = LossComputerHip(cfg).compute_losses(rb, out)
+    lh['TotalLoss'].backward()
+    rtol, gtol = (1e-4, 2e-3) if prec != 'fp16' else (5e-3, 8e-2)
+    assert out['rgb_fine'].shape == (tot, 3) and torch.isfinite(lh['TotalLoss'])
+    for k in ('rgb_coarse', 'rgb_fine', 'acc_fine', 'weights_fine', 'visibility2_fine', 'raw_sigma_fine'):
+        tp.assert_close(out[k], ref[k], rtol=rtol, floor=1e-5 if prec != 'fp16' else 2e-3, what=f'{prec} n={n}+{n_sparse} {k}')
+    tp.assert_close(lh['TotalLoss'], lref['TotalLoss'], rtol=4 * rtol, floor=1e-6, what='TotalLoss')
+    for k, t in model.named_parameters():
+        assert torch.isfinite(t.grad).all(), k
+        tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{prec} n={n}+{n_sparse} grad {k}', l2_tol=gtol)
+
+
+def test_empty_batch_is_a_no_op(dev):
+    b = vo.synthetic_batch(4, 905, scene='fern', nf=2)
+    model, cfg = tp.make_model(dev, True, vo.init_params(906, scale=1.6))
+    model.train()
+    rb = {k: (v[:0] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == 4 else v) for k, v in tp.ref_batch(b, dev, 0).items()}
+    out = model(rb)
+    assert out['rgb_fine'].shape == (0, 3) and out['raw_visibility2_fine'].shape == (0, 192, 1, 1)
+    (out['rgb_fine'].sum() + out['depth_fine'].sum()).backward()
+    for k, t in model.named_parameters():
+        assert t.grad is not None and float(t.grad.abs().max()) == 0, k

@@ -155,7 +155,7 @@ constexpr int WGRAD_SPLIT_PE = 8, WGRAD_SPLIT_THIN = 16, WGRAD_SINGLE_SPLIT = 8;
 __host__ __device__ inline int wgrad_chunk_pts(size_t P) {            // multiple of 32 * WGRAD_SPLIT_THIN
     const int n = wgrad_chunks(P);
     const size_t c = (P + n - 1) / n, q = 32 * WGRAD_SPLIT_THIN;
-    return (int)((c + q - 1) / q * q);
+    return (int)(c == 0 ? q : (c + q - 1) / q * q);          // (an empty batch still gets a well-formed plan)
 }
 __host__ __device__ inline int wgrad_chunks_split(size_t P, int split) {
     const size_t c = wgrad_chunk_pts(P) / split;

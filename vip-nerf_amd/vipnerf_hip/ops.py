@@ -233,6 +233,9 @@ def render_forward(cfg: L.Config, batch: Dict[str, torch.Tensor], rng: Optional[
                 raise RuntimeError(f"render_forward: rng['ray_ids'] has {ids.numel()} elements, {n} expected")
             keep.append(ids)
             rs.ray_ids = _p(ids, torch.int64, name='ray_ids')
+    if n == 0:                       # an empty batch: empty outputs (their NULL data pointers are not handed to the library)
+        extras['_keep'] = keep
+        return coarse, fine, extras
     with on_device(*keep, packed_coarse, packed_fine, acts) as dev:
         L.check(lib.vipnerf_render_forward(C.byref(cfg), C.byref(rays), C.byref(rs) if rs is not None else None,
                                            _p(packed_coarse), _p(packed_fine) if packed_fine is not None else None,
@@ -270,6 +273,10 @@ def render_backward(cfg: L.Config, batch, packed_coarse, packed_fine, coarse, fi
     if gparams_fine is not None:
         for s, t in zip(slots, gparams_fine):
             gf.g[s] = _p(t, name=f'grad param slot {s}')
+    if rays.n_rays == 0:             # no ray, no gradient (the library OVERWRITES the gradient tensors: zeros here)
+        for t in list(gparams_coarse) + list(gparams_fine or []):
+            t.zero_()
+        return keep
     with on_device(*keep, packed_coarse, packed_fine, acts, bwd_ws, *gparams_coarse) as dev:
         L.check(lib.vipnerf_render_backward(C.byref(cfg), C.byref(rays), _p(packed_coarse),
                                             _p(packed_fine) if packed_fine is not None else None, C.byref(out),

@@ -267,12 +267,13 @@ def gen_f4():
         keys_plain=np.array(keys_plain), **{'plain_' + k: v for k, v in out_plain.items()}, **d)
 
 
-def gen_f5(tag, scene, nf, n, n_sparse, seed, depth=8, width=256, n_fine=128, pscale=1.6):
+def gen_f5(tag, scene, nf, n, n_sparse, seed, depth=8, width=256, n_fine=128, pscale=1.6, white_bkgd=False, lindisp=False):
     b = vo.synthetic_batch(n, seed, scene=scene, nf=nf, n_sparse=n_sparse)
     ndc = b['ndc']
     levels = ('coarse', 'fine') if n_fine > 0 else ('coarse',)
     cfg = ref_configs(ndc, depth=depth, width=width, n_fine=n_fine, netchunk=1024, chunk=4096,
                       sparse=n_sparse > 0)
+    cfg['model'].update(white_bkgd=white_bkgd, lindisp=lindisp)      # branches no shipped config takes (VipNeRF01.py:190-193, 379-380)
     params = vo.init_params(seed + 1, depth=depth, width=width, levels=levels, scale=pscale)
     model = ref_model(cfg, params).train()
     lossc = LossComputer(cfg)
@@ -300,7 +301,7 @@ def gen_f5(tag, scene, nf, n, n_sparse, seed, depth=8, width=256, n_fine=128, ps
     for k, v in after.items():
         d['adig_' + k] = digest(v)
     npz(f'f5_train_{tag}', scene=scene, nf=nf, n=n, n_sparse=n_sparse, seed_batch=seed, seed_params=seed + 1,
-        scale_params=pscale, depth=depth, width=width, n_fine=n_fine,
+        scale_params=pscale, depth=depth, width=width, n_fine=n_fine, white_bkgd=white_bkgd, lindisp=lindisp,
         **{'rng_' + k: v for k, v in rng.items()}, **d)
 
 
@@ -465,6 +466,7 @@ if __name__ == '__main__':
     gen_f5('realestate', 'realestate', 3, 16, 16, 510)
     gen_f5('dtu', 'dtu', 3, 24, 0, 520)
     gen_f5('toy', 'toy', 2, 64, 0, 530, depth=4, width=64, n_fine=0, pscale=1.0)
+    gen_f5('dtu4wl', 'dtu', 4, 20, 0, 540, white_bkgd=True, lindisp=True)      # V = 3 secondary views, white background, lindisp
     gen_f6()
     gen_f6b()
     gen_f7()

@@ -246,7 +246,7 @@ def test_eval_render_golden(dev):
     assert_close(plain['rgb_coarse'], g['plain_rgb_coarse'], what='plain rgb_coarse')
 
 
-@pytest.mark.parametrize('tag', ['llff', 'realestate', 'dtu'])
+@pytest.mark.parametrize('tag', ['llff', 'realestate', 'dtu', 'dtu4wl'])
 def test_train_step_golden(dev, tag):
     """F5: forward outputs, the losses at iter 0 / 40000, parameter gradients and one Adam step, against the
     reference.  RNG draws and fine depths are the reference's (teacher forcing)."""
@@ -256,6 +256,7 @@ def test_train_step_golden(dev, tag):
     b = vo.synthetic_batch(int(g['n']), int(g['seed_batch']), scene=str(g['scene']), nf=int(g['nf']), n_sparse=n_sparse)
     params = vo.init_params(int(g['seed_params']), scale=float(g['scale_params']))
     model, cfg = make_model(dev, b['ndc'], params, sparse=n_sparse > 0)
+    cfg['model'].update(white_bkgd=bool(g.get('white_bkgd', False)), lindisp=bool(g.get('lindisp', False)))   # 'dtu4wl': nf = 4, both on
     model.train()
     lossc = LossComputerHip(cfg)
     opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.999))

@@ -99,7 +99,7 @@ def test_f4_eval_render():
         close(plain[str(k)], g['plain_' + str(k)], rtol=2e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize('tag', ['llff', 'realestate', 'dtu', 'toy'])
+@pytest.mark.parametrize('tag', ['llff', 'realestate', 'dtu', 'toy', 'dtu4wl'])
 def test_f5_train_step(tag):
     g = load(f'f5_train_{tag}')
     depth, width, n_fine = int(g['depth']), int(g['width']), int(g['n_fine'])
@@ -110,7 +110,9 @@ def test_f5_train_step(tag):
                             scale=float(g['scale_params']))
     p = vo.params_to_torch(params, requires_grad=True)
     rng = {k[4:]: T(v) for k, v in g.items() if k.startswith('rng_')}
-    out = vo.render_rays(p, b, _cfg(b['ndc'], n_fine, depth), rng, train=True, sec_views=True)
+    cfg = _cfg(b['ndc'], n_fine, depth)
+    cfg.update(white_bkgd=bool(g.get('white_bkgd', False)), lindisp=bool(g.get('lindisp', False)))   # 'dtu4wl': V = 3, both on
+    out = vo.render_rays(p, b, cfg, rng, train=True, sec_views=True)
     _check_outputs(out, g, levels, rtol=2e-5, atol=2e-6)
     lcfg = [{'name': 'MSE01', 'weight': 1}, {'name': 'VisibilityLoss01', 'weight': 0.1},
             {'name': 'VisibilityPriorLoss01', 'iter_weights': {'0': 0, '30000': 0.001}}]

@@ -57,8 +57,14 @@ ARITH = {
     'bf16': ('bf16 operands (rounded once), ONE bf16 MFMA per product in the forward / data-gradient GEMMs, fp32 accumulate and '
              'storage (BASELINE configs[4]-style mixed precision; ~1e-2 relative gradient error)', F16_MFMA_PEAK_TFLOPS, 1, ''),
 }
+# kernels of a step (profile scopes of the library) and the share of a pass's algorithmic MACs each one carries: the eight 256x256
+# weight-gradient GEMMs of an MLP are 8 x 65,536 of the 630,272 MAC/point, the thin GEMMs (encoding columns, view branch, heads) the rest
 STAGE_GROUPS = {'mlp_fwd': ('mlp_fwd_coarse', 'mlp_fwd_fine'), 'mlp_dgrad': ('mlp_dgrad_coarse', 'mlp_dgrad_fine'),
-                'wgrad': ('wgrad_256x256', 'wgrad_small')}
+                'wgrad_256x256': ('wgrad_256x256',), 'wgrad_small': ('wgrad_small',)}
+STAGE_MACS = {'mlp_fwd': MAC_PER_POINT, 'mlp_dgrad': MAC_PER_POINT, 'wgrad_256x256': 8 * 65536, 'wgrad_small': MAC_PER_POINT - 8 * 65536}
+STAGE_KERNEL = {'mlp_fwd': 'k_mlp_fwd* (MLP forward: one launch per level)', 'mlp_dgrad': 'k_mlp_bwd* (MLP data gradients: one launch per level)',
+                'wgrad_256x256': 'k_wgrad<2,8,4> / k_wgrad_*_256 (the eight 256x256 weight-gradient GEMMs: one launch per level)',
+                'wgrad_small': 'the thin weight-gradient GEMMs + the chunk reduction (six launches per level)'}
 
 
 def model_configs():
@@ -177,21 +183,23 @@ def roofline_block(prec, prof, steps, rays, ms_per_step, sclk_mhz):
     stage_ms = {g: sum(prof.get(k, (0, 0.0))[1] for k in ks) / steps for g, ks in STAGE_GROUPS.items()}
     launches = {g: sum(prof.get(k, (0, 0.0))[0] for k in ks) / steps for g, ks in STAGE_GROUPS.items()}
     other_ms = sum(v[1] for k, v in prof.items() if not any(k in ks for ks in STAGE_GROUPS.values())) / steps
-    flop_pass = MAC_PER_POINT * 2.0 * POINTS_PER_RAY * rays           # one pass (forward, data gradient or weight gradient) per step
-    dom = max(stage_ms, key=stage_ms.get)
-    tf = lambda ms: flop_pass / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    kernel = {'mlp_fwd': 'k_mlp_fwd* (coarse + fine launch)', 'mlp_dgrad': 'k_mlp_bwd* (coarse + fine launch)',
-              'wgrad': 'k_wgrad* (all weight-gradient launches of a step)'}[dom]
-    r = {'bound': 'mfma', 'kernel': kernel, 'achieved': round(tf(stage_ms[dom]), 2), 'peak': peak, 'unit': 'TFLOP/s',
-         'frac': round(tf(stage_ms[dom]) / peak, 4),
-         'definition': 'algorithmic 630,272 MAC/point x 2 x %d points per step-pass / device time of the kernel\'s launches in a step '
-                       '(mean over %d timed steps, HIP events on the launch stream) / dense MFMA peak of the operand dtype; forward, '
-                       'data-gradient and weight-gradient passes each count the full MAC count (SURVEY.md 8d, the 3x convention)'
-                       % (POINTS_PER_RAY * rays, steps),
+    points = POINTS_PER_RAY * rays
+    flop_pass = MAC_PER_POINT * 2.0 * points                          # one pass (forward, data gradient or weight gradient) per step
+    dom = max(stage_ms, key=stage_ms.get)                             # the kernel with the largest device time per step
+    tf = lambda g: STAGE_MACS[g] * 2.0 * points / (stage_ms[g] * 1e-3) / 1e12 if stage_ms[g] > 0 else 0.0
+    wg_ms = stage_ms['wgrad_256x256'] + stage_ms['wgrad_small']
+    r = {'bound': 'mfma', 'kernel': STAGE_KERNEL[dom], 'achieved': round(tf(dom), 2), 'peak': peak, 'unit': 'TFLOP/s',
+         'frac': round(tf(dom) / peak, 4),
+         'definition': 'algorithmic MACs of the dominant kernel (%d MAC/point of the pass\'s 630,272) x 2 x %d points per step / device time '
+                       'of its launches in a step (mean over %d timed steps, HIP events on the launch stream) / dense MFMA peak of the operand '
+                       'dtype; forward, data-gradient and weight-gradient passes each count 630,272 MAC/point (SURVEY.md 8d, the 3x convention)'
+                       % (STAGE_MACS[dom], points, steps),
          'avg_launch_ms': round(stage_ms[dom] / max(launches[dom], 1), 4), 'launches_per_step': launches[dom],
-         'mfmas_issued_per_product': issued, 'frac_issued': round(min(tf(stage_ms[dom]) * issued / peak, 9.99), 4),
-         'stages': {g: {'ms_per_step': round(stage_ms[g], 3), 'achieved_tflops': round(tf(stage_ms[g]), 1), 'frac': round(tf(stage_ms[g]) / peak, 4)}
-                    for g in stage_ms},
+         'mfmas_issued_per_product': issued, 'frac_issued': round(min(tf(dom) * issued / peak, 9.99), 4),
+         'stages': dict({g: {'ms_per_step': round(stage_ms[g], 3), 'achieved_tflops': round(tf(g), 1), 'frac': round(tf(g) / peak, 4)}
+                         for g in stage_ms},
+                        wgrad={'ms_per_step': round(wg_ms, 3), 'achieved_tflops': round(flop_pass / (wg_ms * 1e-3) / 1e12, 1) if wg_ms > 0 else 0.0,
+                               'frac': round(flop_pass / (wg_ms * 1e-3) / 1e12 / peak, 4) if wg_ms > 0 else 0.0}),
          'other_kernels_ms_per_step': round(other_ms, 3),
          'step_frac': round(3 * flop_pass / (ms_per_step * 1e-3) / 1e12 / peak, 4),
          'sclk_mhz': sclk_mhz, 'traffic': None}
@@ -201,7 +209,7 @@ def roofline_block(prec, prof, steps, rays, ms_per_step, sclk_mhz):
     r['algorithmic_bytes_per_step'] = algo_bytes
     tr, name = pmc_reference(prec, rays)
     if tr is not None:
-        r['traffic'] = tr['bytes_per_step'][dom]['total']
+        r['traffic'] = tr['bytes_per_step'][dom if dom in tr['bytes_per_step'] else 'wgrad']['total']
         step_bytes = sum(v['total'] for v in tr['bytes_per_step'].values())
         r['traffic_step'] = step_bytes
         r['traffic_ratio'] = round(step_bytes / algo_bytes, 1)

@@ -165,6 +165,10 @@ struct WStreamSkew {
 #endif
 template <typename PL, bool SK> struct StreamOf { typedef WStreamT<PL::CH, PL::NBUF, PL::WAVES, VN_DMA_MODE == 1, VN_DMA_MODE == 2> type; };
 template <typename PL> struct StreamOf<PL, true> { typedef WStreamSkew<PL::CH> type; };
+// every wave issues its eighth of a stage's DMA and drains it itself (plain vmcnt(0) + barrier): measured +1.8 % for the exact-fp32
+// EVAL kernel (0.887 -> 0.903 of the fp32 peak: no stores whose latency that vmcnt(0) would sit out, and no single wave 64 pieces
+// behind at the barrier); neutral for the 16-bit eval kernels, and a loss for every training kernel (their stores)
+template <typename PL> struct StreamShared { typedef WStreamT<PL::CH, PL::NBUF, PL::WAVES, false, false> type; };
 __device__ __forceinline__ void stream_begin(...) {}
 __device__ __forceinline__ void stream_end(...) {}
 template <int CH> __device__ __forceinline__ void stream_begin(WStreamSkew<CH> &w) { w.begin(); }

@@ -2,6 +2,7 @@
 // v_mfma_f32_16x16x32_bf16, 8 waves (two per SIMD) and 128 points per workgroup.  Same algorithm, stage order and
 // stored activations as vipnerf_mlp_fwd_bf16.hip; only the lane <-> (point, feature) map differs: lane (j, q) holds
 // features 16T + 4q .. +3 of tile T for point j.
+#include <type_traits>
 #include "vipnerf_bf16n.h"
 #include "vipnerf_mlp.h"
 
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
     const bool valid = p_raw < a.src.P;
     const int64_t p = valid ? p_raw : a.src.P - 1;
 
-    typename StreamOf<PL, PL::SKEW>::type ws;
+    typename std::conditional<F32 && !SAVE, typename StreamShared<PL>::type, typename StreamOf<PL, PL::SKEW>::type>::type ws;
     ws.start(a.packed + PL::PK_FWD, PL::F_STAGES, stage_buf, lane, wave);
     {
         const float4 *g4 = (const float4 *)(a.packed + PL::PK_RES);

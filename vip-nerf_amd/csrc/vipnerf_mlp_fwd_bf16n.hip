@@ -193,10 +193,10 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             for (int u = 0; u < 2; ++u) {
                 const int t = 2 * s + u;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) x[u][r] = relu_lo<F16>(x[u][r] * AU, lo);
+                for (int r = 0; r < 4; ++r) x[u][r] = relu_lo<F16 || (F32 && SAVE)>(x[u][r] * AU, lo);   // (+0 | positive | NaN for the bit masks)
                 if (SAVE) {
                     if (!(H16 && layer < 8)) store_tile16(dst, p, W, q, t, x[u]);
-                    if (F16) {
+                    if (F16 || F32) {
                         if (t < 8) mk0 = push_nibble(mk0, positive_nibble(x[u])); else mk1 = push_nibble(mk1, positive_nibble(x[u]));
                     } else {
                         unsigned m = 0;

@@ -29,6 +29,9 @@ __device__ __forceinline__ int wg_off(int f, int slot) {
     return row * 64 + ((slot ^ (((f & 3) ^ (f >> 4)) & 3)) << 4);
 }
 
+#ifndef VN_WGRAD_W8
+#define VN_WGRAD_W8 2            // exact-fp32 256 x 256 weight gradients: 0 = the 4-wave k_wgrad<2,8,4>; 2 / 4 = k_wgrad256_w8 with 8 / 16 waves
+#endif
 struct WgDesc {
     const float *A; int lda; int m_load;      // A[p][0..m_load) is read (m_load multiple of 4), zero beyond
     const float *B; int ldb; int k_load;
@@ -181,6 +184,102 @@ __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
     }
 }
 
+
+// The 256 x 256 fp32 GEMMs with EIGHT waves (two per SIMD): wave (wm, wk) owns 2 x 4 of the 8 x 8 tiles (128 accumulators), so a
+// second wave keeps a SIMD's MFMA pipe busy while the first one issues its vector-memory instructions.  Why it matters: a
+// global_load_dwordx4 holds a wave's issue port ~60 cycles whatever else is going on; the 4-wave kernel above issues 16 of them per
+// wave and 32-point block -- ~960 of the block's 16384 MFMA cycles with nothing else to issue on that SIMD, wherever in the block they
+// are placed (spreading them over the k-steps, or issuing the LDS stores at the block's start, measured no different: DESIGN.md 5).
+// Same tiles, same LDS layout, same partial-product format as k_wgrad<2, 8, 4>.
+template <int WK>       // waves along K: 2 -> 8 waves (2 x 4 tiles each), 4 -> 16 waves (2 x 2 tiles each)
+__global__ __launch_bounds__(256 * WK) void k_wgrad256_w8(WgArgs a) {
+    constexpr int MTW = 2, KTW = 8 / WK, Mp = 256, Kp = 256, NTH = 256 * WK, NLD = 2048 / NTH;   // float4 of A and of B per thread and block
+    constexpr int TILE_F = 32 * (Mp + Kp);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const WgDesc &d = a.d[blockIdx.y];
+    if ((int)blockIdx.x >= d.n_chunks) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int wm = wave & 3, wk = wave >> 2;
+    const int64_t p0 = (int64_t)blockIdx.x * a.chunk_pts;
+    const int64_t p1 = p0 + a.chunk_pts < a.P ? p0 + a.chunk_pts : a.P;
+    const int nblk = (int)((p1 - p0 + 31) / 32);
+
+    floatx16 acc[MTW][KTW];
+    float bsum[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        bsum[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KTW; ++j) acc[i][j] = (floatx16)(0.f);
+    }
+    float4 ra[NLD], rb[NLD];
+    const bool linA = d.lda == Mp && d.m_load == Mp, linB = d.ldb == Kp && d.k_load == Kp;
+    auto gload = [&](int blk) {
+        const int64_t pb = p0 + (int64_t)blk * 32;
+        if (pb + 32 <= p1 && linA && linB) {
+            const float4 *ta = (const float4 *)(d.A + (size_t)pb * Mp) + tid;
+            const float4 *tb = (const float4 *)(d.B + (size_t)pb * Kp) + tid;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) { ra[i] = ta[NTH * i]; rb[i] = tb[NTH * i]; }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + NTH * i, row = idx / 64, col = 4 * (idx % 64);
+            const bool oka = (pb + row < p1) && (col < d.m_load), okb = (pb + row < p1) && (col < d.k_load);
+            ra[i] = oka ? *(const float4 *)(d.A + (size_t)(pb + row) * d.lda + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[i] = okb ? *(const float4 *)(d.B + (size_t)(pb + row) * d.ldb + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&](int buf) {
+        float4 *la = (float4 *)(lds + buf * TILE_F), *lb = (float4 *)(lds + buf * TILE_F + 32 * Mp);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) { la[tid + NTH * i] = ra[i]; lb[tid + NTH * i] = rb[i]; }
+    };
+    if (nblk > 0) { gload(0); lstore(0); }
+    __syncthreads();
+    int cur = 0;
+    for (int blk = 0; blk < nblk; ++blk) {
+        if (blk + 1 < nblk) gload(blk + 1);
+        const float *la = lds + cur * TILE_F, *lb = la + 32 * Mp;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            float af[MTW], bf[KTW];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) af[i] = la[(2 * s + h) * Mp + 32 * (wm * MTW + i) + l31];
+#pragma unroll
+            for (int j = 0; j < KTW; ++j) bf[j] = lb[(2 * s + h) * Kp + 32 * (wk * KTW + j) + l31];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+                bsum[i] += af[i];
+#pragma unroll
+                for (int j = 0; j < KTW; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+            }
+        }
+        if (blk + 1 < nblk) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    float *part = a.partial + d.part_off + (size_t)blockIdx.x * d.part_stride;
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int ot = wm * MTW + i;
+#pragma unroll
+        for (int j = 0; j < KTW; ++j) {
+            const int kt = wk * KTW + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * h;
+                part[(size_t)o * Kp + 32 * kt + l31] = acc[i][j][r];
+            }
+        }
+        if (wk == 0) {
+            const float b = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+            if (h == 0) part[(size_t)Mp * Kp + 32 * ot + l31] = b;
+        }
+    }
+}
 
 // Weight-gradient GEMMs on split-precision bf16 MFMA ("bf16x3": hi/lo parts, 3 cross terms, fp32 accumulate),
 // for M = 32*MT, K = 32*KT with MT in {4, 8} (4 waves split the M tiles), KT in {2, 8}.  The fp32 rows of A and B
@@ -1268,7 +1367,14 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
     {
         ProfScope ps("wgrad_256x256", st);
         if (precision == VIPNERF_PREC_FP32) {
+#if VN_WGRAD_W8
+            const size_t ldsb = (size_t)2 * 32 * 512 * sizeof(float);
+            VN_HIP(hipFuncSetAttribute((const void *)k_wgrad256_w8<VN_WGRAD_W8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+            hipLaunchKernelGGL(k_wgrad256_w8<VN_WGRAD_W8>, dim3(n_chunks, n88), dim3(256 * VN_WGRAD_W8), ldsb, st, c88);
+            VN_HIP(hipGetLastError());
+#else
             if ((rc = launch_class<2, 8, 4>(c88, n88, n_chunks, st))) return rc;
+#endif
         } else if (halves == 1) {                  // operands stored as fp16 high parts: single-MFMA kernel, half the bytes
             const size_t ldsb = (size_t)2 * 2 * 256 * 64;
             VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_h16_256<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));

@@ -136,6 +136,88 @@ __global__ __launch_bounds__(512) void k16(const char *w, int reps, float *out) 
     out[blockIdx.x * 512 + tid] = s;
 }
 
+// ---- 8 waves x 32 points in 4 pairs, 32x32x16, HALF-FEATURE ownership: the two waves of a pair share 32 points, each owns
+// 128 of the 256 output features (4 tiles) and the matching half of the next B operand; the partner's half crosses through a
+// small LDS window, one stage's worth (32 features = 2 k-steps of 16, hi+lo: 4 KiB per wave) at a time, double-buffered
+// against the stage barrier that is there anyway.  Stage = 32 KiB (k = 32 x 256 features x hi+lo); a wave reads only its own
+// 16 KiB of it.  Per layer: 4 partner stages (B from the window) then 4 own stages (B from registers; publish for the next layer).
+constexpr int HSTAGE = 32 * 1024, H_STAGES = 72, XSLOT = 4096;
+template <int NBUF>
+__global__ __launch_bounds__(512) void k32h(const char *w, int reps, float *out) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char *xw = lds + NBUF * HSTAGE;                            // exchange window: [wave][slot][4 KiB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = wave & 1, partner = wave ^ 1;
+    floatx16 acc[4];
+    for (int t = 0; t < 4; ++t) acc[t] = (floatx16)(0.f);
+    bf16x8 b[8][2];                                            // own half of the B operand: 8 k-steps of 16, hi+lo
+    for (int s = 0; s < 8; ++s) for (int i = 0; i < 2; ++i) for (int e = 0; e < 8; ++e) b[s][i][e] = (__bf16)(0.001f * (lane + e + s + i));
+    for (int r = 0; r < reps; ++r) {
+        if (wave == 0) glds_stage<2>(w, (unsigned)(size_t)lds, 0, lane);          // 32 pieces
+        for (int layer = 0; layer < H_STAGES / 8; ++layer) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int s = layer * 8 + jj;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const char *st = lds + (s % NBUF) * HSTAGE + half * 4096 + lane * 16;   // chunk (ks, tile, part) at ((ks*8 + tile)*2 + part) KiB
+            const bool own = jj >= 4;
+            bf16x8 fr[3][2][2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) fr[g][tt][i] = *(const bf16x8 *)(st + (((g >> 1) * 8 + (g & 1) * 2 + tt) * 2 + i) * 1024);
+            bf16x8 pb[2][2];
+            if (!own) {
+                const char *xs = xw + (partner * 2 + (s & 1)) * XSLOT + lane * 16;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) pb[ks][i] = *(const bf16x8 *)(xs + (ks * 2 + i) * 1024);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) pb[ks][i] = b[(2 * jj + ks) & 7][i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < H_STAGES && (s & 7) == wave) glds_stage<2>(w + (size_t)(s + 1) * HSTAGE, (unsigned)(size_t)lds + ((s + 1) % NBUF) * HSTAGE, 0, lane);
+            // publish what the partner needs in stage s + 1 (if that is a partner stage)
+            if (((jj + 1) & 7) < 4) {
+                char *xd = xw + (wave * 2 + ((s + 1) & 1)) * XSLOT + lane * 16;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) *(bf16x8 *)(xd + (ks * 2 + i) * 1024) = b[(2 * (jj + 1) + ks) & 7][i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {                      // group = 2 tiles of one k-step
+                if (g + 2 < 4) {
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) fr[(g + 2) % 3][tt][i] = *(const bf16x8 *)(st + ((((g + 2) >> 1) * 8 + ((g + 2) & 1) * 2 + tt) * 2 + i) * 1024);
+                }
+                const int ks = g >> 1, t = (g & 1) * 2;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % 3][0][1], pb[ks][0], acc[t], 0, 0, 0);
+                acc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % 3][1][1], pb[ks][0], acc[t + 1], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % 3][0][0], pb[ks][1], acc[t], 0, 0, 0);
+                acc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % 3][1][0], pb[ks][1], acc[t + 1], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % 3][0][0], pb[ks][0], acc[t], 0, 0, 0);
+                acc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % 3][1][0], pb[ks][0], acc[t + 1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        }
+        __syncthreads();
+    }
+    float s = 0.f;
+    for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) s += acc[t][r];
+    out[blockIdx.x * 512 + tid] = s;
+}
+
 int main() {
     const size_t bytes = (size_t)N_STAGES * STAGE_BYTES;
     char *w; float *out;
@@ -145,23 +227,26 @@ int main() {
     CK(hipFuncSetAttribute((const void *)k32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipFuncSetAttribute((const void *)k16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipFuncSetAttribute((const void *)k16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t ldsh = 2 * HSTAGE + 8 * 2 * XSLOT;
+    CK(hipFuncSetAttribute((const void *)k32h<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int reps = 20;
     // MFMA cycles per task per SIMD: 36 stages x 96 MFMAs x 32 cycles (k32: one wave) = 36 x 2 waves x 96 x 16 (k16)
     const double mfma_cycles = 36.0 * 96 * 32;
     for (int grid : {8, 256, 1024}) {
-        for (int which = 0; which < 3; ++which) {
+        for (int which = 0; which < 4; ++which) {
             for (int pass = 0; pass < 2; ++pass) {
                 CK(hipEventRecord(e0));
                 if (which == 0) hipLaunchKernelGGL(k32, dim3(grid), dim3(256), lds, 0, w, pass ? reps : 2, out);
                 else if (which == 1) hipLaunchKernelGGL(k16<0>, dim3(grid), dim3(512), lds, 0, w, pass ? reps : 2, out);
-                else hipLaunchKernelGGL(k16<1>, dim3(grid), dim3(512), lds, 0, w, pass ? reps : 2, out);
+                else if (which == 2) hipLaunchKernelGGL(k16<1>, dim3(grid), dim3(512), lds, 0, w, pass ? reps : 2, out);
+                else hipLaunchKernelGGL(k32h<2>, dim3(grid), dim3(512), ldsh, 0, w, pass ? reps : 2, out);
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             }
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             const double rounds = grid <= 256 ? 1.0 : grid / 256.0;
             const double us_task = ms * 1e3 / reps / rounds;
-            printf("%s grid=%4d  %7.1f us per task   MFMA utilisation at 2.4 GHz: %.2f\n", which == 2 ? "16-pt x 8 waves, term-major MFMA order" : (which ? "16-pt x 8 waves (16x16x32)            " : "32-pt x 4 waves (32x32x16)            "),
+            printf("%s grid=%4d  %7.1f us per task   MFMA utilisation at 2.4 GHz: %.2f\n", which == 3 ? "32-pt x 8 waves, half-feature pairs      " : which == 2 ? "16-pt x 8 waves, term-major MFMA order" : (which ? "16-pt x 8 waves (16x16x32)            " : "32-pt x 4 waves (32x32x16)            "),
                    grid, us_task, mfma_cycles / 2400.0 / us_task);
         }
     }

@@ -29,7 +29,7 @@ def main(d, prec, out):
         per[st] = {'read': int(rd), 'written': int(wr), 'total': int(rd + wr)}
     busy = {}
     for k, (calls, us, cyc) in m.items():
-        if 'vn::k_mlp' in k or 'k_wgrad_split16_256' in k or 'k_wgrad_bf16x3_256' in k or 'k_wgrad_h16_256' in k or 'k_wgrad<2, 8, 4>' in k:
+        if 'vn::k_mlp' in k or 'k_wgrad_split16_256' in k or 'k_wgrad_bf16x3_256' in k or 'k_wgrad_h16_256' in k or 'k_wgrad<2, 8, 4>' in k or 'k_wgrad256_w8' in k:
             bus = b.get(k)
             if not bus:
                 continue

@@ -90,16 +90,37 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&out)[NS]) {
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 // fp16 fragments ("fp16x3", narrow layout only): same fragment shapes, 11-bit parts instead of 8-bit ones
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+#ifndef VN_SPLIT_FMA_MIX
+#define VN_SPLIT_FMA_MIX 1
+#endif
 template <int NS>
 __device__ __forceinline__ void split8(const float (&x)[8], half8 (&out)[NS]) {
+    if constexpr (NS == 2 && VN_SPLIT_FMA_MIX) {
+        // hi = fp16(x) (v_cvt_pk_f16_f32, two values per instruction); lo = fp16(x - hi) as ONE v_fma_mix{lo,hi}_f16 per value
+        // (fp16 source half, -1.0, fp32 addend; exact difference, one rounding, written straight into its half of the packed
+        // register) instead of v_cvt_f32_f16 + v_sub_f32 + half a v_cvt_pk: the same bits, 3 instead of 5 VALU slots per pair
+        typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float r = x[e];
+        for (int e = 0; e < 8; e += 2) {
+            const half2_ h = {(_Float16)x[e], (_Float16)x[e + 1]};
+            const unsigned hb = __builtin_bit_cast(unsigned, h);
+            unsigned lb;
+            asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hb), "v"(x[e]));
+            asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lb) : "v"(hb), "v"(x[e + 1]));
+            const half2_ l = __builtin_bit_cast(half2_, lb);
+            out[0][e] = h[0]; out[0][e + 1] = h[1];
+            out[1][e] = l[0]; out[1][e + 1] = l[1];
+        }
+    } else {
 #pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            const _Float16 p = (_Float16)r;
-            out[i][e] = p;
-            r = r - (float)p;
+        for (int e = 0; e < 8; ++e) {
+            float r = x[e];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const _Float16 p = (_Float16)r;
+                out[i][e] = p;
+                r = r - (float)p;
+            }
         }
     }
 }

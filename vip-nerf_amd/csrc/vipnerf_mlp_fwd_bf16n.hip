@@ -186,6 +186,9 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
         }
         unsigned mk0 = 0u, mk1 = 0u;
         float *dst = SAVE ? a.acts + (layer < 8 ? a.al.h[layer] : a.al.feat) : nullptr;
+#if defined(VN_EXP) && VN_EXP == 22
+        if (acc[0][0] == 12345.f)                    // timing experiment only: no ReLU / split epilogue
+#endif
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             floatx4 x[2] = {acc[2 * s], acc[2 * s + 1]};
@@ -207,6 +210,9 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
                 }
             }
             if (F16) { x[0] *= XS; x[1] *= XS; }
+#if defined(VN_EXP) && VN_EXP == 21
+            if (x[0][0] == 12345.f)                  // timing experiment only: no operand split
+#endif
             split_pair<NS>(x[0], x[1], bin[s]);
             if (SAVE && !DEFER && H16 == 1 && layer < 8) store_pair16h(dst, p, W, q, s, bin[s][0]);
             if (SAVE && !DEFER && H16 == 2 && layer < 8) store_pair_split(dst, p, W, q, s, bin[s][0], bin[s][NS > 1 ? 1 : 0]);
@@ -239,6 +245,9 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
     }
     stream_end(ws);
 
+#if defined(VN_EXP) && VN_EXP == 23
+    if (sigma_raw == 12345.f)                        // timing experiment only: no view-branch tail
+#endif
 #pragma unroll 1
     for (int dsel = 0; dsel <= a.src.V; ++dsel) {
         float dir[3];

@@ -47,6 +47,42 @@ def test_ray_generation_bit_exact(dev):
         assert float(b['near'].min()) == 1.0 and float(b['far_ndc'].max()) == 1.0
 
 
+@pytest.mark.parametrize('seed', range(6))
+def test_ray_generation_camera_sweep_bit_exact(dev, seed):
+    """Seeded cameras away from the golden's 24 x 32 frame: odd sizes, fx != fy, off-centre principal point, arbitrary
+    rotations and translations, several near planes, NDC on and off -- rays, view directions, NDC rays and secondary camera
+    centres bit-identical to the numpy restatement of DataPreprocessor01.py:335-378 (itself pinned by f6_raygen)."""
+    from data_preprocessors.RayGeneratorHip01 import RayGeneratorHip
+    rs = np.random.default_rng(500 + seed)
+    h, w = int(rs.integers(5, 90)), int(rs.integers(5, 130))
+    K = np.array([[rs.uniform(20, 900), 0, rs.uniform(0.3, 0.7) * w], [0, rs.uniform(20, 900), rs.uniform(0.3, 0.7) * h], [0, 0, 1]], np.float32)
+    nfr = int(rs.integers(2, 5))
+    poses = np.tile(np.eye(4, dtype=np.float32), (nfr, 1, 1))
+    for f in range(nfr):
+        q, _ = np.linalg.qr(rs.normal(size=(3, 3)))
+        if np.linalg.det(q) < 0:
+            q[:, 0] *= -1
+        ang = rs.uniform(0, 0.3)                                   # a moderate rotation: q^ang would need a log; blend and re-orthonormalise
+        r, _ = np.linalg.qr((1 - ang) * np.eye(3) + ang * q)
+        r *= np.sign(np.diag(r))[None, :]                          # columns oriented like the identity's
+        poses[f, :3, :3] = r.astype(np.float32)
+        poses[f, :3, 3] = rs.normal(size=3).astype(np.float32) * 0.3
+    near = float(rs.choice([0.5, 1.0, 2.0]))
+    ndc = bool(seed % 2 == 0)
+    gen = RayGeneratorHip((h, w), K[None], poses, near, 6.0, ndc, dev)
+    for f in range(nfr):
+        b = gen.create_test_data(f, secondary=True)
+        ro_, rd_ = ro.get_rays((h, w), K, poses[f])
+        assert np.array_equal(b['rays_o'].cpu().numpy(), ro_.reshape(-1, 3)), f'rays_o frame {f}'
+        assert np.array_equal(b['rays_d'].cpu().numpy(), rd_.reshape(-1, 3)), f'rays_d frame {f}'
+        assert np.array_equal(b['view_dirs'].cpu().numpy(), ro.get_view_dirs(rd_).reshape(-1, 3)), f'view_dirs frame {f}'
+        if ndc:
+            on, dn = ro.get_ndc_rays(ro_, rd_, (h, w), K, near)
+            assert np.array_equal(b['rays_o_ndc'].cpu().numpy(), on.reshape(-1, 3)), f'rays_o_ndc frame {f}'
+            assert np.array_equal(b['rays_d_ndc'].cpu().numpy(), dn.reshape(-1, 3)), f'rays_d_ndc frame {f}'
+        assert np.array_equal(b['rays_o2'].cpu().numpy(), ro.secondary_origins(poses, np.full(h * w, f)))
+
+
 def test_batch_gather_matches_cached_gather(dev):
     """shuffled indices: the on-device recomputation equals gathering rows of the full per-scene ray cache"""
     g = load('f6_raygen')

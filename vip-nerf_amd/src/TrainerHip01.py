@@ -55,6 +55,7 @@ class TrainerHip:
         return self.lr_init * (0.1 ** (iter_num / self.lr_decay_steps))
 
     def train_one_iter(self, iter_num: int) -> dict:
+        """-> {loss name: 0-dim device tensor, summed over the sub-batches}; nothing here waits for the GPU."""
         batch = self.gen.get_next_batch(iter_num, scheduler=self.scheduler)
         if self.world > 1:
             batch = vdist.shard_batch(batch, self.rank, self.world)
@@ -70,9 +71,10 @@ class TrainerHip:
             out = self.model(sb)
             losses = self.loss_computer.compute_losses(sb, out)
             losses['TotalLoss'].backward()
-            for k, v in losses.items():
+            for k, v in losses.items():                      # kept on the device: a float() here would stall the host every iteration
                 v = v['loss_value'] if isinstance(v, dict) else v
-                logged[k] = logged.get(k, 0.0) + float(v.detach()) if isinstance(v, torch.Tensor) else logged.get(k, 0.0) + float(v)
+                v = v.detach() if isinstance(v, torch.Tensor) else torch.as_tensor(float(v), device=self.device)
+                logged[k] = logged[k] + v if k in logged else v
         self.bucket.all_reduce_mean()
         self.optimizer.step()
         return logged
@@ -113,12 +115,17 @@ class TrainerHip:
             for g in self.optimizer.param_groups:
                 g['lr'] = lr
             losses = self.train_one_iter(iter_num)
-            losses['lr'] = lr
-            history.append(losses)
+            entry = {'lr': lr}
+            history.append((losses, entry))
             if log_every and self.rank == 0 and (iter_num + 1) % log_every == 0:
-                print(f"iter {iter_num + 1}: " + ' '.join(f'{k} {v:.5f}' for k, v in losses.items()), flush=True)
+                print(f"iter {iter_num + 1}: " + ' '.join(f'{k} {float(v):.5f}' for k, v in losses.items()) + f' lr {lr:.3e}', flush=True)
             if val_int and (iter_num + 1) % val_int == 0:
-                losses['validation_psnr'] = float(numpy.mean([v.get('psnr', float('nan')) for v in self.run_validation().values()]))
+                entry['validation_psnr'] = float(numpy.mean([v.get('psnr', float('nan')) for v in self.run_validation().values()]))
             if save_int and (iter_num + 1) % save_int == 0:
                 self.save_model(iter_num + 1)
-        return history
+        # one transfer for the whole history instead of one host wait per iteration and loss
+        if history:
+            keys = list(history[0][0].keys())
+            table = torch.stack([torch.stack([h[0][k].float() for k in keys]) for h in history]).cpu().numpy()
+            return [dict(zip(keys, map(float, row)), **h[1]) for row, h in zip(table, history)]
+        return []

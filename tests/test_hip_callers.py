@@ -158,6 +158,38 @@ def test_visibility_prior_generator_golden(dev):
         assert w.dtype == np.float64 and w.shape == g[key].shape
 
 
+def test_visibility_prior_scene_generation_and_disk_layout(dev, tmp_path):
+    """A whole scene (every ordered pair, reference :248-279): the (n, n-1, h, w) array in the loader's order, each entry equal
+    to the pairwise call; the files written in the reference's layout read back -- `{f1:04}_{f2:04}.png` == 255, as
+    NerfLlffDataLoader01.read_mask does -- to the same masks, and the .npy files hold the bool masks / float64 weights."""
+    from prior_generators.VisibilityMaskHip02 import VisibilityWeightsComputerHip, load_scene_masks
+    g = load('f7_visibility_prior')
+    cfgp = {'num_depth_planes': int(g['n_planes']), 'temperature': float(g['temperature'])}
+    comp = VisibilityWeightsComputerHip(cfgp, dev)
+    rs = np.random.default_rng(4)
+    f3 = np.clip(g['frame1'].astype(np.int32) + rs.integers(-20, 20, size=g['frame1'].shape), 0, 255).astype(np.uint8)
+    E3 = 0.5 * (g['E1'] + g['E2'])
+    E3[:3, :3] = g['E1'][:3, :3]
+    frames, E, K = [g['frame1'], g['frame2'], f3], [g['E1'], g['E2'], E3], [g['K']] * 3
+    nums = [3, 11, 20]
+    lo, hi = float(g['min_depth']), float(g['max_depth'])
+    masks, weights = comp.generate_scene(frames, E, K, lo, hi, frame_nums=nums, output_dirpath=tmp_path)
+    assert masks.shape == (3, 2) + g['frame1'].shape[:2] and masks.dtype == bool and weights.dtype == np.float64
+    np.testing.assert_allclose(weights[0, 0], g['weights12'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(weights[1, 0], g['weights21'], rtol=1e-9, atol=1e-12)
+    for i in range(3):
+        for c, j in enumerate([x for x in range(3) if x != i]):
+            w, m = comp.compute_masks(frames[i], frames[j], E[i], E[j], K[i], K[j], lo, hi)
+            assert np.array_equal(weights[i, c], w) and np.array_equal(masks[i, c], m), (i, j)
+            stem = f'{nums[i]:04}_{nums[j]:04}'
+            assert np.array_equal(np.load(tmp_path / f'visibility_masks/{stem}.npy'), m)
+            assert np.array_equal(np.load(tmp_path / f'visibility_weights/{stem}.npy'), w)
+            assert (tmp_path / f'visibility_weights/{stem}.png').exists()
+    assert np.array_equal(load_scene_masks(tmp_path, nums), masks)
+    dm, dw = comp.generate_scene(frames, E, K, lo, hi, keep_on_device=True)
+    assert dm.is_cuda and np.array_equal(dm.cpu().numpy(), masks) and np.array_equal(dw.cpu().numpy(), weights)
+
+
 def test_visibility_prior_full_frame_properties(dev):
     """LLFF-sized frame (756x1008, 64 planes): identical frames and cameras are fully visible (w = 1); a camera
     displaced far to the side sees nothing (all taps outside -> warped = 0 -> error = mean intensity)."""

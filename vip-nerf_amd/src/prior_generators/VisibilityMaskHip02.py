@@ -63,3 +63,84 @@ class VisibilityWeightsComputerHip:
     def compute_masks(self, frame1, frame2, extrinsic1, extrinsic2, intrinsic1, intrinsic2, min_depth: float, max_depth: float):
         w64, mask = self._run(frame1, frame2, extrinsic1, extrinsic2, intrinsic1, intrinsic2, min_depth, max_depth)
         return w64.cpu().numpy(), mask.cpu().numpy().astype(bool)
+
+    # ---------------------------------------------------------------------------------- a whole scene (reference :233-279)
+    def generate_scene(self, frames, extrinsics, intrinsics, min_depth: float, max_depth: float, frame_nums=None, output_dirpath=None,
+                       keep_on_device: bool = False):
+        """Every ordered pair of a scene's training frames, as the reference's start_generation loop does (:248-279), without the
+        database plumbing around it: `frames` (n,h,w,3) uint8, `extrinsics` (n,4,4), `intrinsics` (n,3,3).
+        -> (masks (n, n-1, h, w) bool, weights (n, n-1, h, w) float64): row f1 holds the other frames in increasing order, the
+        array the reference's loader builds (src/data_loaders/NerfLlffDataLoader01.py:131-160) and RayGeneratorHip takes as
+        `visibility_prior`.  With `output_dirpath` the pair files are written in the reference's on-disk layout
+        (`visibility_masks/{f1:04}_{f2:04}.npy` + `.png` with 255 = visible, `visibility_weights/{f1:04}_{f2:04}.npy` + `.png`
+        with round(255 w)), so the reference's own loader reads them.  keep_on_device: return torch tensors on the GPU instead."""
+        n = len(frames)
+        frame_nums = list(range(n)) if frame_nums is None else [int(x) for x in frame_nums]
+        if len(frame_nums) != n or len(extrinsics) != n or len(intrinsics) != n:
+            raise L.VipNerfHipError('generate_scene: frames, extrinsics, intrinsics and frame_nums must have one entry per frame')
+        masks, weights = [], []
+        for i in range(n):
+            row_m, row_w = [], []
+            for j in range(n):
+                if j == i:
+                    continue
+                w64, mask = self._run(frames[i], frames[j], extrinsics[i], extrinsics[j], intrinsics[i], intrinsics[j], min_depth, max_depth)
+                row_w.append(w64)
+                row_m.append(mask != 0)
+                if output_dirpath is not None:
+                    stem = f'{frame_nums[i]:04}_{frame_nums[j]:04}'
+                    self.save_mask(Path(output_dirpath) / f'visibility_masks/{stem}.npy', row_m[-1].cpu().numpy(), as_image=True)
+                    self.save_weights(Path(output_dirpath) / f'visibility_weights/{stem}.npy', w64.cpu().numpy(), as_png=True)
+            masks.append(torch.stack(row_m))
+            weights.append(torch.stack(row_w))
+        masks, weights = torch.stack(masks), torch.stack(weights)
+        if keep_on_device:
+            return masks, weights
+        return masks.cpu().numpy(), weights.cpu().numpy()
+
+    @staticmethod
+    def _write_png(path: Path, image_u8: numpy.ndarray):
+        from PIL import Image                     # the reference writes through skimage.io (absent here); same 8-bit greyscale PNG
+        Image.fromarray(image_u8, mode='L').save(path.as_posix())
+
+    @classmethod
+    def save_mask(cls, path: Path, mask: numpy.ndarray, as_image: bool = False):
+        """reference :184-197"""
+        path.parent.mkdir(parents=True, exist_ok=True)
+        mask_image = mask.astype('uint8') * 255
+        if path.suffix == '.png':
+            cls._write_png(path, mask_image)
+        elif path.suffix == '.npy':
+            numpy.save(path.as_posix(), mask)
+            if as_image:
+                cls._write_png(path.parent / f'{path.stem}.png', mask_image)
+        else:
+            raise RuntimeError(f'Unknown format: {path.as_posix()}')
+
+    @classmethod
+    def save_weights(cls, path: Path, weights: numpy.ndarray, as_png: bool = False):
+        """reference :199-211"""
+        weights_image = numpy.round(weights * 255).astype('uint8')
+        path.parent.mkdir(parents=True, exist_ok=True)
+        if path.suffix == '.png':
+            cls._write_png(path, weights_image)
+        elif path.suffix == '.npy':
+            numpy.save(path.as_posix(), weights)
+            if as_png:
+                cls._write_png(path.parent / f'{path.stem}.png', weights_image)
+        else:
+            raise RuntimeError(f'Unknown weights format: {path.as_posix()}')
+
+
+def load_scene_masks(masks_dirpath, frame_nums) -> numpy.ndarray:
+    """What the reference's loader does with a scene's mask files (NerfLlffDataLoader01.py:131-143, read_mask :169-177):
+    `{f1:04}_{f2:04}.png` == 255 -> (n, n-1, h, w) bool, row f1 = the other frames in the order of frame_nums."""
+    from PIL import Image
+    masks = []
+    for f1 in frame_nums:
+        row = []
+        for f2 in [x for x in frame_nums if x != f1]:
+            path = Path(masks_dirpath) / f'visibility_masks/{int(f1):04}_{int(f2):04}.png'
+            row.append(numpy.asarray(Image.open(path.as_posix())) == 255)
+        masks.append(row)
+    return numpy.array(masks)

@@ -333,6 +333,51 @@ def main():
     others = {p: timed_run(p) for p in also}
     model.configs['model']['hip_precision'] = args.precision
 
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    def render_bench():
+        # full-frame eval render, camera -> uint8 image on the GPU (SURVEY.md 8d: 756 x 1008 rays, no secondary views):
+        # on-device ray generation -> coarse+fine eval pass -> post-processing (Tester01.predict_frame's job)
+        # N > 1: the frame is cut into N strips of rows, one per rank, no data-path collective; ms_per_frame is
+        # the barrier-bracketed maximum over the ranks
+        from data_preprocessors.RayGeneratorHip01 import RayGeneratorHip, frame_strip, predict_frame
+        import numpy as np
+        model.eval()
+        K = np.array([[815.1316, 0, 504.], [0, 815.1316, 378.], [0, 0, 1.]], dtype=np.float32)
+        poses = np.tile(np.eye(4, dtype=np.float32), (2, 1, 1))
+        poses[:, 0, 3] = [-0.1, 0.1]
+        gen = RayGeneratorHip((756, 1008), K[None], poses, 1.0, 5.1731, True, dev)
+        n = 756 * 1008
+        rows = frame_strip(756, rank, world)
+        render = {}
+        for prec in [args.precision] + [p for p in also if p in ('fp16x3',)]:
+            model.configs['model']['hip_precision'] = prec
+            torch.cuda.empty_cache()
+            ops.profile_enable(True); ops.profile_read()
+            for _ in range(2):
+                barrier(); t0 = time.perf_counter()
+                frame = predict_frame(model, gen, frame=0, rows=rows)
+                torch.cuda.synchronize(); rt = max_over_ranks(time.perf_counter() - t0)
+            rp = ops.profile_read(); ops.profile_enable(False)
+            assert frame['image'].shape == (rows[1] - rows[0], 1008, 3) and frame['image'].dtype == torch.uint8
+            mlp_ms = sum(v[1] for k, v in rp.items() if k.startswith('mlp_fwd')) / 2 * world   # rank 0's strip x N: the frame's kernel time
+            eval_flop = 593536 * 2.0 * POINTS_PER_RAY * n          # SURVEY.md 8d: 231.6 TFLOP per frame
+            render[prec] = {'ms_per_frame': round(rt * 1e3, 1), 'rays_per_sec': round(n / rt, 1),
+                            'mlp_kernel_ms': round(mlp_ms, 1), 'achieved_tflops': round(eval_flop / (mlp_ms * 1e-3) / 1e12, 1),
+                            'frac': round(eval_flop / (mlp_ms * 1e-3) / 1e12 / ARITH[prec][1], 4),
+                            'stage_ms': {k: round(v[1] / 2, 3) for k, v in sorted(rp.items())},
+                            'row_strips': world}            # N > 1: one strip of rows per GPU, stage_ms = rank 0's strip
+        model.configs['model']['hip_precision'] = args.precision
+        model.train()
+        return render
+
+    render = None if args.no_render else render_bench()          # every rank: its strip of the frame
+
     if rank != 0:
         torch.distributed.barrier()              # rank 0 finishes its report, then everybody leaves together
         torch.distributed.destroy_process_group()
@@ -358,38 +403,9 @@ def main():
         result['dtype_' + p] = ARITH[p][0]
         result['roofline_' + p] = roofline_block(p, pr, args.steps, rays, pms, sc)
 
-    if world == 1 and not args.no_render:
-        # full-frame eval render, camera -> uint8 image on the GPU (SURVEY.md 8d: 756 x 1008 rays, no secondary views):
-        # on-device ray generation -> coarse+fine eval pass -> post-processing (Tester01.predict_frame's job)
-        from data_preprocessors.RayGeneratorHip01 import RayGeneratorHip, predict_frame
-        import numpy as np
-        model.eval()
-        K = np.array([[815.1316, 0, 504.], [0, 815.1316, 378.], [0, 0, 1.]], dtype=np.float32)
-        poses = np.tile(np.eye(4, dtype=np.float32), (2, 1, 1))
-        poses[:, 0, 3] = [-0.1, 0.1]
-        gen = RayGeneratorHip((756, 1008), K[None], poses, 1.0, 5.1731, True, dev)
-        n = 756 * 1008
-        render = {}
-        for prec in [args.precision] + [p for p in also if p in ('fp16x3',)]:
-            model.configs['model']['hip_precision'] = prec
-            torch.cuda.empty_cache()
-            ops.profile_enable(True); ops.profile_read()
-            for _ in range(2):
-                torch.cuda.synchronize(); t0 = time.perf_counter()
-                frame = predict_frame(model, gen, frame=0)
-                torch.cuda.synchronize(); rt = time.perf_counter() - t0
-            rp = ops.profile_read(); ops.profile_enable(False)
-            assert frame['image'].shape == (756, 1008, 3) and frame['image'].dtype == torch.uint8
-            mlp_ms = sum(v[1] for k, v in rp.items() if k.startswith('mlp_fwd')) / 2
-            eval_flop = 593536 * 2.0 * POINTS_PER_RAY * n          # SURVEY.md 8d: 231.6 TFLOP per frame
-            render[prec] = {'ms_per_frame': round(rt * 1e3, 1), 'rays_per_sec': round(n / rt, 1),
-                            'mlp_kernel_ms': round(mlp_ms, 1), 'achieved_tflops': round(eval_flop / (mlp_ms * 1e-3) / 1e12, 1),
-                            'frac': round(eval_flop / (mlp_ms * 1e-3) / 1e12 / ARITH[prec][1], 4),
-                            'stage_ms': {k: round(v[1] / 2, 3) for k, v in sorted(rp.items())}}
-        model.configs['model']['hip_precision'] = args.precision
+    if render is not None:
         result['render_ms_per_frame'] = render[args.precision]['ms_per_frame']
         result['render'] = render
-        model.train()
 
     if world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(vo, n_rays=args.cpu_rays)

@@ -145,6 +145,33 @@ def test_predict_frame_against_oracle(dev):
     assert np.abs(r['depth'].cpu().numpy() - dep).max() <= 2e-3 * dep.max()
 
 
+def test_frame_strips_equal_the_whole_frame(dev):
+    """A frame rendered as strips of rows (what N GPUs do, one strip each: predict_frame_sharded) is bit-identical to the frame
+    rendered in one call -- rays are independent and the kernels' results do not depend on the launch size."""
+    from data_preprocessors.RayGeneratorHip01 import frame_strip, predict_frame
+    from models.ModelFactory import get_model
+    g = load('f6_raygen')
+    gen, res = make_gen(g, dev)
+    mlp = lambda ns: {'num_samples': ns, 'netdepth': 8, 'netwidth': 256, 'points_positional_encoding_degree': 10,
+                      'views_positional_encoding_degree': 4, 'use_view_dirs': True, 'view_dependent_rgb': True, 'predict_visibility': True}
+    cfg = {'data_loader': {'ndc': True}, 'model': {'name': 'VipNeRFHip01', 'coarse_mlp': mlp(64), 'fine_mlp': mlp(128), 'lindisp': False,
+                                                    'perturb': True, 'raw_noise_std': 1.0, 'white_bkgd': False}}
+    params = vo.init_params(33, scale=1.6, sigma_bias=0.6)
+    model = get_model(cfg, None)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    model = model.to(dev).eval()
+    whole = predict_frame(model, gen, frame=2, secondary=True)
+    for world in (2, 3, 5):
+        strips = [frame_strip(res[0], r, world) for r in range(world)]
+        assert strips[0][0] == 0 and strips[-1][1] == res[0] and all(a[1] == b[0] for a, b in zip(strips, strips[1:]))
+        parts = [predict_frame(model, gen, frame=2, secondary=True, rows=rw) for rw in strips]
+        for k, v in whole.items():
+            cat = torch.cat([p[k] for p in parts], dim=1 if k == 'visibility2' else 0)
+            assert torch.equal(cat, v), f'{k} with {world} strips'
+    with pytest.raises(Exception):
+        gen.create_test_data(0, rows=(5, res[0] + 1))
+
+
 def test_visibility_prior_generator_golden(dev):
     """f-3: plane-sweep visibility weights on the GPU vs the reference's VisibilityWeightsComputer (float64 geometry:
     1e-9 relative on the weights, identical masks)."""

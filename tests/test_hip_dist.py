@@ -103,6 +103,8 @@ def test_bench_two_ranks_on_one_gpu():
     res = json.loads(lines[0])
     assert res['n_gpus'] == 2 and res['scaling'] == 'weak' and res['value'] > 0 and res['config']['global_rays'] == 2048
     assert res['dtype'] == 'f32' and res['roofline']['bound'] == 'mfma' and 0 < res['roofline']['frac'] < 1
+    # the render leg at N > 1: one strip of the 756-row frame per rank, barrier-bracketed maximum over the ranks
+    assert res['render']['fp32']['row_strips'] == 2 and res['render_ms_per_frame'] > 0
     # strong scaling: configs[3]'s 65,536 rays would not leave room for two ranks on one GPU; the flag itself with a small total
     cmd2 = cmd[:-2] + ['--scaling', 'strong', '--global-rays', '2048']
     r = subprocess.run(cmd2, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
@@ -170,3 +172,46 @@ def test_trainer_two_ranks_equal_one_process():
     # rank 0's logged MSE is the mean over ITS half of the rows: the two halves average to the single-process value
     both = 0.5 * (np.array(ret['mse0']) + np.array(ret['mse1']))
     np.testing.assert_allclose(both, [x['MSEHip01'] for x in hist], rtol=5e-3)
+
+
+# ------------------------------------------------------------------------------------------------ a frame on two ranks
+def _render_setup(dev):
+    from data_preprocessors.RayGeneratorHip01 import RayGeneratorHip
+    from oracle import vipnerf_oracle as vo
+    import test_hip_parity as tp
+    K = np.array([[60.0, 0, 20.0], [0, 60.0, 15.0], [0, 0, 1]], np.float32)
+    poses = np.tile(np.eye(4, dtype=np.float32), (2, 1, 1))
+    poses[:, 0, 3] = [-0.1, 0.1]
+    gen = RayGeneratorHip((31, 40), K[None], poses, 1.0, 6.0, True, dev)          # 31 rows: uneven strips
+    model, _ = tp.make_model(dev, True, vo.init_params(41, scale=1.6, sigma_bias=0.6))
+    return model.eval(), gen
+
+
+def _render_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                      VIPNERF_DIST_BACKEND='gloo')
+    from vipnerf_hip import dist as vdist
+    from data_preprocessors.RayGeneratorHip01 import predict_frame_sharded
+    r, w, _ = vdist.init_from_env(backend='gloo')
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    model, gen = _render_setup(dev)
+    full = predict_frame_sharded(model, gen, frame=1, rank=r, world=w)
+    ret[rank] = {k: v.numpy() for k, v in full.items()}
+    torch.distributed.destroy_process_group()
+
+
+def test_frame_rendered_by_two_ranks_equals_one_process():
+    """predict_frame_sharded: each rank renders its strip of rows (no data-path collective), the strips are gathered on the host
+    -- every rank ends up with the frame one process renders, bit for bit."""
+    from data_preprocessors.RayGeneratorHip01 import predict_frame
+    world, port = 2, 34000 + (os.getpid() % 2000)
+    ret = mp.Manager().dict()
+    mp.spawn(_render_worker, args=(world, port, ret), nprocs=world, join=True)
+    model, gen = _render_setup(torch.device('cuda:0'))
+    whole = predict_frame(model, gen, frame=1)
+    for r in range(world):
+        assert set(ret[r]) == set(whole)
+        for k, v in whole.items():
+            assert np.array_equal(ret[r][k], v.cpu().numpy()), f'rank {r}: {k}'
+    assert ret[0]['image'].shape == (31, 40, 3) and ret[0]['image'].dtype == np.uint8

@@ -223,25 +223,28 @@ class RayGeneratorHip:
         return b
 
     # ---- inference side -----------------------------------------------------------------------------------
-    def create_test_data(self, frame: int = 0, secondary: bool = False):
-        """All h*w rays of camera `frame` (the cameras given at construction)."""
-        hw = self.h * self.w
-        b = self._generate(hw, first_index=frame * hw, want_o2=secondary)
+    def create_test_data(self, frame: int = 0, secondary: bool = False, rows=None):
+        """All h*w rays of camera `frame` (the cameras given at construction); rows = (r0, r1): the strip of image rows r0 .. r1-1
+        only (rays are independent: a frame splits into strips across GPUs with no exchange)."""
+        r0, r1 = (0, self.h) if rows is None else (int(rows[0]), int(rows[1]))
+        if not 0 <= r0 <= r1 <= self.h:
+            raise L.VipNerfHipError(f'create_test_data: rows {rows} outside the {self.h}-row frame')
+        b = self._generate((r1 - r0) * self.w, first_index=frame * self.h * self.w + r0 * self.w, want_o2=secondary)
         b['num_frames'] = self.n
         return b
 
-    def retrieve_inference_outputs(self, out: dict, fine: bool = True):
+    def retrieve_inference_outputs(self, out: dict, fine: bool = True, rows=None):
         lib = L.load()
         sfx = '_fine' if fine else '_coarse'
-        hw = self.h * self.w
+        h = self.h if rows is None else int(rows[1]) - int(rows[0])
+        hw = h * self.w
         dev = self.device
-        image = torch.empty(self.h, self.w, 3, dtype=torch.uint8, device=dev)
-        res = {'image': image, 'depth': torch.empty(self.h, self.w, device=dev), 'depth_var': torch.empty(self.h, self.w, device=dev)}
-        p = lambda t: ops.f32c(t).data_ptr() if t is not None else None
+        image = torch.empty(h, self.w, 3, dtype=torch.uint8, device=dev)
+        res = {'image': image, 'depth': torch.empty(h, self.w, device=dev), 'depth_var': torch.empty(h, self.w, device=dev)}
         dn, dvn = out.get(f'depth_ndc{sfx}'), out.get(f'depth_var_ndc{sfx}')
         if self.ndc:
-            res['depth_ndc'] = torch.empty(self.h, self.w, device=dev)
-            res['depth_var_ndc'] = torch.empty(self.h, self.w, device=dev)
+            res['depth_ndc'] = torch.empty(h, self.w, device=dev)
+            res['depth_var_ndc'] = torch.empty(h, self.w, device=dev)
         keep = [ops.f32c(out[f'rgb{sfx}']), ops.f32c(out[f'depth{sfx}']), ops.f32c(out[f'depth_var{sfx}']),
                 ops.f32c(dn) if dn is not None else None, ops.f32c(dvn) if dvn is not None else None]
         with ops.on_device(*keep, image):
@@ -253,14 +256,36 @@ class RayGeneratorHip:
                                                   res['depth_var_ndc'].data_ptr() if self.ndc else None,
                                                   ops._stream(dev)), 'vipnerf_postprocess_frame')
         if f'visibility2{sfx}' in out:
-            res['visibility2'] = out[f'visibility2{sfx}'].reshape(self.h, self.w, -1).permute(2, 0, 1).contiguous()
+            res['visibility2'] = out[f'visibility2{sfx}'].reshape(h, self.w, -1).permute(2, 0, 1).contiguous()
         return res
 
 
-def predict_frame(model, gen: RayGeneratorHip, frame: int = 0, secondary: bool = False):
+def predict_frame(model, gen: RayGeneratorHip, frame: int = 0, secondary: bool = False, rows=None):
     """NerfTester.predict_frame (reference src/Tester01.py:57-66): camera -> rays -> eval render -> images, all on
-    the GPU."""
-    b = gen.create_test_data(frame, secondary)
+    the GPU.  rows = (r0, r1): that strip of the frame only (predict_frame_sharded)."""
+    b = gen.create_test_data(frame, secondary, rows=rows)
     with torch.no_grad():
         out = model(b, sec_views_vis=secondary)
-    return gen.retrieve_inference_outputs(out, fine=getattr(model, 'fine_mlp_needed', True))
+    return gen.retrieve_inference_outputs(out, fine=getattr(model, 'fine_mlp_needed', True), rows=rows)
+
+
+def frame_strip(h: int, rank: int, world: int):
+    """Rows [r0, r1) of an h-row frame that rank `rank` of `world` renders: contiguous strips, sizes differing by at most one row."""
+    return (h * rank) // world, (h * (rank + 1)) // world
+
+
+def predict_frame_sharded(model, gen: RayGeneratorHip, frame: int = 0, secondary: bool = False, rank: int = 0, world: int = 1,
+                          gather: bool = True):
+    """One frame on `world` GPUs: every rank renders its strip of rows (no data-path collective -- rays are independent); with
+    gather=True the strips are then exchanged (torch.distributed.all_gather_object of the host copies: 2.3 MB of uint8 per
+    756 x 1008 frame) and every rank returns the whole frame as host tensors, otherwise its own strip on the GPU."""
+    rows = frame_strip(gen.h, rank, world)
+    part = predict_frame(model, gen, frame, secondary, rows=rows)
+    if not gather or world == 1:
+        return part
+    import torch.distributed as dist
+    host = {k: v.cpu() for k, v in part.items()}
+    parts = [None] * world
+    dist.all_gather_object(parts, host)
+    cat_dim = lambda k: 1 if k == 'visibility2' else 0          # visibility2 is (V, h, w)
+    return {k: torch.cat([p[k] for p in parts], dim=cat_dim(k)) for k in host}

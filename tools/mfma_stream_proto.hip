@@ -218,6 +218,200 @@ __global__ __launch_bounds__(512) void k32h(const char *w, int reps, float *out)
     out[blockIdx.x * 512 + tid] = s;
 }
 
+// ---- 8 waves x 16 points again (the shipped layout), with a layer EPILOGUE every 4 stages (64 values per lane: scale, ReLU, hi/lo
+// split into the next operand -- ~5 VALU slots per value, accumulators reset), and two ways of synchronising the weight ring:
+//   FREE = false: the shipped scheme -- the issuing wave drains its DMA, then ONE workgroup barrier per stage: all eight waves
+//                 (both waves of every SIMD) run in lock-step and reach the epilogue together, the MFMA pipe idles through it;
+//   FREE = true : no barrier at all.  landed[slot] (written by the wave that issued the stage, after its vmcnt drain) tells the
+//                 consumers a stage is there; done[slot] (one ds_add per wave and stage) tells the next issuer the slot is free.
+//                 Waves drift up to about a stage apart, so one wave's epilogue can fall under its SIMD partner's MFMAs.
+__device__ __forceinline__ unsigned lds_flag(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <bool FREE, bool EPI, bool PRIO>
+__global__ __launch_bounds__(512) void k16f(const char *w, int reps, float *out) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    unsigned *landed = (unsigned *)(lds + 2 * STAGE_BYTES), *done = landed + 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    floatx4 acc[16];
+    for (int t = 0; t < 16; ++t) acc[t] = (floatx4)(0.f);
+    bf16x8 b[2][2];
+    for (int s = 0; s < 2; ++s) for (int i = 0; i < 2; ++i) for (int e = 0; e < 8; ++e) b[s][i][e] = (__bf16)(0.001f * (lane + e + s + i));
+    if (tid < 4) landed[tid] = 0;
+    __syncthreads();
+    if (PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);          // a nudge out of lock-step: the second wave of each SIMD goes first
+    const int total = reps * N_STAGES;
+    if (wave == 0) glds_stage<1>(w, (unsigned)(size_t)lds, 0, lane);
+    for (int S = 0; S < total; ++S) {
+        const int slot = S & 1;
+        if (FREE) {
+            if (wave == (S & 7)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(landed + slot, (unsigned)(S + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            while (lds_flag(landed + slot) < (unsigned)(S + 1)) __builtin_amdgcn_s_sleep(1);
+        } else {
+            if (wave == (S & 7)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        asm volatile("" ::: "memory");
+        const char *st = lds + slot * STAGE_BYTES + lane * 16;
+        bf16x8 fr[3][2][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fr[g][tt][i] = *(const bf16x8 *)(st + ((g * 2 + tt) * 2 + i) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        if (S + 1 < total && wave == ((S + 1) & 7)) {
+            if (FREE) while (lds_flag(done + ((S + 1) & 1)) < 8u * (unsigned)((S + 1) >> 1)) __builtin_amdgcn_s_sleep(1);
+            glds_stage<1>(w + (size_t)((S + 1) % N_STAGES) * STAGE_BYTES, (unsigned)(size_t)lds + ((S + 1) & 1) * STAGE_BYTES, 0, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            if (g + 2 < 16) {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) fr[(g + 2) % 3][tt][i] = *(const bf16x8 *)(st + (((g + 2) * 2 + tt) * 2 + i) * 1024);
+            }
+            const int lin = g * 2, ks = lin / 16, t = lin % 16;
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][0][1], b[ks][0], acc[t], 0, 0, 0);
+            acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][1][1], b[ks][0], acc[t + 1], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][0][0], b[ks][1], acc[t], 0, 0, 0);
+            acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][1][0], b[ks][1], acc[t + 1], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][0][0], b[ks][0], acc[t], 0, 0, 0);
+            acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][1][0], b[ks][0], acc[t + 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (FREE && lane == 0) __hip_atomic_fetch_add(done + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (EPI && (S & 3) == 3) {
+            float fold[2][2][8];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) fold[q >> 4][(q >> 3) & 1][q & 7] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = fmaxf(acc[t][r] * 0.00390625f, 0.f);
+                    const __bf16 hi = (__bf16)v;
+                    const __bf16 lo = (__bf16)(v - (float)hi);
+                    fold[t >> 3][0][((t & 1) << 2) | r] += (float)hi * 1e-3f;
+                    fold[t >> 3][1][((t & 1) << 2) | r] += (float)lo;
+                    acc[t][r] = 0.01f * r;
+                }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) b[ks][i][e] = (__bf16)fold[ks][i][e];
+        }
+    }
+    __syncthreads();
+    float sum = 0.f;
+    for (int t = 0; t < 16; ++t) for (int r = 0; r < 4; ++r) sum += acc[t][r];
+    out[blockIdx.x * 512 + tid] = sum + (float)b[0][0][0];
+}
+
+// ---- the flag-synchronised ring again, deeper: NSLOT slots of 32 KiB (one k-step x 16 tiles x hi+lo), DMA NSLOT-1 stages ahead, so a
+// wave may run up to NSLOT-1 short stages ahead of the slowest one -- room for a whole epilogue of drift between the two waves of a SIMD.
+// A layer is 8 such stages; the epilogue follows every 8th.  The issuer of a stage publishes it one stage later (its DMA has had a
+// stage's time to land).
+template <int NSLOT, bool EPI, bool PRIO>
+__global__ __launch_bounds__(512) void k16g(const char *w, int reps, float *out) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int SB = 32 * 1024, NST = 2 * N_STAGES;            // 72 stages of 32 KiB per task
+    unsigned *landed = (unsigned *)(lds + NSLOT * SB), *done = landed + NSLOT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    floatx4 acc[16];
+    for (int t = 0; t < 16; ++t) acc[t] = (floatx4)(0.f);
+    bf16x8 b[2];
+    for (int i = 0; i < 2; ++i) for (int e = 0; e < 8; ++e) b[i][e] = (__bf16)(0.001f * (lane + e + i));
+    if (tid < 2 * NSLOT) landed[tid] = 0;
+    __syncthreads();
+    if (PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    const int total = reps * NST;
+    for (int T = 0; T < NSLOT - 1; ++T)
+        if (wave == (T & 7)) glds_stage<2>(w + (size_t)T * SB, (unsigned)(size_t)lds + T * SB, 0, lane);     // 32 pieces
+    for (int S = 0; S < total; ++S) {
+        const int slot = S % NSLOT;
+        {   // publish what this wave issued one stage ago (stage S + NSLOT - 2; the prologue's stages at S = 0)
+            const int T = S + NSLOT - 2;
+            if (S == 0) {
+                if (wave < NSLOT - 1) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(landed + wave, (unsigned)(wave + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else if (T < total && wave == (T & 7)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(landed + T % NSLOT, (unsigned)(T + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        while (lds_flag(landed + slot) < (unsigned)(S + 1)) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        const char *st = lds + slot * SB + lane * 16;
+        bf16x8 fr[3][2][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fr[g][tt][i] = *(const bf16x8 *)(st + ((g * 2 + tt) * 2 + i) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        {   // next DMA: stage S + NSLOT - 1 into the slot of stage S - 1, once all eight waves are done with that one
+            const int T = S + NSLOT - 1;
+            if (T < total && wave == (T & 7)) {
+                if (S >= 1) while (lds_flag(done + (S - 1) % NSLOT) < 8u * (unsigned)((S - 1) / NSLOT + 1)) __builtin_amdgcn_s_sleep(1);
+                glds_stage<2>(w + (size_t)(T % NST) * SB, (unsigned)(size_t)lds + (T % NSLOT) * SB, 0, lane);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g + 2 < 8) {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) fr[(g + 2) % 3][tt][i] = *(const bf16x8 *)(st + (((g + 2) * 2 + tt) * 2 + i) * 1024);
+            }
+            const int t = g * 2;
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][0][1], b[0], acc[t], 0, 0, 0);
+            acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][1][1], b[0], acc[t + 1], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][0][0], b[1], acc[t], 0, 0, 0);
+            acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][1][0], b[1], acc[t + 1], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][0][0], b[0], acc[t], 0, 0, 0);
+            acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][1][0], b[0], acc[t + 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (lane == 0) __hip_atomic_fetch_add(done + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (EPI && (S & 7) == 7) {
+            float fold[2][8];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) fold[q >> 3][q & 7] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = fmaxf(acc[t][r] * 0.00390625f, 0.f);
+                    const __bf16 hi = (__bf16)v;
+                    const __bf16 lo = (__bf16)(v - (float)hi);
+                    fold[0][((t & 1) << 2) | r] += (float)hi * 1e-3f;
+                    fold[1][((t & 1) << 2) | r] += (float)lo;
+                    acc[t][r] = 0.01f * r;
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) b[i][e] = (__bf16)fold[i][e];
+        }
+    }
+    __syncthreads();
+    float sum = 0.f;
+    for (int t = 0; t < 16; ++t) for (int r = 0; r < 4; ++r) sum += acc[t][r];
+    out[blockIdx.x * 512 + tid] = sum + (float)b[0][0];
+}
+
 int main() {
     const size_t bytes = (size_t)N_STAGES * STAGE_BYTES;
     char *w; float *out;
@@ -227,26 +421,46 @@ int main() {
     CK(hipFuncSetAttribute((const void *)k32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipFuncSetAttribute((const void *)k16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipFuncSetAttribute((const void *)k16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t ldsf = 2 * STAGE_BYTES + 64;
+    CK(hipFuncSetAttribute((const void *)k16f<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
+    CK(hipFuncSetAttribute((const void *)k16f<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
+    CK(hipFuncSetAttribute((const void *)k16f<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
+    CK(hipFuncSetAttribute((const void *)k16f<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
+    CK(hipFuncSetAttribute((const void *)k16f<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
+    const size_t ldsg = 4 * 32 * 1024 + 64;
+    CK(hipFuncSetAttribute((const void *)k16g<4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg));
+    CK(hipFuncSetAttribute((const void *)k16g<4, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg));
+    CK(hipFuncSetAttribute((const void *)k16g<4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg));
+    CK(hipFuncSetAttribute((const void *)k16g<3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg));
     const size_t ldsh = 2 * HSTAGE + 8 * 2 * XSLOT;
     CK(hipFuncSetAttribute((const void *)k32h<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int reps = 20;
     // MFMA cycles per task per SIMD: 36 stages x 96 MFMAs x 32 cycles (k32: one wave) = 36 x 2 waves x 96 x 16 (k16)
     const double mfma_cycles = 36.0 * 96 * 32;
-    for (int grid : {8, 256, 1024}) {
-        for (int which = 0; which < 4; ++which) {
+    for (int grid : {256, 1024}) {
+        for (int which = 0; which < 13; ++which) {
             for (int pass = 0; pass < 2; ++pass) {
                 CK(hipEventRecord(e0));
                 if (which == 0) hipLaunchKernelGGL(k32, dim3(grid), dim3(256), lds, 0, w, pass ? reps : 2, out);
                 else if (which == 1) hipLaunchKernelGGL(k16<0>, dim3(grid), dim3(512), lds, 0, w, pass ? reps : 2, out);
                 else if (which == 2) hipLaunchKernelGGL(k16<1>, dim3(grid), dim3(512), lds, 0, w, pass ? reps : 2, out);
-                else hipLaunchKernelGGL(k32h<2>, dim3(grid), dim3(512), ldsh, 0, w, pass ? reps : 2, out);
+                else if (which == 3) hipLaunchKernelGGL(k32h<2>, dim3(grid), dim3(512), ldsh, 0, w, pass ? reps : 2, out);
+                else if (which == 4) hipLaunchKernelGGL((k16f<false, false, false>), dim3(grid), dim3(512), ldsf, 0, w, pass ? reps : 2, out);
+                else if (which == 5) hipLaunchKernelGGL((k16f<true, false, false>), dim3(grid), dim3(512), ldsf, 0, w, pass ? reps : 2, out);
+                else if (which == 6) hipLaunchKernelGGL((k16f<false, true, false>), dim3(grid), dim3(512), ldsf, 0, w, pass ? reps : 2, out);
+                else if (which == 7) hipLaunchKernelGGL((k16f<true, true, false>), dim3(grid), dim3(512), ldsf, 0, w, pass ? reps : 2, out);
+                else if (which == 8) hipLaunchKernelGGL((k16f<true, true, true>), dim3(grid), dim3(512), ldsf, 0, w, pass ? reps : 2, out);
+                else if (which == 9) hipLaunchKernelGGL((k16g<4, false, false>), dim3(grid), dim3(512), ldsg, 0, w, pass ? reps : 2, out);
+                else if (which == 10) hipLaunchKernelGGL((k16g<4, true, false>), dim3(grid), dim3(512), ldsg, 0, w, pass ? reps : 2, out);
+                else if (which == 11) hipLaunchKernelGGL((k16g<4, true, true>), dim3(grid), dim3(512), ldsg, 0, w, pass ? reps : 2, out);
+                else hipLaunchKernelGGL((k16g<3, true, true>), dim3(grid), dim3(512), ldsg, 0, w, pass ? reps : 2, out);
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             }
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             const double rounds = grid <= 256 ? 1.0 : grid / 256.0;
             const double us_task = ms * 1e3 / reps / rounds;
-            printf("%s grid=%4d  %7.1f us per task   MFMA utilisation at 2.4 GHz: %.2f\n", which == 3 ? "32-pt x 8 waves, half-feature pairs      " : which == 2 ? "16-pt x 8 waves, term-major MFMA order" : (which ? "16-pt x 8 waves (16x16x32)            " : "32-pt x 4 waves (32x32x16)            "),
+            printf("%s grid=%4d  %7.1f us per task   MFMA utilisation at 2.4 GHz: %.2f\n", which == 12 ? "16-pt, flags, 3 x 32K, epilogue, setprio " : which == 11 ? "16-pt, flags, 4 x 32K, epilogue, setprio " : which == 10 ? "16-pt, flags, 4 x 32K ring, epilogue     " : which == 9 ? "16-pt, flags, 4 x 32K ring, no epilogue  " : which == 8 ? "16-pt, flags, epilogue, setprio         " : which == 7 ? "16-pt, flags (no barrier), epilogue     " : which == 6 ? "16-pt, barrier, epilogue               " : which == 5 ? "16-pt, flags (no barrier), no epilogue  " : which == 4 ? "16-pt, barrier, one issuing wave        " : which == 3 ? "32-pt x 8 waves, half-feature pairs      " : which == 2 ? "16-pt x 8 waves, term-major MFMA order" : (which ? "16-pt x 8 waves (16x16x32)            " : "32-pt x 4 waves (32x32x16)            "),
                    grid, us_task, mfma_cycles / 2400.0 / us_task);
         }
     }

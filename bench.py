@@ -40,6 +40,10 @@ ALGO_BYTES_FIXED = 2 * 4767784
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMDs x 256 FLOP/clk... @ 2.4 GHz
 F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA
 PEAK_CLOCK_MHZ = 2400.0         # the clock both peaks assume
+# What the chip SUSTAINS for dense 16-bit MFMA from registers alone, operands that look like data, over seconds (tools/
+# mfma_f16_sustained.hip next to rocm-smi, profiles/r02_mfma_f16_sustained.txt): 1686 (fp16) / 1708 (bf16) TFLOP/s -- power management
+# holds the 16-bit MFMA rate at 0.68 of the nominal figure whatever the kernel does.  Reported beside the contract's frac, never instead.
+F16_MFMA_SUSTAINED_TFLOPS = 1690.0
 HBM_PEAK_GBS = 8000.0
 # arithmetic -> (dtype string, dense MFMA peak of the operand dtype, MFMAs issued per multiply-add, note)
 ARITH = {
@@ -205,6 +209,12 @@ def roofline_block(prec, prof, steps, rays, ms_per_step, sclk_mhz):
          'sclk_mhz': sclk_mhz, 'traffic': None}
     if sclk_mhz:
         r['frac_at_measured_sclk'] = round(r['frac'] * PEAK_CLOCK_MHZ / sclk_mhz, 4)
+    if peak == F16_MFMA_PEAK_TFLOPS:
+        r['sustained_peak'] = F16_MFMA_SUSTAINED_TFLOPS
+        r['frac_of_sustained'] = round(tf(dom) / F16_MFMA_SUSTAINED_TFLOPS, 4)
+        r['frac_issued_of_sustained'] = round(min(tf(dom) * issued / F16_MFMA_SUSTAINED_TFLOPS, 9.99), 4)
+        r['sustained_note'] = 'dense 16-bit MFMA rate this chip sustains from registers alone (tools/mfma_f16_sustained.hip: 1.69 PFLOP/s ' \
+                              'at 1.75-1.9 GHz, 1.2-1.3 kW): the practical ceiling behind the nominal 2.5 PFLOP/s'
     algo_bytes = ALGO_BYTES_PER_RAY * rays + ALGO_BYTES_FIXED
     r['algorithmic_bytes_per_step'] = algo_bytes
     tr, name = pmc_reference(prec, rays)
@@ -370,6 +380,8 @@ def main():
             render[prec] = {'ms_per_frame': round(rt * 1e3, 1), 'rays_per_sec': round(n / rt, 1),
                             'mlp_kernel_ms': round(mlp_ms, 1), 'achieved_tflops': round(eval_flop / (mlp_ms * 1e-3) / 1e12, 1),
                             'frac': round(eval_flop / (mlp_ms * 1e-3) / 1e12 / ARITH[prec][1], 4),
+                            'frac_issued_of_sustained': round(eval_flop * ARITH[prec][2] / (mlp_ms * 1e-3) / 1e12 /
+                                                              (F16_MFMA_SUSTAINED_TFLOPS if ARITH[prec][1] == F16_MFMA_PEAK_TFLOPS else ARITH[prec][1]), 4),
                             'stage_ms': {k: round(v[1] / 2, 3) for k, v in sorted(rp.items())},
                             'row_strips': world}            # N > 1: one strip of rows per GPU, stage_ms = rank 0's strip
         model.configs['model']['hip_precision'] = args.precision

@@ -5,6 +5,8 @@
 // build: hipcc --offload-arch=gfx950 -O3 tools/mfma_stream_proto.hip -o tools/bin/mfma_stream_proto
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -412,10 +414,25 @@ __global__ __launch_bounds__(512) void k16g(const char *w, int reps, float *out)
     out[blockIdx.x * 512 + tid] = sum + (float)b[0][0];
 }
 
-int main() {
+// argv[1] = seconds: SUSTAINED mode -- weights that look like data (pseudo-random bf16 values; the default run streams zeros and so
+// never meets the power limit), every selected variant run back to back for that long, MFMA utilisation printed per one-second window
+int main(int argc, char **argv) {
+    const int sustained = argc > 1 ? atoi(argv[1]) : 0;
     const size_t bytes = (size_t)N_STAGES * STAGE_BYTES;
     char *w; float *out;
     CK(hipMalloc(&w, bytes)); CK(hipMemset(w, 0, bytes));
+    if (sustained) {
+        unsigned short *h = (unsigned short *)malloc(bytes);
+        unsigned seed = 12345u;
+        for (size_t i = 0; i < bytes / 2; ++i) {
+            seed = seed * 1664525u + 1013904223u;
+            const float v = ((int)(seed >> 16) % 2001 - 1000) * 1e-4f;
+            unsigned u; memcpy(&u, &v, 4);
+            h[i] = (unsigned short)(u >> 16);
+        }
+        CK(hipMemcpy(w, h, bytes, hipMemcpyHostToDevice));
+        free(h);
+    }
     CK(hipMalloc(&out, 4096 * 512 * 4));
     const size_t lds = 2 * STAGE_BYTES;
     CK(hipFuncSetAttribute((const void *)k32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -438,6 +455,30 @@ int main() {
     const int reps = 20;
     // MFMA cycles per task per SIMD: 36 stages x 96 MFMAs x 32 cycles (k32: one wave) = 36 x 2 waves x 96 x 16 (k16)
     const double mfma_cycles = 36.0 * 96 * 32;
+    auto name_of = [](int which) { return which == 12 ? "16-pt, flags, 3 x 32K, epilogue, setprio " : which == 11 ? "16-pt, flags, 4 x 32K, epilogue, setprio " : which == 10 ? "16-pt, flags, 4 x 32K ring, epilogue     " : which == 9 ? "16-pt, flags, 4 x 32K ring, no epilogue  " : which == 8 ? "16-pt, flags, epilogue, setprio         " : which == 7 ? "16-pt, flags (no barrier), epilogue     " : which == 6 ? "16-pt, barrier, epilogue               " : which == 5 ? "16-pt, flags (no barrier), no epilogue  " : which == 4 ? "16-pt, barrier, one issuing wave        " : which == 3 ? "32-pt x 8 waves, half-feature pairs      " : which == 2 ? "16-pt x 8 waves, term-major MFMA order" : (which ? "16-pt x 8 waves (16x16x32)            " : "32-pt x 4 waves (32x32x16)            "); };
+    if (sustained) {
+        const int grid = 1024;
+        for (int which : {0, 2, 3, 4, 6}) {
+            printf("%s", name_of(which));
+            for (int sec = 0; sec < sustained; ++sec) {
+                int n = 0; float ms = 0.f;
+                CK(hipEventRecord(e0));
+                do {
+                    if (which == 0) hipLaunchKernelGGL(k32, dim3(grid), dim3(256), lds, 0, w, reps, out);
+                    else if (which == 2) hipLaunchKernelGGL(k16<1>, dim3(grid), dim3(512), lds, 0, w, reps, out);
+                    else if (which == 3) hipLaunchKernelGGL(k32h<2>, dim3(grid), dim3(512), ldsh, 0, w, reps, out);
+                    else if (which == 4) hipLaunchKernelGGL((k16f<false, false, false>), dim3(grid), dim3(512), ldsf, 0, w, reps, out);
+                    else hipLaunchKernelGGL((k16f<false, true, false>), dim3(grid), dim3(512), ldsf, 0, w, reps, out);
+                    ++n; CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+                } while (ms < 1000.f);
+                const double us_task = ms * 1e3 / n / reps / (grid / 256.0);
+                printf(" %.2f", mfma_cycles / 2400.0 / us_task);
+                fflush(stdout);
+            }
+            printf("   MFMA utilisation vs 2.4 GHz per 1-s window (x 2500 = issued TFLOP/s)\n");
+        }
+        return 0;
+    }
     for (int grid : {256, 1024}) {
         for (int which = 0; which < 13; ++which) {
             for (int pass = 0; pass < 2; ++pass) {

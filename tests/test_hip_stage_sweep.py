@@ -90,3 +90,56 @@ def test_sample_fine_sweep_bit_exact(dev, kind, shape):
         assert torch.equal(s.cpu(), s_o), f'{kind} {shape} det={uu is None}: samples'
         assert torch.equal(zf.cpu(), zf_o), f'{kind} {shape} det={uu is None}: sorted merge'
         assert zf.shape == (n, Sc + Sf) and bool((zf[:, 1:] >= zf[:, :-1]).all())
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_composite_sweep_vs_oracle(dev, seed):
+    """volume_rendering + convert_depth_from_ndc (reference VipNeRF01.py:259-338) on explicit network outputs: sample counts 32..256,
+    densities from exactly 0 over 1e-6 to 1e4 (alpha -> 1 in one sample), NDC depths that reach exactly 1 and repeat, white
+    background, 0 / 1 / 3 secondary views."""
+    from test_hip_round2 import assert_close_few_outliers
+    ops = tp.hip_ops()
+    rs = np.random.default_rng(1300 + seed)
+    n, S = int(rs.integers(1, 150)), int(32 * rs.integers(1, 9))
+    ndc, white, V = bool(seed % 2), bool(seed % 3 == 0), int([0, 1, 3][seed % 3])
+    z = np.sort(rs.uniform(0.02 if not ndc else 0.0, 1.0 if ndc else 6.0, size=(n, S)).astype(np.float32), axis=1)
+    if ndc:
+        z[rs.random(n) < 0.3, -1] = 1.0                                       # far plane hit exactly: the 1e-3 guard of :329
+        z[rs.random(n) < 0.2, -3:] = 1.0
+    rep = rs.random(n) < 0.2
+    z[rep, 4:7] = z[rep, 4:5]                                                # repeated depths (zero-length intervals), still sorted
+    mag = rs.choice([0.0, 1e-6, 1e-2, 1.0, 50.0, 1e4], size=(n, S), p=[0.3, 0.1, 0.2, 0.25, 0.1, 0.05])
+    sigma = (mag * rs.random((n, S))).astype(np.float32)
+    sigma[rs.random(n) < 0.1] = 0.0                                          # empty rays: acc = 0, depth = 0 / (0 + 1e-10)
+    rgb = rs.random((n, S, 3), dtype=np.float32)
+    vis2 = rs.random((n, S, max(V, 1)), dtype=np.float32)[:, :, :V]
+    rays_d = np.stack([rs.uniform(-0.5, 0.5, n), rs.uniform(-0.4, 0.4, n), -np.ones(n)], -1).astype(np.float32)
+    rays_o = (rs.normal(size=(n, 3)) * 0.2).astype(np.float32)
+    rays_o[:, 2] = rs.uniform(-0.1, 0.1, n).astype(np.float32)
+    o_ndc, d_ndc = rays_o.copy(), (rs.normal(size=(n, 3)) * 0.7).astype(np.float32)
+    t = torch.from_numpy
+    net = {'sigma': t(sigma), 'rgb': t(rgb)}
+    if V:
+        net['visibility2'] = t(vis2)
+    ref = vo.composite(net, t(z), t(d_ndc if ndc else rays_d), ndc, t(rays_o), t(rays_d), white_bkgd=white)
+    cfg = ops.make_config(ndc, S, 0, V, False, white_bkgd=white)
+    b = {'rays_o': tp.cu(rays_o, dev), 'rays_d': tp.cu(rays_d, dev), 'view_dirs': tp.cu(rays_d, dev),
+         'rays_o2': tp.cu(np.zeros((n, max(V, 1), 3), np.float32)[:, :V], dev)}
+    zero = torch.zeros(n, device=dev)
+    if ndc:
+        b.update(rays_o_ndc=tp.cu(o_ndc, dev), rays_d_ndc=tp.cu(d_ndc, dev), near_ndc=zero, far_ndc=zero + 1)
+    else:
+        b.update(near=zero, far=zero + 1)
+    lvl = ops.composite(cfg, b, tp.cu(z, dev), tp.cu(sigma, dev), tp.cu(rgb, dev), tp.cu(vis2, dev) if V else None)
+    for hk, rk in (('rgb', 'rgb'), ('acc', 'acc'), ('alpha', 'alpha'), ('visibility', 'visibility'), ('weights', 'weights'),
+                   ('depth', 'depth'), ('depth_var', 'depth_var'), ('vis2', 'visibility2'), ('depth_ndc', 'depth_ndc'),
+                   ('depth_var_ndc', 'depth_var_ndc')):
+        if rk not in ref:
+            continue
+        a_, b_ = lvl[hk].cpu().double().numpy().reshape(ref[rk].shape), ref[rk].double().numpy()
+        assert np.isfinite(a_).all(), f'seed {seed} {rk}: non-finite'
+        if rk.startswith('depth') or rk == 'visibility2':                   # ratios by acc: a nearly empty ray is ill-conditioned
+            assert_close_few_outliers(lvl[hk], ref[rk], 2e-4, f'seed {seed} {rk}', max_frac=max(0.02, 1.5 / n))
+        else:
+            tol = 1e-4 * np.abs(b_) + max(1e-5 * np.abs(b_).max(), 2e-7)    # alpha carries an ulp of 1.0 absolute (test_hip_sweep.py)
+            assert np.all(np.abs(a_ - b_) <= tol), f'seed {seed} {rk}: max abs err {np.abs(a_ - b_).max():.3e} (ref max {np.abs(b_).max():.3e})'

@@ -48,14 +48,14 @@ ProfScope::ProfScope(const char *name, hipStream_t s) : idx(-1), st(s) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r{name, prof_event(), prof_event()};
     if (!r.e0 || !r.e1) return;
-    hipEventRecord(r.e0, st);
+    if (hipEventRecord(r.e0, st) != hipSuccess) return;       // profiling only: a scope that cannot be timed is dropped, not an error
     g_recs.push_back(r);
     idx = (int)g_recs.size() - 1;
 }
 ProfScope::~ProfScope() {
     if (idx < 0) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (idx < (int)g_recs.size()) hipEventRecord(g_recs[idx].e1, st);
+    if (idx < (int)g_recs.size()) (void)hipEventRecord(g_recs[idx].e1, st);   // a failed record shows up as a failed hipEventElapsedTime in profile_read, which skips the scope
 }
 
 // hipGetLastError() is sticky per thread: an error left behind by an unrelated earlier HIP call (e.g. a probe while

@@ -9,7 +9,6 @@ import os
 import sys
 from pathlib import Path
 
-import torch
 
 try:
     import vipnerf_hip  # noqa: F401

@@ -617,3 +617,14 @@ def test_empty_batch_is_a_no_op(dev):
     (out['rgb_fine'].sum() + out['depth_fine'].sum()).backward()
     for k, t in model.named_parameters():
         assert t.grad is not None and float(t.grad.abs().max()) == 0, k
+
+
+def test_build_then_smoke_in_one_interpreter():
+    """__graft_entry__.build() loads the library (and checks its ABI) before anything has imported torch; smoke() then needs the GPU
+    through PyTorch's HIP runtime.  With this library pulled in ahead of torch's own libamdhip64 the process held two runtimes and
+    the first kernel launch reported "no ROCm-capable device is detected" -- _lib.load() imports torch first now.  A fresh
+    interpreter, in the driver's order."""
+    import subprocess
+    r = subprocess.run([sys.executable, '-c', 'import __graft_entry__ as g; g.build(); g.smoke(); print("BUILD+SMOKE OK")'],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and 'BUILD+SMOKE OK' in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])

@@ -156,6 +156,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise VipNerfHipError(f'{LIB_PATH} not found: build it with vip-nerf_amd/build.sh '
                               f'(or __graft_entry__.build()); there is no CPU fallback')
+    # PyTorch-ROCm brings its own HIP runtime (torch/lib/libamdhip64.so); the device memory this library works on is PyTorch's, so
+    # that runtime must be the one in the process.  Loaded the other way round -- this library first, resolving its libamdhip64
+    # from /opt/rocm, torch afterwards -- the process holds two runtimes and the second one to touch the driver reports "no
+    # ROCm-capable device is detected" (seen with build() followed by smoke() in one interpreter).
+    import torch  # noqa: F401
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:

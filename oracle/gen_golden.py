@@ -2,6 +2,7 @@
 /root/reference/src, never copied) on seeded synthetic inputs.  Runs only in the build container.
 
     python oracle/gen_golden.py            # rewrites tests/golden/*.npz
+    python oracle/check_goldens.py         # regenerates into a temporary directory and compares with the committed files, bit for bit
 
 What is captured: F1 sample_pdf (+ searchsorted indices), F2 MLP.forward, F3
 volume_rendering / convert_depth_from_ndc / compute_other_view_dirs, F4 render_rays in eval mode, F5 one
@@ -30,7 +31,7 @@ from models.ModelFactory import get_model  # noqa: E402  (reference)
 from models.VipNeRF01 import VipNeRF, MLP  # noqa: E402  (reference)
 from loss_functions.LossComputer01 import LossComputer  # noqa: E402  (reference)
 
-GOLD = os.path.join(ROOT, 'tests', 'golden')
+GOLD = os.environ.get('VIPNERF_GOLDEN_OUT') or os.path.join(ROOT, 'tests', 'golden')     # oracle/check_goldens.py redirects it
 os.makedirs(GOLD, exist_ok=True)
 
 

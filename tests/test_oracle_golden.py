@@ -161,3 +161,14 @@ def test_f7_visibility_prior_generator():
                                int(g['n_planes']), float(g['temperature']))
         np.testing.assert_allclose(w, g[key], rtol=1e-11, atol=1e-13)
         assert np.array_equal(w > 0.5, g[key] > 0.5)
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/src'), reason='the reference tree exists in the build container only')
+def test_committed_goldens_are_what_the_reference_produces():
+    """oracle/check_goldens.py: every fixture regenerated from the imported reference into a temporary directory equals the
+    committed file -- same keys, every array bit for bit (a generator edited without re-committing its output fails here)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'oracle', 'check_goldens.py')], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

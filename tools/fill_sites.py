@@ -1,0 +1,38 @@
+"""Where do the small fill / elementwise kernels of a training step come from?  torch.profiler with Python stacks over two bench steps:
+   python tools/fill_sites.py [precision]"""
+import os, sys, collections, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'vip-nerf_amd')); sys.path.insert(0, os.path.join(ROOT, 'vip-nerf_amd', 'src'))
+import bench
+from oracle import vipnerf_oracle as vo          # synthetic batches only
+from models.ModelFactory import get_model
+from loss_functions.LossComputerHip01 import LossComputerHip
+from vipnerf_hip import dist as vdist
+dev = torch.device('cuda:0')
+cfg = bench.model_configs(); cfg['model']['hip_precision'] = sys.argv[1] if len(sys.argv) > 1 else 'fp32'
+model = get_model(cfg, None).to(dev).train()
+lossc = LossComputerHip(cfg)
+opt = torch.optim.Adam(model.parameters(), lr=5e-4, fused=True)
+bucket = vdist.FlatGradBucket(model.parameters())
+b = bench.make_batch(vo, 4096, 1, dev)
+def step(i):
+    bb = dict(b); bb['iter_num'] = 40000 + i; bb['common_data'] = {'poses': b['common_data']['poses']}
+    bucket.release()
+    out = model(bb)
+    lossc.compute_losses(bb, out)['TotalLoss'].backward()
+    bucket.all_reduce_mean()
+    opt.step()
+for i in range(3): step(i)
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    for i in range(2): step(10 + i)
+    torch.cuda.synchronize()
+sites = collections.Counter()
+for e in prof.events():
+    if e.name in ('aten::fill_', 'aten::zero_', 'aten::zeros', 'aten::mul', 'aten::add', 'aten::sum', 'aten::copy_', 'aten::index', 'aten::eq',
+                  'aten::ones_like', 'aten::full', 'aten::div', 'aten::sub', 'aten::neg', 'aten::to', 'aten::_to_copy', 'aten::clone', 'aten::cat'):
+        st = [s for s in (e.stack or []) if 'vip-nerf_amd' in s or 'bench.py' in s or 'fill_sites' in s]
+        sites[(e.name, st[0] if st else '(no repo frame)')] += 1
+for (n, s), c in sites.most_common(40):
+    print(f'{c / 2:5.1f} per step  {n:16s} {s}')

@@ -220,8 +220,14 @@ static int wgrad(int64_t P, int M, const float *dY, int ldy, const float *X0, in
     GenWgrad g;
     g.P = P; g.M = M; g.dY = dY; g.ldy = ldy; g.X0 = X0; g.ldx0 = ldx0; g.K0 = K0; g.X1 = X1; g.ldx1 = ldx1; g.K1 = K1;
     g.dW = dW; g.ldw = ldw; g.woff = woff; g.db = db;
-    int chunks = (int)((P + 4095) / 4096);
-    if (chunks > 1024) chunks = 1024;
+    // point chunks: enough workgroups to fill the chip whatever the layer's size (a 64 x 64 layer is ONE output tile -- with 4096-point
+    // chunks the toy network's 65,536 points ran on 16 of 256 CUs, 0.54 ms per GEMM), at least 128 points each so that the atomics
+    // that merge the chunks stay a small part of the work
+    const int tiles = ((M + GT - 1) / GT) * ((K0 + K1 + GT - 1) / GT);
+    int chunks = (1024 + tiles - 1) / tiles;
+    const int64_t most = (P + 127) / 128;
+    if (chunks > most) chunks = (int)most;
+    if (chunks < 1) chunks = 1;
     g.chunk = (int)(((P + chunks - 1) / chunks + GK - 1) / GK * GK);
     chunks = (int)((P + g.chunk - 1) / g.chunk);
     hipLaunchKernelGGL(k_gen_wgrad, dim3((unsigned)((M + GT - 1) / GT), (unsigned)((K0 + K1 + GT - 1) / GT), (unsigned)chunks), dim3(256), 0, st, g);

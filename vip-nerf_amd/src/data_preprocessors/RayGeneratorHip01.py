@@ -256,7 +256,8 @@ class RayGeneratorHip:
                                                   res['depth_var_ndc'].data_ptr() if self.ndc else None,
                                                   ops._stream(dev)), 'vipnerf_postprocess_frame')
         if f'visibility2{sfx}' in out:
-            res['visibility2'] = out[f'visibility2{sfx}'].reshape(h, self.w, -1).permute(2, 0, 1).contiguous()
+            v2 = out[f'visibility2{sfx}']
+            res['visibility2'] = v2.reshape(h, self.w, v2.shape[-1]).permute(2, 0, 1).contiguous()      # (an empty strip has no -1 to infer)
         return res
 
 

@@ -24,6 +24,10 @@ import sys
 import threading
 import time
 
+# multi-process GPU work on this platform needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails with the legacy mode); the environment
+# exports it already -- kept here for launchers that build their own environment.  Must be set before the HSA runtime starts.
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -9,6 +9,8 @@ means is the global mean and averaging the gradients is exact.
 import os
 from typing import Iterable, List
 
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')    # dmabuf IPC for RCCL across processes (no effect once the runtime is up)
+
 import torch
 import torch.distributed as dist
 

@@ -1,5 +1,5 @@
 """Trains the synthetic 3-camera plane scene of tests/test_hip_train_e2e.py with TrainerHip01 in one arithmetic and prints the
-loss / PSNR trajectory:  python tools/train_synthetic.py [precision=fp16x3] [iterations=1500]"""
+loss / PSNR trajectory:  python tools/train_synthetic.py [precision=fp16x3] [iterations=1500] [image side=64] [rays per iteration=1024]"""
 import os, sys, time, tempfile
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,20 +10,24 @@ from TrainerHip01 import TrainerHip
 from data_preprocessors.RayGeneratorHip01 import BatchIndexScheduler, RayGeneratorHip
 prec = sys.argv[1] if len(sys.argv) > 1 else 'fp16x3'
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
+side = int(sys.argv[3]) if len(sys.argv) > 3 else 64            # image side; focal length scales with it
+rays = int(sys.argv[4]) if len(sys.argv) > 4 else 1024           # rays per iteration
 dev = torch.device('cuda:0')
-n, h, w = 3, 64, 64
-K, poses, images_u8 = e2e.synthetic_scene(n, h, w, f=80.0)
+n, h, w = 3, side, side
+K, poses, images_u8 = e2e.synthetic_scene(n, h, w, f=80.0 * side / 64)
 images = torch.from_numpy(images_u8.astype(np.float32) / 255)
 torch.manual_seed(0); np.random.seed(0)
 cfg = e2e.configs(iters, prec)
 cfg['model_save_interval'] = 0
-cfg['validation_interval'] = 250
+cfg['validation_interval'] = 250 if iters <= 3000 else 1000
 gen = RayGeneratorHip((h, w), K[None], poses, 2.0, 4.0, False, dev, images=images, visibility_prior=torch.ones(n, n - 1, h, w))
-tr = TrainerHip(cfg, gen, BatchIndexScheduler(n, h, w, num_rays=1024), output_dirpath=tempfile.mkdtemp())
+if rays > 1024:
+    cfg['sub_batch_size'] = 0      # one sub-batch (the default configuration splits its 1024 rays into two of 512)
+tr = TrainerHip(cfg, gen, BatchIndexScheduler(n, h, w, num_rays=rays), output_dirpath=tempfile.mkdtemp())
 torch.cuda.synchronize(); t0 = time.time()
 hist = tr.train()
 torch.cuda.synchronize(); dt = time.time() - t0
 mse = np.array([x['MSEHip01'] for x in hist])
 psnr = [(i + 1, round(x['validation_psnr'], 2)) for i, x in enumerate(hist) if 'validation_psnr' in x]
-print(f'{prec}: {iters} iterations of 1024 rays in {dt:.1f} s ({iters * 1024 / dt / 1e3:.0f} k rays/s incl. validation renders); '
+print(f'{prec}: {iters} iterations of {rays} rays ({side} x {side} images) in {dt:.1f} s ({iters * rays / dt / 1e3:.0f} k rays/s incl. validation renders); '
       f'MSE {mse[:10].mean():.4f} -> {mse[-50:].mean():.5f}; all finite: {bool(np.isfinite(mse).all())}; PSNR of the training views: {psnr}')

@@ -200,16 +200,12 @@ class RayGeneratorHip:
             if scheduler is None:
                 raise L.VipNerfHipError('get_next_batch needs either ray indices or a BatchIndexScheduler')
             indices, row_is_sparse = scheduler.next(iter_num)
-        if isinstance(indices, numpy.ndarray):
-            indices = torch.from_numpy(indices)
-        indices = indices.to(self.device)
+        indices = self._upload(indices, torch.int64)
         sparse_on = self.sparse_depths is not None
         if row_is_sparse is None and sparse_on:
-            row_is_sparse = numpy.zeros(indices.shape[0], dtype=bool)
+            row_is_sparse = torch.zeros(indices.shape[0], dtype=torch.bool, device=self.device)
         if row_is_sparse is not None:
-            if isinstance(row_is_sparse, numpy.ndarray):
-                row_is_sparse = torch.from_numpy(row_is_sparse)
-            row_is_sparse = row_is_sparse.to(self.device).bool()
+            row_is_sparse = self._upload(row_is_sparse, torch.bool)
         b = self._generate(indices.shape[0], indices=indices, want_targets=True, row_is_sparse=row_is_sparse if sparse_on else None)
         b['iter_num'] = iter_num
         b['num_frames'] = self.n
@@ -221,6 +217,36 @@ class RayGeneratorHip:
             b['indices_mask_nerf'] = torch.ones(indices.shape[0], dtype=torch.bool, device=self.device)
         b['common_data'] = {'poses': self.poses[None]}
         return b
+
+    def _upload(self, x, dtype):
+        """Host index / flag arrays -> device WITHOUT draining the stream: a copy from pageable host memory waits for everything
+        queued before it (one full stall of the GPU per training iteration); from a pinned staging buffer it is just another
+        stream-ordered operation.  A ring of staging buffers, each reused only after the copy that last read it has completed."""
+        if isinstance(x, torch.Tensor) and x.is_cuda:
+            return x.to(self.device, dtype)
+        t = torch.from_numpy(numpy.ascontiguousarray(x)) if isinstance(x, numpy.ndarray) else x
+        t = t.to(dtype)
+        n = t.numel()
+        if n == 0 or self.device.type != 'cuda':
+            return t.to(self.device)
+        ring = self.__dict__.setdefault('_staging', {})
+        slots = ring.setdefault(dtype, [])
+        k = self.__dict__.get('_staging_next', 0)
+        self._staging_next = k + 1
+        i = k % 4
+        while len(slots) <= i:
+            slots.append([None, None])
+        buf, ev = slots[i]
+        if ev is not None:
+            ev.synchronize()                                   # the copy issued four uploads ago: long done
+        if buf is None or buf.numel() < n:
+            buf = torch.empty(max(n, 8192), dtype=dtype).pin_memory()
+        buf[:n].copy_(t.reshape(-1))
+        out = buf[:n].to(self.device, non_blocking=True).reshape(t.shape)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        slots[i] = [buf, ev]
+        return out
 
     # ---- inference side -----------------------------------------------------------------------------------
     def create_test_data(self, frame: int = 0, secondary: bool = False, rows=None):

@@ -165,7 +165,11 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
 #pragma unroll 1
     for (int it = 0; it < 8; ++it) {
         const int layer = 7 - it;
+#if defined(VN_EXP) && VN_EXP == 31
+        const uint2 mk = make_uint2(0xffffffffu, 0xfffffffeu + (unsigned)(layer & 1));   // timing experiment only: no ReLU-mask loads
+#else
         const uint2 mk = *(const uint2 *)(a.acts + a.al.hm[layer] + ((size_t)p * 4 + q) * 2);
+#endif
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc[t] = (floatx4)(0.f);
 #pragma unroll
@@ -194,8 +198,10 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
                     x[u][0] = fmaf(w4.x, dsig_raw, x[u][0]); x[u][1] = fmaf(w4.y, dsig_raw, x[u][1]);
                     x[u][2] = fmaf(w4.z, dsig_raw, x[u][2]); x[u][3] = fmaf(w4.w, dsig_raw, x[u][3]);
                 }
+#if !(defined(VN_EXP) && VN_EXP == 32)                                   // timing experiment 32: no mask arithmetic
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[u][r] = mask_apply16(x[u][r], mk.x, mk.y, t, r);
+#endif
                 if (!H16 || it == 7) store_tile16(dst, p, W, q, t, x[u]);
                 if (H16 == 1 && layer == SKIP_LAYER) store_tile16(a.bwd + a.bl.dy5f, p, W, q, t, x[u]);   // pre-split storage keeps both parts: no copy
             }

@@ -104,32 +104,30 @@ class VisibilityWeightsComputerHip:
         Image.fromarray(image_u8, mode='L').save(path.as_posix())
 
     @classmethod
-    def save_mask(cls, path: Path, mask: numpy.ndarray, as_image: bool = False):
-        """reference :184-197"""
+    def _save(cls, path: Path, array: numpy.ndarray, preview_u8: numpy.ndarray, also_png: bool):
+        """One pair file in the reference's formats: `.npy` holds the array itself (optionally with an 8-bit PNG preview beside
+        it), `.png` only the preview."""
+        path = Path(path)
         path.parent.mkdir(parents=True, exist_ok=True)
-        mask_image = mask.astype('uint8') * 255
-        if path.suffix == '.png':
-            cls._write_png(path, mask_image)
-        elif path.suffix == '.npy':
-            numpy.save(path.as_posix(), mask)
-            if as_image:
-                cls._write_png(path.parent / f'{path.stem}.png', mask_image)
+        kind = path.suffix.lower()
+        if kind == '.npy':
+            numpy.save(path.as_posix(), array)
+            if also_png:
+                cls._write_png(path.with_suffix('.png'), preview_u8)
+        elif kind == '.png':
+            cls._write_png(path, preview_u8)
         else:
             raise RuntimeError(f'Unknown format: {path.as_posix()}')
 
     @classmethod
+    def save_mask(cls, path: Path, mask: numpy.ndarray, as_image: bool = False):
+        """Bool mask; preview 255 = visible, 0 = not (what the reference's loader compares against; reference :184-197)."""
+        cls._save(path, mask, numpy.where(mask, 255, 0).astype(numpy.uint8), as_image)
+
+    @classmethod
     def save_weights(cls, path: Path, weights: numpy.ndarray, as_png: bool = False):
-        """reference :199-211"""
-        weights_image = numpy.round(weights * 255).astype('uint8')
-        path.parent.mkdir(parents=True, exist_ok=True)
-        if path.suffix == '.png':
-            cls._write_png(path, weights_image)
-        elif path.suffix == '.npy':
-            numpy.save(path.as_posix(), weights)
-            if as_png:
-                cls._write_png(path.parent / f'{path.stem}.png', weights_image)
-        else:
-            raise RuntimeError(f'Unknown weights format: {path.as_posix()}')
+        """float64 weights in [0, 1]; preview round(255 w) (reference :199-211)."""
+        cls._save(path, weights, numpy.rint(weights * 255).astype(numpy.uint8), as_png)
 
 
 def load_scene_masks(masks_dirpath, frame_nums) -> numpy.ndarray:

@@ -242,7 +242,7 @@ int32_t vipnerf_query_workspace(const vipnerf_config *cfg, int64_t n_rays, size_
     if (acts_bytes)
         *acts_bytes = cfg->save_acts ? (act_layout(Pc, cfg->n_sec).total + (Pf ? act_layout(Pf, cfg->n_sec).total : 0)) * sizeof(float) : 0;
     if (bwd_bytes) {
-        const bool h16 = cfg->precision == VIPNERF_PREC_FP16X3H || cfg->precision == VIPNERF_PREC_FP16;       // the only mode with an fp32 copy of dY_5 in the workspace
+        const bool h16 = stores_high16(cfg->precision);       // the modes with an fp32 copy of dY_5 in the workspace
         const size_t a = bwd_total(Pc, cfg->n_sec, h16), b = Pf ? bwd_total(Pf, cfg->n_sec, h16) : 0;
         *bwd_bytes = (a > b ? a : b) * sizeof(float);       // levels run one after the other
     }
@@ -447,7 +447,7 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
             if ((rc = launch_gen_bwd(t, src, (const float *)(lv ? packed_fine : packed_coarse), L.raw_sigma, ga, bw, gb, G, st))) return rc;
             continue;
         }
-        const BwdLayout bl = bwd_layout(P, V, cfg->precision == VIPNERF_PREC_FP16X3H || cfg->precision == VIPNERF_PREC_FP16);
+        const BwdLayout bl = bwd_layout(P, V, stores_high16(cfg->precision));
         // 1. compositing backward -> dLoss/d(raw network outputs)
         CompositeBwdArgs cb;
         memset(&cb, 0, sizeof(cb));

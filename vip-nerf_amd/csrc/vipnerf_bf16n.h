@@ -34,6 +34,16 @@ __host__ __device__ constexpr int dir_feat16(int q, int e) {
     return e < 6 ? 3 + 6 * q + e : (q == 0 ? e - 6 : (q == 1 && e == 6 ? 2 : -1));
 }
 
+// timing-only builds (tools/build_exp.sh N; results are garbage): which stores of the narrow training kernels are left out.
+//   40: every activation / gradient / mask / encoding store (the kernels' compute floor)
+//   41: the fp32 "extras" only -- feature, view hidden, gamma(x), gamma(dir); dY_0, the fp32 dY_5 copy, dYv, sum dYv
+//   42: gamma(x) / gamma(dir) only
+#if defined(VN_EXP)
+constexpr bool EXP_NO_STORES = VN_EXP == 40, EXP_NO_EXTRAS = VN_EXP == 40 || VN_EXP == 41, EXP_NO_PE = VN_EXP == 40 || VN_EXP == 41 || VN_EXP == 42;
+#else
+constexpr bool EXP_NO_STORES = false, EXP_NO_EXTRAS = false, EXP_NO_PE = false;
+#endif
+
 // VN_SKEW (two-part modes only): waves 4..7 -- the second wave of every SIMD -- run one weight stage behind waves 0..3,
 // so that one wave's layer epilogue (VALU, stores) falls under the other's MFMAs instead of both doing it at once.
 // Needs three resident stages, hence half-size ones (32 KiB); WStreamSkew below.  Built, correct (all tests pass with
@@ -237,6 +247,16 @@ __device__ __forceinline__ floatx4 load_tile16(const float *base, int64_t p, int
 #ifndef VN_DEFER_STORES
 #define VN_DEFER_STORES 1
 #endif
+// VIPNERF_PREC_BF16 (single bf16 MFMA per product): 1 = the trunk activations h_1..h_8 and the gradients dY_1..dY_7, dY_feature are
+// stored as the bf16 operands the next GEMM consumes anyway (2 bytes per value, like VIPNERF_PREC_FP16; the 256x256 weight-gradient
+// GEMMs then run ONE bf16 MFMA per product on them); 0 = round 2's fp32 storage + bf16 hi/lo weight gradients.
+#ifndef VN_BF16_H16
+#define VN_BF16_H16 1
+#endif
+// precisions whose 256-wide trunk activations / gradients are stored as 16-bit high parts only ([P][256] halves in the fp32 slot)
+__host__ __device__ inline bool stores_high16(int precision) {
+    return precision == VIPNERF_PREC_FP16X3H || precision == VIPNERF_PREC_FP16 || (precision == VIPNERF_PREC_BF16 && VN_BF16_H16);
+}
 // FP16X3H: the fp16 high parts of a B fragment (k-step s <- tiles 2s, 2s+1) ARE the fp16 image of those two tiles:
 // elements 4u .. 4u+3 of part 0 are features 16 (2s+u) + 4q .. +3.  Stored as [P][ld] halves (8 bytes per lane, tile).
 __device__ __forceinline__ void store_pair16h(float *base, int64_t p, int ld, int q, int s, const half8 &hi) {
@@ -246,7 +266,14 @@ __device__ __forceinline__ void store_pair16h(float *base, int64_t p, int ld, in
     __builtin_nontemporal_store(a, (half4 *)(row + 16 * (2 * s)));
     __builtin_nontemporal_store(b, (half4 *)(row + 16 * (2 * s + 1)));
 }
-__device__ __forceinline__ void store_pair16h(float *, int64_t, int, int, int, const bf16x8 &) {}   // never used
+// the same for bf16 high parts (VIPNERF_PREC_BF16: the rounded operand of the next GEMM is what is stored)
+__device__ __forceinline__ void store_pair16h(float *base, int64_t p, int ld, int q, int s, const bf16x8 &hi) {
+    typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+    __bf16 *row = (__bf16 *)base + (size_t)p * ld + 4 * q;
+    const bf4 a = {hi[0], hi[1], hi[2], hi[3]}, b = {hi[4], hi[5], hi[6], hi[7]};
+    __builtin_nontemporal_store(a, (bf4 *)(row + 16 * (2 * s)));
+    __builtin_nontemporal_store(b, (bf4 *)(row + 16 * (2 * s + 1)));
+}
 __device__ __forceinline__ void store_pair16h(float *, int64_t, int, int, int, const f32q &) {}
 // VN_F16_PRESPLIT: both fp16 parts of the two tiles, in the fp32 array's own geometry: the 16 bytes a lane owns per tile
 // (4 features) hold [hi(f0,f1)] [hi(f2,f3)] [lo(f0,f1)] [lo(f2,f3)] -- the registers of the split as they are, one 16-byte
@@ -295,6 +322,7 @@ struct DeferredStores {
     template <int g, int NG> static constexpr bool active() { return H16 == 1 ? g == NG - 1 : (g == VN_STORE_GROUP_A || g == VN_STORE_GROUP_B); }
     template <int g, int NG>
     __device__ __forceinline__ void at() const {
+        if (EXP_NO_STORES) return;
         if (H16 == 1 || (g == VN_STORE_GROUP_A) == (wave < 4)) {
 #pragma unroll
             for (int s = s0; s < s0 + NSTEP; ++s) {

@@ -127,12 +127,12 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
             d[1] = g[1] > 0.f ? dg.y : 0.f;
             d[2] = g[2] > 0.f ? dg.z : 0.f;
             d[3] = g[3] > 0.f ? dg.w : 0.f;
-            store_tile16(a.bwd + a.bl.dyv[dsel], p, WV, q, t, d);
+            if (!EXP_NO_EXTRAS) store_tile16(a.bwd + a.bl.dyv[dsel], p, WV, q, t, d);
             vsum[t] += d;
         }
     }
 #pragma unroll
-    for (int t = 0; t < 8; ++t) store_tile16(a.bwd + a.bl.dyvsum, p, WV, q, t, vsum[t]);
+    for (int t = 0; t < 8; ++t) if (!EXP_NO_EXTRAS) store_tile16(a.bwd + a.bl.dyvsum, p, WV, q, t, vsum[t]);
 
     // ---------------------------------------------------------------- d(feature) = W_vf^T sum_a dYv_a   (K = 128: 4 k-steps)
     FR bin[8][NS];
@@ -202,8 +202,8 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[u][r] = mask_apply16(x[u][r], mk.x, mk.y, t, r);
 #endif
-                if (!H16 || it == 7) store_tile16(dst, p, W, q, t, x[u]);
-                if (H16 == 1 && layer == SKIP_LAYER) store_tile16(a.bwd + a.bl.dy5f, p, W, q, t, x[u]);   // pre-split storage keeps both parts: no copy
+                if ((!H16 || it == 7) && !((H16 && it == 7) ? EXP_NO_EXTRAS : EXP_NO_STORES)) store_tile16(dst, p, W, q, t, x[u]);
+                if (H16 == 1 && layer == SKIP_LAYER && !EXP_NO_EXTRAS) store_tile16(a.bwd + a.bl.dy5f, p, W, q, t, x[u]);   // pre-split storage keeps both parts: no copy
             }
             if (it < 7) {
                 split_pair<NS>(x[0], x[1], bin[s]);
@@ -231,7 +231,7 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
     if (precision == 0) return launch_one_bwd_n<2, false, VN_F32_DEFER ? 3 : 0, true>(a, grid, st);
     if (precision == 1) return launch_one_bwd_n<2>(a, grid, st);
     if (precision == 2) return launch_one_bwd_n<3>(a, grid, st);
-    if (precision == 6) return launch_one_bwd_n<1>(a, grid, st);
+    if (precision == 6) return launch_one_bwd_n<1, false, VN_BF16_H16>(a, grid, st);
     if (precision == 3 || precision == 4 || precision == 5) {
         // the level's largest seed first (one pass over 5+V floats per point)
         unsigned *slot = (unsigned *)(a.bwd + a.bl.gmax);

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
         load_point(a.src, p, pc0);           // than kept in 13 registers across the trunk
         encode_x16(pc0.x, q, pe);
     }
-    if (SAVE && valid) store_x16(a.acts + a.al.pex + (size_t)p * DPE_PAD, q, pe);
+    if (SAVE && valid && !EXP_NO_PE) store_x16(a.acts + a.al.pex + (size_t)p * DPE_PAD, q, pe);
     if (F16) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[u][r] = relu_lo<F16 || (F32 && SAVE)>(x[u][r] * AU, lo);   // (+0 | positive | NaN for the bit masks)
                 if (SAVE) {
-                    if (!(H16 && layer < 8)) store_tile16(dst, p, W, q, t, x[u]);
+                    if (!(H16 && layer < 8) && !(layer < 8 ? EXP_NO_STORES : EXP_NO_EXTRAS)) store_tile16(dst, p, W, q, t, x[u]);
                     if (F16 || F32) {
                         if (t < 8) mk0 = push_nibble(mk0, positive_nibble(x[u])); else mk1 = push_nibble(mk1, positive_nibble(x[u]));
                     } else {
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             if (SAVE && !DEFER && H16 == 2 && layer < 8) store_pair_split(dst, p, W, q, s, bin[s][0], bin[s][NS > 1 ? 1 : 0]);
             if (SAVE && !DEFER && H16 == 3 && layer < 8) store_pair_f32(dst, p, W, q, s, bin[s][0], bin[s][NS > 1 ? 1 : 0]);
         }
-        if (SAVE && layer < 8) *(uint2 *)(a.acts + a.al.hm[layer] + ((size_t)p * 4 + q) * 2) = make_uint2(mk0, mk1);
+        if (SAVE && layer < 8 && !EXP_NO_STORES) *(uint2 *)(a.acts + a.al.hm[layer] + ((size_t)p * 4 + q) * 2) = make_uint2(mk0, mk1);
     }
 
     {
@@ -271,9 +271,11 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) g[t][r] = relu_lo<F16>(g[t][r] * AU, 0.f);
         if (SAVE) {
+            if (!EXP_NO_EXTRAS) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) store_tile16(a.acts + a.al.g[dsel], p, WV, q, t, g[t]);
-            if (valid) store_d16(a.acts + a.al.ped[dsel] + (size_t)p * DVE_PAD, q, ped);
+                for (int t = 0; t < 8; ++t) store_tile16(a.acts + a.al.g[dsel], p, WV, q, t, g[t]);
+            }
+            if (valid && !EXP_NO_PE) store_d16(a.acts + a.al.ped[dsel] + (size_t)p * DVE_PAD, q, ped);
         }
         float qv[4];
 #pragma unroll
@@ -323,7 +325,7 @@ int launch_mlp_fwd_bf16n(const MlpFwdArgs &a, int precision, hipStream_t st) {
     if (precision == 3) return a.acts ? launch_one_n<true, 2, true, VN_F16_PRESPLIT ? 2 : 0>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);
     if (precision == 4) return a.acts ? launch_one_n<true, 2, true, 1>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);
     if (precision == 5) return a.acts ? launch_one_n<true, 1, true, 1>(a, grid, st) : launch_one_n<false, 1, true>(a, grid, st);
-    if (precision == 6) return a.acts ? launch_one_n<true, 1>(a, grid, st) : launch_one_n<false, 1>(a, grid, st);
+    if (precision == 6) return a.acts ? launch_one_n<true, 1, false, VN_BF16_H16>(a, grid, st) : launch_one_n<false, 1>(a, grid, st);
     set_error("mlp_fwd_bf16n: precision %d", precision);
     return VIPNERF_E_ARG;
 }

@@ -71,6 +71,10 @@ struct WgReduceArgs {
     const unsigned *gmax;                     // FP16X3: the partials are 2^S times the gradients (grad_scale_from_max)
 };
 
+typedef _Float16 wg_half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ floatx16 mfma16_32(wg_half8 a, wg_half8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ floatx16 mfma16_32(wg_bf8 a, wg_bf8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ floatx16 mfma32(float a, float b, floatx16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -630,14 +634,17 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16x3_256(WgArgs a) {
 // follows the first in the array's slot (P * 128 floats further), three cross terms -- the bytes of the fp32 arrays, but
 // no split and no conversion while staging: a thread gathers the 8 points of a feature from its 8 row registers with
 // v_perm and writes them as one 16-byte LDS store per plane (same [feature][4 slots of 8 points] planes and swizzle).
-template <bool HAS_W, int PARTS>
+// BF: the 16-bit values are bf16 (VIPNERF_PREC_BF16, v_mfma_f32_32x32x16_bf16) instead of fp16 -- same bytes, same staging.
+template <bool HAS_W, int PARTS, bool BF = false>
 __device__ __forceinline__ void wgrad_h16_256_body(const WgArgs &a) {
     constexpr int MTW = 2, KTW = 8, Mp = 256, Kp = 256;
     constexpr int PLANE = 256 * 64;                       // bytes: one operand, one part, 256 features x 32 points x 2 B
     constexpr int BUF = 2 * PARTS * PLANE;                // A parts, then B parts
     extern __shared__ __attribute__((aligned(16))) float lds[];
     char *lb = (char *)lds;
-    typedef _Float16 half8_ __attribute__((ext_vector_type(8)));
+    static_assert(!BF || PARTS == 1, "bf16 storage is high parts only");
+    typedef typename std::conditional<BF, __bf16, _Float16>::type el16;
+    typedef el16 half8_ __attribute__((ext_vector_type(8)));
 
     const WgDesc &d = a.d[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -675,6 +682,7 @@ __device__ __forceinline__ void wgrad_h16_256_body(const WgArgs &a) {
     auto half_of = [](const uint2 &u, int c) -> float {   // feature c (0..3) of a row's 8 bytes
         const unsigned w = c < 2 ? u.x : u.y;
         const unsigned short bits = (unsigned short)((c & 1) ? (w >> 16) : (w & 0xffffu));
+        if (BF) return __uint_as_float((unsigned)bits << 16);
         return (float)__builtin_bit_cast(_Float16, bits);
     };
     // the 8 points of feature c: dword k packs rows 2k (low half) and 2k + 1 (high half)
@@ -744,10 +752,10 @@ __device__ __forceinline__ void wgrad_h16_256_body(const WgArgs &a) {
                 for (int j = 0; j < KTW; ++j) {
                     floatx16 c = acc[i][j];
                     if (PARTS == 2) {
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][PARTS - 1], bf[j][0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][PARTS - 1], c, 0, 0, 0);
+                        c = mfma16_32(af[i][PARTS - 1], bf[j][0], c);
+                        c = mfma16_32(af[i][0], bf[j][PARTS - 1], c);
                     }
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][0], c, 0, 0, 0);
+                    c = mfma16_32(af[i][0], bf[j][0], c);
                     acc[i][j] = c;
                 }
         }
@@ -1187,11 +1195,11 @@ __global__ __launch_bounds__(256) void k_wgrad_split16_256(WgArgs a) {
 #endif
 }
 
-template <int PARTS>
+template <int PARTS, bool BF = false>
 __global__ __launch_bounds__(256) void k_wgrad_h16_256(WgArgs a) {
     if ((int)blockIdx.x >= a.d[blockIdx.y].n_chunks) return;
-    if (a.d[blockIdx.y].wcol) wgrad_h16_256_body<true, PARTS>(a);
-    else wgrad_h16_256_body<false, PARTS>(a);
+    if (a.d[blockIdx.y].wcol) wgrad_h16_256_body<true, PARTS, BF>(a);
+    else wgrad_h16_256_body<false, PARTS, BF>(a);
 }
 
 // Ordered sum over chunks.  A workgroup of 256 threads handles 64 consecutive output elements: thread (e, q) sums
@@ -1269,8 +1277,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
               chunk_single = chunk_pts / WGRAD_SINGLE_SPLIT;
     float *partial = bwd + bl.partial;
     // storage of the 256x256 class's operands: 0 = fp32, 1 = fp16 high parts (FP16X3H), 2 = fp16 hi + lo planes (FP16X3)
-    const int halves = (precision == VIPNERF_PREC_FP16X3H || precision == VIPNERF_PREC_FP16) ? 1
-                       : (precision == VIPNERF_PREC_FP16X3 && VN_F16_PRESPLIT ? 2 : 0);
+    const int halves = stores_high16(precision) ? 1 : (precision == VIPNERF_PREC_FP16X3 && VN_F16_PRESPLIT ? 2 : 0);
 
     WgArgs c88, c82, c48, c41, c18, c14;       // classes by (M tiles, K tiles)
     WgReduceArgs red;
@@ -1377,8 +1384,13 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
 #endif
         } else if (halves == 1) {                  // operands stored as fp16 high parts: single-MFMA kernel, half the bytes
             const size_t ldsb = (size_t)2 * 2 * 256 * 64;
-            VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_h16_256<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-            hipLaunchKernelGGL(k_wgrad_h16_256<1>, dim3(n_chunks, n88), dim3(256), ldsb, st, c88);
+            if (precision == VIPNERF_PREC_BF16) {
+                VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_h16_256<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+                hipLaunchKernelGGL((k_wgrad_h16_256<1, true>), dim3(n_chunks, n88), dim3(256), ldsb, st, c88);
+            } else {
+                VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_h16_256<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+                hipLaunchKernelGGL(k_wgrad_h16_256<1>, dim3(n_chunks, n88), dim3(256), ldsb, st, c88);
+            }
             VN_HIP(hipGetLastError());
         } else if (halves == 2) {                  // operands stored pre-split (hi and lo fp16 planes): 3 fp16 cross terms
             const size_t ldsb = (size_t)2 * 4 * 256 * 64;

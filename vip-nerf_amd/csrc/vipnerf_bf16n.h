@@ -254,7 +254,18 @@ __device__ __forceinline__ floatx4 load_tile16(const float *base, int64_t p, int
 #define VN_BF16_H16 1
 #endif
 // precisions whose 256-wide trunk activations / gradients are stored as 16-bit high parts only ([P][256] halves in the fp32 slot)
+// VN_T16 (default): in the single-MFMA modes EVERY operand of the weight-gradient GEMMs -- h_1..h_8, the feature, the view hidden per
+// direction, gamma(x), gamma(dir), dY_0..dY_7, dY_feature, dYv per direction, their sum, the head seeds -- is stored as 16-bit values in
+// the tile-blocked layout T16 (store_t16 below), which the weight-gradient kernels DMA straight into LDS and read with the hardware
+// transpose (vipnerf_wgrad16.hip); 0 = round 2's storage (row-major [P][256] halves for the 256x256 GEMMs, fp32 for everything else).
+#ifndef VN_T16
+#define VN_T16 1
+#endif
+__host__ __device__ inline bool stores_t16(int precision) {
+    return VN_T16 && (precision == VIPNERF_PREC_FP16 || (precision == VIPNERF_PREC_BF16 && VN_BF16_H16));
+}
 __host__ __device__ inline bool stores_high16(int precision) {
+    if (stores_t16(precision)) return false;
     return precision == VIPNERF_PREC_FP16X3H || precision == VIPNERF_PREC_FP16 || (precision == VIPNERF_PREC_BF16 && VN_BF16_H16);
 }
 // FP16X3H: the fp16 high parts of a B fragment (k-step s <- tiles 2s, 2s+1) ARE the fp16 image of those two tiles:
@@ -298,6 +309,23 @@ __device__ __forceinline__ void store_pair_f32(float *base, int64_t p, int ld, i
 __device__ __forceinline__ void store_pair_f32(float *, int64_t, int, int, int, const bf16x8 &, const bf16x8 &) {}
 __device__ __forceinline__ void store_pair_f32(float *, int64_t, int, int, int, const half8 &, const half8 &) {}
 
+// T16 (H16 == 4): an array of `tiles` 16-feature tiles is [P / 16 groups][tiles][16 points][16 features] of 16-bit values -- every
+// (group, tile) a dense row-major 16 x 16 matrix of 512 bytes.  A wave's 16 points are one group; the part-0 B fragment of k-step s
+// (elements 0..3 = features 4q..4q+3 of tile 2s, 4..7 = the same of tile 2s + 1, for point j) is two 8-byte stores per lane, and each
+// store instruction of the wave writes one whole tile = 512 contiguous bytes (no partially written lines).  The weight-gradient
+// kernels copy 32-point blocks of these arrays into LDS by DMA and read their MFMA fragments (lane = feature, 4 consecutive points)
+// with ds_read_b64_tr_b16.  Wave-uniformly predicated by the caller (P is a multiple of 16 in the render path).
+template <typename FR>
+__device__ __forceinline__ void store_t16(float *base, int64_t grp, int tiles, int s, int j, int q, const FR &v) {
+    static_assert(sizeof(FR) == 16, "a 16-byte fragment part");
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u4 w = __builtin_bit_cast(u4, v);
+    char *t0 = (char *)base + ((size_t)grp * tiles + 2 * s) * 512 + j * 32 + q * 8;
+    const u2 lo = {w[0], w[1]}, hi = {w[2], w[3]};
+    __builtin_nontemporal_store(lo, (u2 *)t0);
+    __builtin_nontemporal_store(hi, (u2 *)(t0 + 512));
+}
 // two C/D tiles (2s, 2s+1) -> the NS-part B fragment of k-step s
 template <int NS, typename FR>
 __device__ __forceinline__ void split_pair(const floatx4 &lo, const floatx4 &hi, FR (&out)[NS]) {
@@ -318,11 +346,19 @@ template <int H16, int NS, typename FR, int NSTEP = 2>
 struct DeferredStores {
     float *dst; int64_t p; int q, wave, s0;
     const FR (*bin)[NS];
-    // the 8-byte stores of the high-parts-only storage (H16 = 1) measured better all together behind the last group
-    template <int g, int NG> static constexpr bool active() { return H16 == 1 ? g == NG - 1 : (g == VN_STORE_GROUP_A || g == VN_STORE_GROUP_B); }
+    int64_t grp; int j; bool valid;         // H16 == 4 (T16): the wave's 16-point group, the lane's point in it, group in range
+    // the 8-byte stores of the high-parts-only storage (H16 = 1, 4) measured better all together behind the last group
+    template <int g, int NG> static constexpr bool active() { return (H16 == 1 || H16 == 4) ? g == NG - 1 : (g == VN_STORE_GROUP_A || g == VN_STORE_GROUP_B); }
     template <int g, int NG>
     __device__ __forceinline__ void at() const {
         if (EXP_NO_STORES) return;
+        if (H16 == 4) {
+            if (valid) {
+#pragma unroll
+                for (int s = s0; s < s0 + NSTEP; ++s) store_t16(dst, grp, 16, s, j, q, bin[s][0]);
+            }
+            return;
+        }
         if (H16 == 1 || (g == VN_STORE_GROUP_A) == (wave < 4)) {
 #pragma unroll
             for (int s = s0; s < s0 + NSTEP; ++s) {

@@ -58,6 +58,11 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
     typedef typename FragOf<F16, F32>::type FR;
     constexpr float AU = F16 ? 1.f / F16_WSCALE : 1.f;
     constexpr bool DEFER = H16 != 0 && VN_DEFER_STORES;    // fp16-stored gradients leave from the next GEMM's stages (vipnerf_bf16n.h)
+    // H16 == 4 (VN_T16): every gradient the weight-gradient GEMMs read is stored as 16-bit T16 (store_t16) -- dY_0..dY_7, dY_feature, dYv per
+    // direction and their sum, the head seeds as one 16-column tile per direction -- and the view hidden's ReLU comes from the 32 bits per
+    // lane the forward left (no fp32 copy of dY_5, no read of the view hidden)
+    constexpr bool T16 = H16 == 4;
+    static_assert(!T16 || NS == 1, "T16 storage: single-MFMA modes");
     constexpr int S_PER_STAGE = 8 / PL::ST_256;
     const float gs = (F16 && a.gmax) ? grad_scale_from_max(*a.gmax) : 1.f;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -70,6 +75,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
     const int64_t p_raw = (int64_t)blockIdx.x * MLP_PTS_PER_WG + wave * 16 + j;
     const bool valid = p_raw < a.src.P;
     const int64_t p = valid ? p_raw : a.src.P - 1;
+    const int64_t grp = (int64_t)blockIdx.x * (MLP_PTS_PER_WG / 16) + wave;   // T16: the wave's 16-point group (valid is wave-uniform)
     const int V = a.src.V;
 
     typename StreamOf<PL, PL::SKEW>::type ws;
@@ -107,14 +113,28 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
             dq[0] = dq[1] = dq[2] = 0.f;
             dq[3] = gb[a.bl.dvis2 + p * V + (dsel - 1)] * gs * ((1.f - y) * y);
         }
-        if (valid && q == 0) {
+        if (T16) {
+            if (valid) {     // head seeds as a 16-column T16 tile: columns 0..3 d(pre-sigmoid rgb, vis), column 4 d(sigma_raw) (direction 0), zeros
+                const float x8[8] = {dq[0], dq[1], dq[2], dq[3], dsel == 0 ? dsig_raw : 0.f, 0.f, 0.f, 0.f};
+                FR t8[NS];
+                split8<NS>(x8, t8);
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                const u4 w = __builtin_bit_cast(u4, t8[0]);
+                const u2 mine = {q == 0 ? w[0] : (q == 1 ? w[2] : 0u), q == 0 ? w[1] : (q == 1 ? w[3] : 0u)};
+                __builtin_nontemporal_store(mine, (u2 *)((char *)(a.bwd + a.bl.dq[dsel]) + (size_t)grp * 512 + j * 32 + q * 8));
+            }
+        } else if (valid && q == 0) {
             float *row = a.bwd + a.bl.dq[dsel] + (size_t)p * 8;
             *(float4 *)row = make_float4(dq[0], dq[1], dq[2], dq[3]);
             *(float4 *)(row + 4) = make_float4(dsel == 0 ? dsig_raw : 0.f, 0.f, 0.f, 0.f);
         }
+        const unsigned gmask = T16 ? ((const unsigned *)(a.acts + a.al.g[dsel] + (size_t)a.src.P * (WV / 2)))[(size_t)p * 4 + q] : 0u;
+        floatx4 dprev = (floatx4)(0.f);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            const floatx4 g = load_tile16(a.acts + a.al.g[dsel], p, WV, q, t);
+            floatx4 g = (floatx4)(0.f);
+            if (!T16) g = load_tile16(a.acts + a.al.g[dsel], p, WV, q, t);
             float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -123,22 +143,36 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
                 dg.z = fmaf(w4.z, dq[c], dg.z); dg.w = fmaf(w4.w, dq[c], dg.w);
             }
             floatx4 d;
+            if (T16) {
+                d[0] = mask_apply16(dg.x, gmask, 0u, t, 0); d[1] = mask_apply16(dg.y, gmask, 0u, t, 1);
+                d[2] = mask_apply16(dg.z, gmask, 0u, t, 2); d[3] = mask_apply16(dg.w, gmask, 0u, t, 3);
+                if (t & 1) {
+                    FR dh[NS];
+                    split_pair<NS>(dprev, d, dh);
+                    if (valid && !EXP_NO_EXTRAS) store_t16(a.bwd + a.bl.dyv[dsel], grp, 8, t >> 1, j, q, dh[0]);
+                }
+                dprev = d;
+            } else {
             d[0] = g[0] > 0.f ? dg.x : 0.f;
             d[1] = g[1] > 0.f ? dg.y : 0.f;
             d[2] = g[2] > 0.f ? dg.z : 0.f;
             d[3] = g[3] > 0.f ? dg.w : 0.f;
             if (!EXP_NO_EXTRAS) store_tile16(a.bwd + a.bl.dyv[dsel], p, WV, q, t, d);
+            }
             vsum[t] += d;
         }
     }
 #pragma unroll
-    for (int t = 0; t < 8; ++t) if (!EXP_NO_EXTRAS) store_tile16(a.bwd + a.bl.dyvsum, p, WV, q, t, vsum[t]);
+    for (int t = 0; t < 8; ++t) if (!EXP_NO_EXTRAS && !T16) store_tile16(a.bwd + a.bl.dyvsum, p, WV, q, t, vsum[t]);
 
     // ---------------------------------------------------------------- d(feature) = W_vf^T sum_a dYv_a   (K = 128: 4 k-steps)
     FR bin[8][NS];
     floatx4 acc[16];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) split_pair<NS>(vsum[2 * s], vsum[2 * s + 1], bin[s]);
+    for (int s = 0; s < 4; ++s) {
+        split_pair<NS>(vsum[2 * s], vsum[2 * s + 1], bin[s]);
+        if (T16 && valid && !EXP_NO_EXTRAS) store_t16(a.bwd + a.bl.dyvsum, grp, 8, s, j, q, bin[s][0]);
+    }
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[t] = (floatx4)(0.f);
     stream_begin(ws);
@@ -159,6 +193,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
         if (!DEFER && H16 == 1) store_pair16h(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0]);
         if (!DEFER && H16 == 2) store_pair_split(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0], bin[s][NS > 1 ? 1 : 0]);
         if (!DEFER && H16 == 3) store_pair_f32(a.bwd + a.bl.dyf, p, W, q, s, bin[s][0], bin[s][NS > 1 ? 1 : 0]);
+        if (!DEFER && T16 && valid) store_t16(a.bwd + a.bl.dyf, grp, 16, s, j, q, bin[s][0]);
     }
 
     // ---------------------------------------------------------------- feature layer, then layers 7..1
@@ -180,7 +215,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
             const float *st = jj == 0 ? ws.template wait<DEFER ? 2 * S_PER_STAGE : 16, DEFER ? 0 : 16>(it == 0)
                                       : ws.template wait<DEFER ? 2 * S_PER_STAGE : 0>();
             if (DEFER) {                                 // bin = the fp16 parts of the gradient this GEMM consumes
-                DeferredStores<H16, NS, FR, S_PER_STAGE> ds{a.bwd + (it == 0 ? a.bl.dyf : a.bl.dy[layer + 1]), p, q, wave, S_PER_STAGE * jj, bin};
+                DeferredStores<H16, NS, FR, S_PER_STAGE> ds{a.bwd + (it == 0 ? a.bl.dyf : a.bl.dy[layer + 1]), p, q, wave, S_PER_STAGE * jj, bin, grp, j, valid};
                 gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws, ds);
             } else {
                 gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
@@ -202,11 +237,12 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[u][r] = mask_apply16(x[u][r], mk.x, mk.y, t, r);
 #endif
-                if ((!H16 || it == 7) && !((H16 && it == 7) ? EXP_NO_EXTRAS : EXP_NO_STORES)) store_tile16(dst, p, W, q, t, x[u]);
+                if ((!H16 || it == 7) && !T16 && !((H16 && it == 7) ? EXP_NO_EXTRAS : EXP_NO_STORES)) store_tile16(dst, p, W, q, t, x[u]);
                 if (H16 == 1 && layer == SKIP_LAYER && !EXP_NO_EXTRAS) store_tile16(a.bwd + a.bl.dy5f, p, W, q, t, x[u]);   // pre-split storage keeps both parts: no copy
             }
-            if (it < 7) {
+            if (it < 7 || T16) {
                 split_pair<NS>(x[0], x[1], bin[s]);
+                if (T16 && (it == 7 || !DEFER) && valid && !EXP_NO_EXTRAS) store_t16(dst, grp, 16, s, j, q, bin[s][0]);   // dY_0 (the others: deferred)
                 if (!DEFER && H16 == 1) store_pair16h(dst, p, W, q, s, bin[s][0]);
                 if (!DEFER && H16 == 2) store_pair_split(dst, p, W, q, s, bin[s][0], bin[s][NS > 1 ? 1 : 0]);
                 if (!DEFER && H16 == 3) store_pair_f32(dst, p, W, q, s, bin[s][0], bin[s][NS > 1 ? 1 : 0]);
@@ -231,7 +267,7 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
     if (precision == 0) return launch_one_bwd_n<2, false, VN_F32_DEFER ? 3 : 0, true>(a, grid, st);
     if (precision == 1) return launch_one_bwd_n<2>(a, grid, st);
     if (precision == 2) return launch_one_bwd_n<3>(a, grid, st);
-    if (precision == 6) return launch_one_bwd_n<1, false, VN_BF16_H16>(a, grid, st);
+    if (precision == 6) return launch_one_bwd_n<1, false, VN_BF16_H16 ? (VN_T16 ? 4 : 1) : 0>(a, grid, st);
     if (precision == 3 || precision == 4 || precision == 5) {
         // the level's largest seed first (one pass over 5+V floats per point)
         unsigned *slot = (unsigned *)(a.bwd + a.bl.gmax);
@@ -241,7 +277,7 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
         VN_HIP(hipGetLastError());
         MlpBwdArgs b = a;
         b.gmax = slot;
-        if (precision == 5) return launch_one_bwd_n<1, true, 1>(b, grid, st);
+        if (precision == 5) return launch_one_bwd_n<1, true, VN_T16 ? 4 : 1>(b, grid, st);
         return precision == 4 ? launch_one_bwd_n<2, true, 1>(b, grid, st) : launch_one_bwd_n<2, true, VN_F16_PRESPLIT ? 2 : 0>(b, grid, st);
     }
     set_error("mlp_bwd_bf16n: precision %d", precision);

@@ -78,12 +78,16 @@ __device__ __forceinline__ void store_d16(float *row, int q, const float (&pd)[1
 // 1 = fp16 high parts only (FP16X3H); 2 = both fp16 parts in the 16 bytes a lane owns per tile (FP16X3, store_pair_split:
 // the same bytes as fp32, but already split).  With H16 != 0 the stores of a layer's output leave from the NEXT layer's
 // weight stages (DEFER; the stored form is that layer's B operand).  Everything else stays fp32.
+// H16 == 4 (single-MFMA modes, VN_T16): every stored operand is 16-bit in the tile-blocked layout T16 (vipnerf_bf16n.h: store_t16) --
+// h_1..h_8, the feature, the view hidden and its ReLU bits per direction, gamma(x) / gamma(dir) in their slot order -- written from the
+// B fragments the GEMMs consume anyway.
 // F32: exact-fp32 fragments (f32q, vipnerf_bf16.h): v_mfma_f32_16x16x4_f32, one MFMA per product, no split, no scaling.
 template <bool SAVE, int NS, bool F16, int H16 = 0, bool F32 = false>
 __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) {
     typedef BnPlan<NS> PL;
     typedef typename FragOf<F16, F32>::type FR;
-    static_assert(!(F16 && F32) && (!F32 || (NS == 2 && (H16 == 0 || H16 == 3))) && (F32 || H16 != 3), "arithmetic");
+    static_assert(!(F16 && F32) && (!F32 || (NS == 2 && (H16 == 0 || H16 == 3))) && (F32 || H16 != 3) && (H16 != 4 || NS == 1), "arithmetic");
+    constexpr bool T16 = SAVE && H16 == 4;
     constexpr float XS = F16 ? F16_XSCALE : 1.f;           // B operands are split as XS * x
     constexpr float AU = F16 ? F16_ACC_UNSCALE : 1.f;
     constexpr bool DEFER = SAVE && H16 != 0 && VN_DEFER_STORES;   // h_1..h_8 leave from the next layer's stages (vipnerf_bf16n.h)
@@ -99,6 +103,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
     const int64_t p_raw = (int64_t)blockIdx.x * MLP_PTS_PER_WG + wave * 16 + j;
     const bool valid = p_raw < a.src.P;
     const int64_t p = valid ? p_raw : a.src.P - 1;
+    const int64_t grp = (int64_t)blockIdx.x * (MLP_PTS_PER_WG / 16) + wave;   // T16: this wave's 16-point group (valid is wave-uniform: P % 16 == 0)
 
     typename std::conditional<F32 && !SAVE, typename StreamShared<PL>::type, typename StreamOf<PL, PL::SKEW>::type>::type ws;
     ws.start(a.packed + PL::PK_FWD, PL::F_STAGES, stage_buf, lane, wave);
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
         load_point(a.src, p, pc0);           // than kept in 13 registers across the trunk
         encode_x16(pc0.x, q, pe);
     }
-    if (SAVE && valid && !EXP_NO_PE) store_x16(a.acts + a.al.pex + (size_t)p * DPE_PAD, q, pe);
+    if (SAVE && !T16 && valid && !EXP_NO_PE) store_x16(a.acts + a.al.pex + (size_t)p * DPE_PAD, q, pe);
     if (F16) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
                 // the mask store when the tiles are deferred); later stages: the deferred stores behind the stage before
                 const float *st = jj == 0 ? ws.template wait<DEFER ? 1 : EPI_STORES>() : ws.template wait<DEFER ? 2 * S_PER_STAGE : 0>();
                 if (DEFER) {                             // bin = the fp16 parts of h_layer, the output of layer - 1
-                    DeferredStores<H16, NS, FR, S_PER_STAGE> ds{a.acts + a.al.h[layer - 1], p, q, wave, S_PER_STAGE * jj, bin};
+                    DeferredStores<H16, NS, FR, S_PER_STAGE> ds{a.acts + a.al.h[layer - 1], p, q, wave, S_PER_STAGE * jj, bin, grp, j, valid};
                     gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws, ds);
                 } else {
                     gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
@@ -156,6 +161,12 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             FR bpe[PL::PE_KS][NS];
 #pragma unroll
             for (int s = 0; s < 2; ++s) split8<NS>(pe[s], bpe[s]);
+            if (T16 && layer == 0 && valid && !EXP_NO_PE) {   // gamma(x), slot order: column 16 q + u of a 64-wide T16 array = tile q
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                char *row = (char *)(a.acts + a.al.pex) + ((size_t)grp * 4 + q) * 512 + j * 32;
+                __builtin_nontemporal_store(__builtin_bit_cast(u4, bpe[0][0]), (u4 *)row);
+                __builtin_nontemporal_store(__builtin_bit_cast(u4, bpe[1][0]), (u4 *)(row + 16));
+            }
 #pragma unroll
             for (int s = 2; s < PL::PE_KS; ++s) {            // padding k-steps of the single-MFMA plan (zero weight columns)
                 const float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -198,7 +209,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[u][r] = relu_lo<F16 || (F32 && SAVE)>(x[u][r] * AU, lo);   // (+0 | positive | NaN for the bit masks)
                 if (SAVE) {
-                    if (!(H16 && layer < 8) && !(layer < 8 ? EXP_NO_STORES : EXP_NO_EXTRAS)) store_tile16(dst, p, W, q, t, x[u]);
+                    if (!(H16 && layer < 8) && !T16 && !(layer < 8 ? EXP_NO_STORES : EXP_NO_EXTRAS)) store_tile16(dst, p, W, q, t, x[u]);
                     if (F16 || F32) {
                         if (t < 8) mk0 = push_nibble(mk0, positive_nibble(x[u])); else mk1 = push_nibble(mk1, positive_nibble(x[u]));
                     } else {
@@ -217,6 +228,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             if (SAVE && !DEFER && H16 == 1 && layer < 8) store_pair16h(dst, p, W, q, s, bin[s][0]);
             if (SAVE && !DEFER && H16 == 2 && layer < 8) store_pair_split(dst, p, W, q, s, bin[s][0], bin[s][NS > 1 ? 1 : 0]);
             if (SAVE && !DEFER && H16 == 3 && layer < 8) store_pair_f32(dst, p, W, q, s, bin[s][0], bin[s][NS > 1 ? 1 : 0]);
+            if (T16 && (layer == 8 || !DEFER) && valid && !EXP_NO_EXTRAS) store_t16(dst, grp, 16, s, j, q, bin[s][0]);   // the feature (h_1..h_8: deferred)
         }
         if (SAVE && layer < 8 && !EXP_NO_STORES) *(uint2 *)(a.acts + a.al.hm[layer] + ((size_t)p * 4 + q) * 2) = make_uint2(mk0, mk1);
     }
@@ -269,8 +281,28 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) g[t][r] = relu_lo<F16>(g[t][r] * AU, 0.f);
-        if (SAVE) {
+            for (int r = 0; r < 4; ++r) g[t][r] = relu_lo<F16 || T16>(g[t][r] * AU, 0.f);     // (+0 | positive | NaN for the T16 ReLU bits)
+        if (T16) {
+            if (valid && !EXP_NO_EXTRAS) {
+                // view hidden as 16-bit T16 (8 tiles) + its 32 ReLU bits per lane (bit 4 t + r), which is all the data-gradient
+                // kernel needs of it: [P][4] words behind the T16 array in the same slot
+                unsigned gm = 0u;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    FR gh[NS];
+                    split_pair<NS>(g[2 * s], g[2 * s + 1], gh);
+                    store_t16(a.acts + a.al.g[dsel], grp, 8, s, j, q, gh[0]);
+                    gm = push_nibble(gm, positive_nibble(g[2 * s]));
+                    gm = push_nibble(gm, positive_nibble(g[2 * s + 1]));
+                }
+                ((unsigned *)(a.acts + a.al.g[dsel] + (size_t)a.src.P * (WV / 2)))[(size_t)p * 4 + q] = gm;
+            }
+            if (valid && !EXP_NO_PE) {     // gamma(dir), slot order: column 8 q + e of a 32-wide T16 array
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                char *row = (char *)(a.acts + a.al.ped[dsel]) + ((size_t)grp * 2 + (q >> 1)) * 512 + j * 32 + (q & 1) * 16;
+                __builtin_nontemporal_store(__builtin_bit_cast(u4, bpd[0][0]), (u4 *)row);
+            }
+        } else if (SAVE) {
             if (!EXP_NO_EXTRAS) {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) store_tile16(a.acts + a.al.g[dsel], p, WV, q, t, g[t]);
@@ -324,8 +356,11 @@ int launch_mlp_fwd_bf16n(const MlpFwdArgs &a, int precision, hipStream_t st) {
     if (precision == 2) return a.acts ? launch_one_n<true, 3>(a, grid, st) : launch_one_n<false, 3>(a, grid, st);
     if (precision == 3) return a.acts ? launch_one_n<true, 2, true, VN_F16_PRESPLIT ? 2 : 0>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);
     if (precision == 4) return a.acts ? launch_one_n<true, 2, true, 1>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);
-    if (precision == 5) return a.acts ? launch_one_n<true, 1, true, 1>(a, grid, st) : launch_one_n<false, 1, true>(a, grid, st);
-    if (precision == 6) return a.acts ? launch_one_n<true, 1, false, VN_BF16_H16>(a, grid, st) : launch_one_n<false, 1>(a, grid, st);
+    constexpr int H5 = VN_T16 ? 4 : 1, H6 = VN_BF16_H16 ? (VN_T16 ? 4 : 1) : 0;
+    if ((precision == 5 || precision == 6) && a.acts && stores_t16(precision) && a.src.P % 16) {
+        set_error("mlp_fwd: the 16-bit training kernels need a multiple of 16 points (got %lld)", (long long)a.src.P); return VIPNERF_E_UNSUPPORTED; }
+    if (precision == 5) return a.acts ? launch_one_n<true, 1, true, H5>(a, grid, st) : launch_one_n<false, 1, true>(a, grid, st);
+    if (precision == 6) return a.acts ? launch_one_n<true, 1, false, H6>(a, grid, st) : launch_one_n<false, 1>(a, grid, st);
     set_error("mlp_fwd_bf16n: precision %d", precision);
     return VIPNERF_E_ARG;
 }

@@ -32,45 +32,6 @@ __device__ __forceinline__ int wg_off(int f, int slot) {
 #ifndef VN_WGRAD_W8
 #define VN_WGRAD_W8 2            // exact-fp32 256 x 256 weight gradients: 0 = the 4-wave k_wgrad<2,8,4>; 2 / 4 = k_wgrad256_w8 with 8 / 16 waves
 #endif
-struct WgDesc {
-    const float *A; int lda; int m_load;      // A[p][0..m_load) is read (m_load multiple of 4), zero beyond
-    const float *B; int ldb; int k_load;
-    size_t part_off;                          // float offset of this GEMM's partials (chunk 0)
-    int n_chunks;                             // chunks of this GEMM (workgroups beyond it exit)
-    size_t part_stride;                       // floats per chunk: Mp*Kp + Mp (+ WCOL_EXTRA with wcol)
-    // 256x256 split-precision kernel only: a per-point weight column w[p] = wcol[p * wcol_stride].  The workgroup also
-    // accumulates sum_p w[p] * B[p][0..256) and sum_p w[p] into its partial (after the bias sums) -- the weight and
-    // bias gradient of a 1-output head fed by B (the sigma head reads the same h_8 as the feature layer's GEMM)
-    const float *wcol; int wcol_stride;
-    // k_wgrad_bf16x3 only: A is stored pre-split (store_pair_split: the 16 bytes of 4 features hold [hi f0 f1][hi f2 f3]
-    // [lo f0 f1][lo f2 f3] as fp16) instead of 4 floats -- layer 5's gradient, which the 256x256 GEMM reads in that form
-    int a_split16;
-};
-constexpr int WCOL_EXTRA = 256 + 64;          // 256 weighted column sums, the weight sum, pad
-constexpr int WG_MAX_DESC = 12;
-struct WgArgs {
-    WgDesc d[WG_MAX_DESC];
-    int64_t P;
-    int chunk_pts;
-    float *partial;
-};
-
-// output groups for the ordered reduction
-struct WgGroup {
-    size_t part_off, part_stride;             // of the group's first GEMM
-    int n_desc;                               // GEMMs summed into this output (consecutive, same shape)
-    size_t desc_stride;                       // float distance between consecutive GEMMs' partial blocks
-    int Mp, Kp, m_valid, k_valid, n_chunks;
-    float *dW; int ldw; int col_off;
-    float *dbias;                             // NULL = no bias output
-};
-constexpr int WG_MAX_GROUP = 24;
-struct WgReduceArgs {
-    WgGroup g[WG_MAX_GROUP];
-    const float *partial;
-    const unsigned *gmax;                     // FP16X3: the partials are 2^S times the gradients (grad_scale_from_max)
-};
-
 typedef _Float16 wg_half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wg_bf8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ floatx16 mfma16_32(wg_half8 a, wg_half8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
@@ -1221,13 +1182,14 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgReduceArgs a) {
             if (e < n_w) {
                 const int m = e / g.k_valid, k = e % g.k_valid;
                 off = (size_t)m * g.Kp + k;
-                dst = g.dW + (size_t)m * g.ldw + g.col_off + k;
+                const int kn = wg_colperm(g.colperm, k);         // slot-ordered columns (gamma(x) / gamma(dir) in T16) -> feature
+                dst = kn >= 0 ? g.dW + (size_t)m * g.ldw + g.col_off + kn : nullptr;
             } else {
                 const int m = e - n_w;
-                off = (size_t)g.Mp * g.Kp + m;
+                off = g.bias_off + m;
                 dst = g.dbias + m;
             }
-            for (int dd = 0; dd < g.n_desc; ++dd) {
+            for (int dd = 0; dd < (dst ? g.n_desc : 0); ++dd) {
                 const float *pp = a.partial + g.part_off + (size_t)dd * g.desc_stride + off;
                 // eight loads in flight per thread (the sum is latency-bound otherwise); fixed order -> deterministic
                 float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -1252,7 +1214,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgReduceArgs a) {
         }
         sh[q][el] = s;
         __syncthreads();
-        if (q == 0 && e < n_all) *dst = ((sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el])) * unscale;
+        if (q == 0 && e < n_all && dst) *dst = ((sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el])) * unscale;
         __syncthreads();
     }
 }
@@ -1271,6 +1233,7 @@ static int launch_class(const WgArgs &args, int n_desc, int n_chunks, hipStream_
 int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float *bwd, const BwdLayout &bl,
                  const vipnerf_mlp_grads *G, int precision, hipStream_t st, const unsigned *gmax) {
     if (P == 0) return VIPNERF_OK;
+    if (stores_t16(precision)) return launch_wgrad16(P, V, acts, al, bwd, bl, G, precision, st, gmax);
     const int n_chunks = wgrad_chunks(P), n_pe = wgrad_chunks_split(P, WGRAD_SPLIT_PE), n_thin = wgrad_chunks_split(P, WGRAD_SPLIT_THIN),
               n_single = wgrad_chunks_split(P, WGRAD_SINGLE_SPLIT);
     const int chunk_pts = wgrad_chunk_pts(P), chunk_pe = chunk_pts / WGRAD_SPLIT_PE, chunk_thin = chunk_pts / WGRAD_SPLIT_THIN,
@@ -1305,6 +1268,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
         g.n_chunks = chunks;
         g.desc_stride = (size_t)g.n_chunks * g.part_stride;
         g.Mp = Mp; g.Kp = Kp; g.m_valid = m_valid; g.k_valid = k_valid; g.dW = dW; g.ldw = ldw; g.col_off = col_off; g.dbias = dbias;
+        g.bias_off = (size_t)Mp * Kp; g.colperm = 0;
     };
     const float *pex = acts + al.pex;
     // trunk
@@ -1415,6 +1379,10 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
     if ((rc = launch_class<1, 1, 4>(c41, n41, n_thin, st))) return rc;
     if ((rc = launch_class<1, 2, 1>(c18, n18, n_single, st))) return rc;
     if ((rc = launch_class<1, 1, 1>(c14, n14, n_thin, st))) return rc;
+    return launch_wgrad_reduce(red, ng, st);
+}
+
+int launch_wgrad_reduce(const WgReduceArgs &red, int ng, hipStream_t st) {
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(512, ng), dim3(256), 0, st, red);
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;

@@ -1,0 +1,273 @@
+// Weight gradients of one level in the single-MFMA 16-bit modes (VIPNERF_PREC_FP16 / BF16) with T16 operand storage
+// (vipnerf_bf16n.h: store_t16): dW[M][N] = sum_p A[p][M] * B[p][N], db[M] = sum_p A[p][M]  (autograd of reference
+// src/models/VipNeRF01.py:537-596 w.r.t. the parameters).
+//
+// Every operand is a 16-bit array in the tile-blocked layout the forward / data-gradient kernels wrote:
+//     [P / 16 groups][width / 16 tiles][16 points][16 features],   one (group, tile) = a row-major 16 x 16 matrix = 512 B,
+// so the bytes of a 32-point block of an operand are contiguous in HBM.  Nothing is staged through registers:
+//   * HBM -> LDS by DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, lane-linear: the LDS image IS the HBM image), a ring of
+//     NB blocks, counted vmcnt + one raw workgroup barrier per block;
+//   * LDS -> MFMA fragments by the hardware transpose read: ds_read_b64_tr_b16 of lane l at (tile base + 8 l) returns, for feature
+//     l & 15, the points 4 (l >> 4) .. + 3 of the tile -- one read per 16-point group, two per 32-deep v_mfma_f32_16x16x32 fragment.
+//     The same read serves A and B (contraction index = point: element e < 4 of lane group q is point 4 q + e of the block's first
+//     group, e >= 4 point 4 q + e - 4 of its second), and every read instruction covers 512 contiguous bytes: no bank conflicts;
+//   * bias gradients = column sums of A, taken from the A fragments with v_dot2 (fp32 accumulate) under the MFMAs.
+// A workgroup owns one (GEMM, point chunk) pair, keeps its share of the product in accumulators and writes a partial; the ordered
+// reduction of vipnerf_wgrad.hip (k_wgrad_reduce) sums the chunks into the nn.Linear-layout gradients (deterministic, no atomics).
+// These GEMMs have 0.5 ... 64 MFMAs per KiB of operand: all of them are bound by how many bytes a CU keeps in flight, which is what
+// the DMA ring is for (3-4 blocks per workgroup, several workgroups per CU for the thin ones).
+#include "vipnerf_wgrad.h"
+#include "vipnerf_prof.h"
+
+namespace vn {
+
+// lane l: for feature (l & 15), the 4 points 4 (l >> 4) .. + 3 of the 16 x 16 tile at `tile` (LDS), 16-bit each
+__device__ __forceinline__ uint2 tr_read16(const char *tile, int lane) {
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    const s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4 *)(tile + lane * 8));
+    return __builtin_bit_cast(uint2, v);
+}
+template <typename FR>
+__device__ __forceinline__ FR frag16(const char *tile_g0, const char *tile_g1, int lane) {
+    const uint2 a = tr_read16(tile_g0, lane), b = tr_read16(tile_g1, lane);
+    const uint4 w = make_uint4(a.x, a.y, b.x, b.y);
+    return __builtin_bit_cast(FR, w);
+}
+__device__ __forceinline__ float dot_ones(const half8 &v, float s) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const uint4 w = __builtin_bit_cast(uint4, v);
+    const h2 one = {(_Float16)1.f, (_Float16)1.f};
+    s = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, w.x), one, s, false);
+    s = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, w.y), one, s, false);
+    s = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, w.z), one, s, false);
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, w.w), one, s, false);
+}
+__device__ __forceinline__ float dot_ones(const bf16x8 &v, float s) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const uint4 w = __builtin_bit_cast(uint4, v);
+    const b2 one = {(__bf16)1.f, (__bf16)1.f};
+    s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, w.x), one, s, false);
+    s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, w.y), one, s, false);
+    s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, w.z), one, s, false);
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, w.w), one, s, false);
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// M = 16 MT, N = 16 NT; WM x WN waves, wave (wm, wn) owns MT / WM x NT / WN tiles; NB 32-point blocks resident in LDS.
+template <bool BF, int MT, int NT, int WM, int WN, int NB>
+__global__ __launch_bounds__(64 * WM * WN) void k_wg16(WgArgs a) {
+    typedef typename FragOf<!BF>::type FR;
+    constexpr int NW = WM * WN, TM = MT / WM, TN = NT / WN;
+    constexpr int PIECES = MT + NT;                  // 1 KiB DMA pieces per block: the block's A bytes, then its B bytes
+    constexpr int BLK = PIECES * 1024;
+    constexpr int PW = (PIECES + NW - 1) / NW;       // pieces per wave and block: PW, or PW - 1 for the last waves
+    constexpr int MINP = PIECES / NW;                // what the waits count (conservative for the waves that issue PW)
+    static_assert(MT % WM == 0 && NT % WN == 0 && NB >= 2 && NB <= 4 && (NB - 1) * PW <= 63 && MINP >= 1, "shape");
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    char *lds = (char *)lds_f;
+
+    const WgDesc &d = a.d[blockIdx.y];
+    if ((int)blockIdx.x >= d.n_chunks) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int64_t p0 = (int64_t)blockIdx.x * a.chunk_pts;
+    const int64_t p1 = p0 + a.chunk_pts < a.P ? p0 + a.chunk_pts : a.P;
+    const int nblk = (int)((p1 - p0) / 32);          // P and the chunk sizes are multiples of 32
+    const char *gA = (const char *)d.A + (size_t)(p0 >> 4) * (MT * 512) + lane * 16;
+    const char *gB = (const char *)d.B + (size_t)(p0 >> 4) * (NT * 512) + lane * 16;
+
+    floatx4 acc[TM][TN];
+    float bsum[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        bsum[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (floatx4)(0.f);
+    }
+
+    auto issue = [&](int b, int slot) {
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int pc = wave + i * NW;
+            if (pc < PIECES) {
+                const char *src = pc < MT ? gA + ((size_t)b * MT + pc) * 1024 : gB + ((size_t)b * NT + (pc - MT)) * 1024;
+                glds_chunks<1>((const float *)src, __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds + slot * BLK + pc * 1024)));
+            }
+        }
+    };
+    int fill = 0;
+#pragma unroll
+    for (int b = 0; b < NB - 1; ++b)
+        if (b < nblk) { issue(b, fill); fill = fill + 1 == NB ? 0 : fill + 1; }
+
+    int cur = 0;
+    for (int b = 0; b < nblk; ++b) {
+        // this wave's pieces of block b have landed: at most the pieces of the y younger blocks it has issued stay outstanding
+        const int y = nblk - 1 - b < NB - 2 ? nblk - 1 - b : NB - 2;
+        __builtin_amdgcn_sched_barrier(0);
+        if (y <= 0) wait_vm<0>();
+        else if (y == 1) wait_vm<MINP>();
+        else wait_vm<2 * MINP>();
+        __builtin_amdgcn_s_barrier();                // every wave's pieces are in; every wave is done with the slot about to be refilled
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (b + NB - 1 < nblk) { issue(b + NB - 1, fill); fill = fill + 1 == NB ? 0 : fill + 1; }
+
+        const char *A = lds + cur * BLK, *B = A + MT * 1024;
+        cur = cur + 1 == NB ? 0 : cur + 1;
+        FR af[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int t = wm * TM + i;
+            af[i] = frag16<FR>(A + t * 512, A + (MT + t) * 512, lane);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int t = wn * TN + j;
+            const FR bf = frag16<FR>(B + t * 512, B + (NT + t) * 512, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] = mfma_bf(af[i], bf, acc[i][j]);
+        }
+        if (wn == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) bsum[i] = dot_ones(af[i], bsum[i]);
+        }
+    }
+
+    // partial product of this chunk: [16 MT][16 NT] row-major, then the column sums of A [16 MT]
+    constexpr int Mp = 16 * MT, Np = 16 * NT;
+    float *part = a.partial + d.part_off + (size_t)blockIdx.x * d.part_stride;
+    const int jn = lane & 15, qr = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int tm = wm * TM + i;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int tn = wn * TN + j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(size_t)(16 * tm + 4 * qr + r) * Np + 16 * tn + jn] = acc[i][j][r];
+        }
+        if (wn == 0) {
+            float s = bsum[i];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (lane < 16) part[(size_t)Mp * Np + 16 * tm + lane] = s;
+        }
+    }
+}
+
+template <bool BF, int MT, int NT, int WM, int WN, int NB>
+static int launch_wg16(const WgArgs &args, int n_desc, int n_chunks, hipStream_t st) {
+    if (n_desc == 0) return VIPNERF_OK;
+    const size_t ldsb = (size_t)NB * (MT + NT) * 1024;
+    VN_HIP(hipFuncSetAttribute((const void *)k_wg16<BF, MT, NT, WM, WN, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    hipLaunchKernelGGL((k_wg16<BF, MT, NT, WM, WN, NB>), dim3(n_chunks, n_desc), dim3(64 * WM * WN), ldsb, st, args);
+    VN_HIP(hipGetLastError());
+    return VIPNERF_OK;
+}
+
+template <bool BF>
+static int launch_all(const WgArgs &big, int nbig, int n_chunks, const WgArgs &pe, int npe, int n_pe, const WgArgs &vf, int nvf, const WgArgs &sg, int nsg,
+                      int n_single, const WgArgs &vd, int nvd, const WgArgs &oh, int noh, int n_thin, hipStream_t st) {
+    int rc;
+    {
+        ProfScope ps("wgrad_256x256", st);
+        if ((rc = launch_wg16<BF, 16, 16, 2, 4, 4>(big, nbig, n_chunks, st))) return rc;
+    }
+    ProfScope ps("wgrad_small", st);
+    if ((rc = launch_wg16<BF, 16, 4, 4, 1, 3>(pe, npe, n_pe, st))) return rc;
+    if ((rc = launch_wg16<BF, 8, 16, 2, 2, 3>(vf, nvf, n_single, st))) return rc;
+    if ((rc = launch_wg16<BF, 1, 16, 1, 4, 4>(sg, nsg, n_single, st))) return rc;
+    if ((rc = launch_wg16<BF, 8, 2, 4, 1, 4>(vd, nvd, n_thin, st))) return rc;
+    return launch_wg16<BF, 1, 8, 1, 4, 4>(oh, noh, n_thin, st);
+}
+
+int launch_wgrad16(size_t P, int V, const float *acts, const ActLayout &al, float *bwd, const BwdLayout &bl,
+                   const vipnerf_mlp_grads *G, int precision, hipStream_t st, const unsigned *gmax) {
+    if (P == 0) return VIPNERF_OK;
+    if (P % 32) { set_error("wgrad16: %zu points (a multiple of 32 is required)", P); return VIPNERF_E_UNSUPPORTED; }
+    const int n_chunks = wgrad_chunks(P), n_pe = wgrad_chunks_split(P, WGRAD_SPLIT_PE), n_thin = wgrad_chunks_split(P, WGRAD_SPLIT_THIN),
+              n_single = wgrad_chunks_split(P, WGRAD_SINGLE_SPLIT);
+    const int chunk_pts = wgrad_chunk_pts(P);
+    float *partial = bwd + bl.partial;
+
+    WgArgs big, pe, vf, sg, vd, oh;            // 256x256 x8 | 256x64 (gamma(x) columns) x2 | 128x256 | sigma head 16x256 | 128x32 per direction | 16x128 per direction
+    int nbig = 0, npe = 0, nvf = 0, nsg = 0, nvd = 0, noh = 0, ng = 0;
+    WgReduceArgs red;
+    red.partial = partial;
+    red.gmax = gmax;
+    size_t off = 0;
+    auto init = [&](WgArgs &w, int cp) { w.P = (int64_t)P; w.chunk_pts = cp; w.partial = partial; };
+    init(big, chunk_pts); init(pe, chunk_pts / WGRAD_SPLIT_PE); init(vf, chunk_pts / WGRAD_SINGLE_SPLIT); init(sg, chunk_pts / WGRAD_SINGLE_SPLIT);
+    init(vd, chunk_pts / WGRAD_SPLIT_THIN); init(oh, chunk_pts / WGRAD_SPLIT_THIN);
+    auto add = [&](WgArgs &w, int &n, int chunks, int Mp, int Np, const float *A, const float *B) {
+        WgDesc &d = w.d[n++];
+        d.A = A; d.lda = Mp; d.m_load = Mp; d.B = B; d.ldb = Np; d.k_load = Np;
+        d.wcol = nullptr; d.wcol_stride = 0; d.a_split16 = 0;
+        d.part_off = off; d.part_stride = (size_t)Mp * Np + Mp; d.n_chunks = chunks;
+        const size_t o = off;
+        off += (size_t)chunks * d.part_stride;
+        return o;
+    };
+    auto group = [&](int chunks, size_t part_off, int n_desc, int Mp, int Np, int m_valid, int k_valid, float *dW, int ldw, int col_off, float *dbias,
+                     int colperm = 0) -> WgGroup & {
+        WgGroup &g = red.g[ng++];
+        g.part_off = part_off; g.part_stride = (size_t)Mp * Np + Mp; g.n_desc = n_desc; g.n_chunks = chunks;
+        g.desc_stride = (size_t)chunks * g.part_stride;
+        g.Mp = Mp; g.Kp = Np; g.m_valid = m_valid; g.k_valid = k_valid; g.dW = dW; g.ldw = ldw; g.col_off = col_off; g.dbias = dbias;
+        g.bias_off = (size_t)Mp * Np; g.colperm = colperm;
+        return g;
+    };
+    const float *pex = acts + al.pex;
+    for (int i = 0; i < D; ++i) {
+        const float *dy = bwd + bl.dy[i];
+        float *dW = G->g[2 * i], *db = G->g[2 * i + 1];
+        if (i == 0) {
+            const size_t o = add(pe, npe, n_pe, 256, 64, dy, pex);
+            group(n_pe, o, 1, 256, 64, W, 64, dW, DPE, 0, db, 1);
+        } else if (i == SKIP_LAYER) {
+            const size_t o1 = add(pe, npe, n_pe, 256, 64, dy, pex);
+            group(n_pe, o1, 1, 256, 64, W, 64, dW, W + DPE, 0, nullptr, 1);
+            const size_t o2 = add(big, nbig, n_chunks, 256, 256, dy, acts + al.h[i - 1]);
+            group(n_chunks, o2, 1, 256, 256, W, W, dW, W + DPE, DPE, db);
+        } else {
+            const size_t o = add(big, nbig, n_chunks, 256, 256, dy, acts + al.h[i - 1]);
+            group(n_chunks, o, 1, 256, 256, W, W, dW, W, 0, db);
+        }
+    }
+    {   // feature_linear
+        const size_t o = add(big, nbig, n_chunks, 256, 256, bwd + bl.dyf, acts + al.h[D - 1]);
+        group(n_chunks, o, 1, 256, 256, W, W, G->g[P_FW], W, 0, G->g[P_FB]);
+    }
+    {   // sigma head: row 4 of the head-seed tile of direction 0 against h_8
+        const size_t o = add(sg, nsg, n_single, 16, 256, bwd + bl.dq[0], acts + al.h[D - 1]);
+        WgGroup &g = group(n_single, o + 4 * 256, 1, 16, 256, 1, W, G->g[P_SW], W, 0, G->g[P_SB]);
+        g.bias_off = (size_t)16 * 256 + 4 - 4 * 256;
+    }
+    {   // view layer, feature columns: A = sum over directions of dYv
+        const size_t o = add(vf, nvf, n_single, 128, 256, bwd + bl.dyvsum, acts + al.feat);
+        group(n_single, o, 1, 128, 256, WV, W, G->g[P_VW], W + DVE, 0, G->g[P_VB]);
+    }
+    {   // view layer, direction columns (gamma(dir) in slot order) and the output head: one GEMM per direction, summed in order
+        size_t first_d = 0, first_o = 0;
+        for (int k = 0; k <= V; ++k) {
+            const size_t o = add(vd, nvd, n_thin, 128, 32, bwd + bl.dyv[k], acts + al.ped[k]);
+            if (k == 0) first_d = o;
+        }
+        group(n_thin, first_d, 1 + V, 128, 32, WV, 32, G->g[P_VW], W + DVE, W, nullptr, 2);
+        for (int k = 0; k <= V; ++k) {
+            const size_t o = add(oh, noh, n_thin, 16, 128, bwd + bl.dq[k], acts + al.g[k]);
+            if (k == 0) first_o = o;
+        }
+        group(n_thin, first_o, 1 + V, 16, 128, 4, WV, G->g[P_OW], WV, 0, G->g[P_OB]);
+    }
+    if (off > wgrad_partial_total(P, V)) { set_error("wgrad16: partial buffer plan mismatch"); return VIPNERF_E_ARG; }
+
+    int rc = precision == VIPNERF_PREC_BF16 ? launch_all<true>(big, nbig, n_chunks, pe, npe, n_pe, vf, nvf, sg, nsg, n_single, vd, nvd, oh, noh, n_thin, st)
+                                            : launch_all<false>(big, nbig, n_chunks, pe, npe, n_pe, vf, nvf, sg, nsg, n_single, vd, nvd, oh, noh, n_thin, st);
+    if (rc) return rc;
+    ProfScope ps("wgrad_small", st);
+    return launch_wgrad_reduce(red, ng, st);
+}
+
+}  // namespace vn

@@ -11,11 +11,18 @@ fine 8x256 MLP, fp32): forward -> fused losses (MSE 1, Visibility 0.1, Visibilit
 [RCCL all-reduce of the flat gradient bucket] -> Adam.  Batches are generated and resident in HBM before the timed region;
 the random numbers of a step are drawn on the device (Philox) inside it.  Rank 0 prints ONE JSON line.
 
-`value` / `dtype` are the EXACT-fp32 MFMA arithmetic (v_mfma_f32_16x16x4_f32 / 32x32x2_f32), as configs[1] says; the faster split
-arithmetics are timed by the same procedure (W warm-up + K timed steps each) and reported beside it (`value_fp16x3`, ...),
-each with its own `roofline` block (MFMA-bound path, algorithmic 630,272 MAC/point against the dense MFMA peak
-of the operand dtype).  `--scaling strong` runs BASELINE configs[3]'s statement (65,536 rays per iteration split over the
-ranks) instead of the weak-scaling default (4096 rays per GPU).
+`value` / `dtype` are the EXACT-fp32 MFMA arithmetic (v_mfma_f32_16x16x4_f32 / 32x32x2_f32), as configs[1] says; the faster
+arithmetics (`--also`, default fp16x3, fp16, bf16) are timed by the same procedure (W warm-up + K timed steps each) and reported
+beside it (`value_fp16x3`, ...), each with its own `roofline` block (MFMA-bound path, algorithmic 630,272 MAC/point
+against the dense MFMA peak of the operand dtype).  At N = 1 the line also carries `configs4_dtu`: BASELINE configs[4]'s per-GPU
+shard (DTU geometry, non-NDC, 3 views = 2 secondary views, 131,072 / 8 = 16,384 rays per iteration, bf16 / fp16 mixed precision)
+timed the same way.  `--workload fern|realestate|dtu` selects the scene of `value` itself; `--scaling strong` runs the
+ray-sharded statement of configs[3] / configs[4] (`--global-rays` rays per iteration split over the ranks) instead of the
+weak-scaling default (`--rays` per GPU).  `--force-dist` makes a single process take the multi-rank code path (RCCL process group
+with world_size 1, broadcast, all-reduce of the flat gradient bucket inside the timed step, barriers).
+
+The batches come from the product's own on-device batch builder (RayGeneratorHip: synthetic cameras, random images and visibility
+priors, rays generated on the GPU); `oracle/` is imported for the `cpu_baseline` leg only.
 """
 import argparse
 import json
@@ -35,8 +42,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'vip-nerf_amd'))
 sys.path.insert(0, os.path.join(ROOT, 'vip-nerf_amd', 'src'))
 
-MAC_PER_POINT = 630272          # trunk+sigma+feature 556,800 + 2 x 36,736 view-branch evaluations (V = 1)
+MAC_TRUNK = 556800              # trunk + sigma head + feature layer, per point
+MAC_VIEW = 36736                # one view-branch evaluation (1 + V of them per point)
+MAC_PER_POINT = MAC_TRUNK + 2 * MAC_VIEW      # 630,272 with V = 1 (configs[1])
 POINTS_PER_RAY = 64 + 192
+# synthetic scenes: geometry constants of the reference's shipped ModelConfigs (numbers, not code) -- h, w, focal, near, far, ndc, views
+SCENES = {'fern': (756, 1008, 815.1316, 1.0, 5.1731, True, 2), 'realestate': (576, 1024, 900.0, 1.0, 133.33, True, 3),
+          'dtu': (300, 400, 361.54, 0.09, 5.0, False, 3)}
 # SURVEY.md 8d algorithmic bytes: ~105 B/ray in + ~72 B/ray per-ray outputs + 10,240 B/ray of per-sample training outputs,
 # + the weights once per launch and the gradients once per step (4.77 MB each)
 ALGO_BYTES_PER_RAY = 105 + 72 + 10240
@@ -62,24 +74,29 @@ ARITH = {
     'fp16': ('f16 operands (rounded once, power-of-two scaling), ONE fp16 MFMA per product, fp32 accumulate; trunk activations / '
              'gradients stored as fp16; fp32 master weights, encodings, heads, compositing, losses (BASELINE configs[4]-style mixed '
              'precision; ~1e-3 relative gradient error)', F16_MFMA_PEAK_TFLOPS, 1, ''),
-    'bf16': ('bf16 operands (rounded once), ONE bf16 MFMA per product in the forward / data-gradient GEMMs, fp32 accumulate and '
-             'storage (BASELINE configs[4]-style mixed precision; ~1e-2 relative gradient error)', F16_MFMA_PEAK_TFLOPS, 1, ''),
+    'bf16': ('bf16 operands (rounded once), ONE bf16 MFMA per product in every GEMM (forward, data gradients, weight gradients), fp32 '
+             'accumulate; activations / gradients stored as the bf16 operands; fp32 master weights, encodings, heads, compositing, losses '
+             '(BASELINE configs[4]: bf16 mixed precision; ~1e-2 relative gradient error)', F16_MFMA_PEAK_TFLOPS, 1, ''),
 }
 # kernels of a step (profile scopes of the library) and the share of a pass's algorithmic MACs each one carries: the eight 256x256
 # weight-gradient GEMMs of an MLP are 8 x 65,536 of the 630,272 MAC/point, the thin GEMMs (encoding columns, view branch, heads) the rest
 STAGE_GROUPS = {'mlp_fwd': ('mlp_fwd_coarse', 'mlp_fwd_fine'), 'mlp_dgrad': ('mlp_dgrad_coarse', 'mlp_dgrad_fine'),
                 'wgrad_256x256': ('wgrad_256x256',), 'wgrad_small': ('wgrad_small',)}
-STAGE_MACS = {'mlp_fwd': MAC_PER_POINT, 'mlp_dgrad': MAC_PER_POINT, 'wgrad_256x256': 8 * 65536, 'wgrad_small': MAC_PER_POINT - 8 * 65536}
 STAGE_KERNEL = {'mlp_fwd': 'k_mlp_fwd* (MLP forward: one launch per level)', 'mlp_dgrad': 'k_mlp_bwd* (MLP data gradients: one launch per level)',
-                'wgrad_256x256': 'k_wgrad<2,8,4> / k_wgrad_*_256 (the eight 256x256 weight-gradient GEMMs: one launch per level)',
+                'wgrad_256x256': 'k_wgrad256_w8 / k_wgrad_*_256 / k_wg16<16,16> (the eight 256x256 weight-gradient GEMMs: one launch per level)',
                 'wgrad_small': 'the thin weight-gradient GEMMs + the chunk reduction (six launches per level)'}
 
 
-def model_configs():
+def stage_macs(n_sec):
+    per_point = MAC_TRUNK + (1 + n_sec) * MAC_VIEW
+    return {'mlp_fwd': per_point, 'mlp_dgrad': per_point, 'wgrad_256x256': 8 * 65536, 'wgrad_small': per_point - 8 * 65536}
+
+
+def model_configs(ndc=True):
     mlp = lambda ns: {'num_samples': ns, 'netdepth': 8, 'netwidth': 256, 'points_positional_encoding_degree': 10,
                       'views_positional_encoding_degree': 4, 'use_view_dirs': True, 'view_dependent_rgb': True,
                       'predict_visibility': True}
-    return {'data_loader': {'ndc': True},
+    return {'data_loader': {'ndc': ndc},
             'model': {'name': 'VipNeRFHip01', 'coarse_mlp': mlp(64), 'fine_mlp': mlp(128), 'chunk': 4096,
                       'netchunk': 16384, 'lindisp': False, 'perturb': True, 'raw_noise_std': 1.0, 'white_bkgd': False},
             'losses': [{'name': 'MSEHip01', 'weight': 1}, {'name': 'VisibilityLossHip01', 'weight': 0.1},
@@ -87,8 +104,31 @@ def model_configs():
             'device': [0]}
 
 
-def make_batch(vo, n_rays, seed, dev, iter_num=40000):
-    b = vo.synthetic_batch(n_rays, seed, scene='fern', nf=2)
+def make_scene(name, dev, seed=0):
+    """The product's on-device batch builder over a synthetic scene: `views` cameras on a 0.2-wide baseline looking down -z, random
+    images and random visibility-prior masks (there is no dataset in the container).  -> RayGeneratorHip"""
+    import numpy as np
+    from data_preprocessors.RayGeneratorHip01 import RayGeneratorHip
+    h, w, f, near, far, ndc, nf = SCENES[name]
+    K = np.array([[f, 0, w / 2.], [0, f, h / 2.], [0, 0, 1.]], dtype=np.float32)
+    poses = np.tile(np.eye(4, dtype=np.float32), (nf, 1, 1))
+    poses[:, 0, 3] = np.linspace(-0.1, 0.1, nf)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    images = torch.rand(nf, h, w, 3, generator=g, device=dev)
+    prior = (torch.rand(nf, nf - 1, h, w, generator=g, device=dev) < 0.5).float()
+    return RayGeneratorHip((h, w), K[None], poses, near, far, ndc, dev, images=images, visibility_prior=prior)
+
+
+def make_batch(gen, n_rays, seed, iter_num=40000):
+    """One resident training batch of n_rays random pixels of the scene (rays generated on the GPU by vipnerf_generate_rays)."""
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(0, gen.n * gen.h * gen.w, (n_rays,), generator=g)
+    return gen.get_next_batch(iter_num, indices=ids.numpy())
+
+
+def make_batch_oracle(vo, n_rays, seed, dev, iter_num=40000, scene='fern', nf=2):
+    """A batch from the ORACLE's generator (tools/ diagnostics that compare against the oracle on the same rays); not used by the benchmark."""
+    b = vo.synthetic_batch(n_rays, seed, scene=scene, nf=nf)
     rb = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items() if k not in ('poses', 'ndc')}
     rb['common_data'] = {'poses': b['poses'][None].clone().to(dev)}
     rb['iter_num'] = iter_num
@@ -171,37 +211,39 @@ class ClockSampler:
         return s[len(s) // 2] if s else None
 
 
-def pmc_reference(prec, rays):
-    """HBM bytes per step from the committed rocprofv3 --pmc passes of this very command (profiles/r02_pmc_traffic_<prec>.json;
-    counters cannot be collected from inside the process).  Used only when the workload matches the one profiled."""
-    for name in ('r02_pmc_traffic_%s.json' % prec,):
+def pmc_reference(prec, rays, workload):
+    """HBM bytes per step from the committed rocprofv3 --pmc passes of this very command (profiles/r03_pmc_traffic_<prec>.json;
+    counters cannot be collected from inside the process).  Used only when the workload matches the one profiled; the block
+    says which file, of which commit and date, it quotes -- the figure goes stale when a kernel changes without re-profiling."""
+    for name in ('r03_pmc_traffic_%s.json' % prec, 'r02_pmc_traffic_%s.json' % prec):
         try:
             tr = json.load(open(os.path.join(ROOT, 'profiles', name)))
-            if tr['workload']['rays_per_gpu'] == rays and tr['workload']['precision'] == prec:
+            if tr['workload']['rays_per_gpu'] == rays and tr['workload']['precision'] == prec and tr['workload'].get('scene', 'fern') == workload:
                 return tr, name
         except (OSError, KeyError, ValueError):
             pass
     return None, None
 
 
-def roofline_block(prec, prof, steps, rays, ms_per_step, sclk_mhz):
+def roofline_block(prec, prof, steps, rays, ms_per_step, sclk_mhz, n_sec=1, workload='fern'):
     """the path is MFMA-bound; frac = algorithmic FLOP of the dominant kernel's launches / its device time
     (HIP events on the launch stream inside the timed region) / dense MFMA peak of the operand dtype."""
     dtype, peak, issued, _ = ARITH[prec]
+    macs = stage_macs(n_sec)
     stage_ms = {g: sum(prof.get(k, (0, 0.0))[1] for k in ks) / steps for g, ks in STAGE_GROUPS.items()}
     launches = {g: sum(prof.get(k, (0, 0.0))[0] for k in ks) / steps for g, ks in STAGE_GROUPS.items()}
     other_ms = sum(v[1] for k, v in prof.items() if not any(k in ks for ks in STAGE_GROUPS.values())) / steps
     points = POINTS_PER_RAY * rays
-    flop_pass = MAC_PER_POINT * 2.0 * points                          # one pass (forward, data gradient or weight gradient) per step
+    flop_pass = macs['mlp_fwd'] * 2.0 * points                        # one pass (forward, data gradient or weight gradient) per step
     dom = max(stage_ms, key=stage_ms.get)                             # the kernel with the largest device time per step
-    tf = lambda g: STAGE_MACS[g] * 2.0 * points / (stage_ms[g] * 1e-3) / 1e12 if stage_ms[g] > 0 else 0.0
+    tf = lambda g: macs[g] * 2.0 * points / (stage_ms[g] * 1e-3) / 1e12 if stage_ms[g] > 0 else 0.0
     wg_ms = stage_ms['wgrad_256x256'] + stage_ms['wgrad_small']
     r = {'bound': 'mfma', 'kernel': STAGE_KERNEL[dom], 'achieved': round(tf(dom), 2), 'peak': peak, 'unit': 'TFLOP/s',
          'frac': round(tf(dom) / peak, 4),
-         'definition': 'algorithmic MACs of the dominant kernel (%d MAC/point of the pass\'s 630,272) x 2 x %d points per step / device time '
+         'definition': 'algorithmic MACs of the dominant kernel (%d MAC/point of the pass\'s %d) x 2 x %d points per step / device time '
                        'of its launches in a step (mean over %d timed steps, HIP events on the launch stream) / dense MFMA peak of the operand '
-                       'dtype; forward, data-gradient and weight-gradient passes each count 630,272 MAC/point (SURVEY.md 8d, the 3x convention)'
-                       % (STAGE_MACS[dom], points, steps),
+                       'dtype; forward, data-gradient and weight-gradient passes each count the full MAC/point (SURVEY.md 8d, the 3x convention)'
+                       % (macs[dom], macs['mlp_fwd'], points, steps),
          'avg_launch_ms': round(stage_ms[dom] / max(launches[dom], 1), 4), 'launches_per_step': launches[dom],
          'mfmas_issued_per_product': issued, 'frac_issued': round(min(tf(dom) * issued / peak, 9.99), 4),
          'stages': dict({g: {'ms_per_step': round(stage_ms[g], 3), 'achieved_tflops': round(tf(g), 1), 'frac': round(tf(g) / peak, 4)}
@@ -217,11 +259,11 @@ def roofline_block(prec, prof, steps, rays, ms_per_step, sclk_mhz):
         r['sustained_peak'] = F16_MFMA_SUSTAINED_TFLOPS
         r['frac_of_sustained'] = round(tf(dom) / F16_MFMA_SUSTAINED_TFLOPS, 4)
         r['frac_issued_of_sustained'] = round(min(tf(dom) * issued / F16_MFMA_SUSTAINED_TFLOPS, 9.99), 4)
-        r['sustained_note'] = 'dense 16-bit MFMA rate this chip sustains from registers alone (tools/mfma_f16_sustained.hip: 1.69 PFLOP/s ' \
-                              'at 1.75-1.9 GHz, 1.2-1.3 kW): the practical ceiling behind the nominal 2.5 PFLOP/s'
+        r['sustained_note'] = 'what a seconds-long dense 16-bit MFMA stream sustains on this part under its power limit (tools/' \
+                              'mfma_f16_sustained.hip, DESIGN.md 4.1b); informational -- frac is against the nominal 2.5 PFLOP/s'
     algo_bytes = ALGO_BYTES_PER_RAY * rays + ALGO_BYTES_FIXED
     r['algorithmic_bytes_per_step'] = algo_bytes
-    tr, name = pmc_reference(prec, rays)
+    tr, name = pmc_reference(prec, rays, workload)
     if tr is not None:
         r['traffic'] = tr['bytes_per_step'][dom if dom in tr['bytes_per_step'] else 'wgrad']['total']
         step_bytes = sum(v['total'] for v in tr['bytes_per_step'].values())
@@ -229,7 +271,8 @@ def roofline_block(prec, prof, steps, rays, ms_per_step, sclk_mhz):
         r['traffic_ratio'] = round(step_bytes / algo_bytes, 1)
         r['hbm_gbs_step'] = round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1)
         r['traffic_note'] = 'HBM bytes per step (dominant kernel / whole step): FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc ' \
-                            'passes of this command, profiles/%s; traffic_ratio = whole step / SURVEY 8d algorithmic bytes' % name
+                            'passes of this command, profiles/%s (profiled at commit %s on %s -- NOT a measurement of this run); traffic_ratio ' \
+                            '= whole step / SURVEY 8d algorithmic bytes' % (name, tr.get('git_head', 'unknown'), tr.get('date', 'unknown'))
         mb = tr.get('mfma_busy', {})
         if mb:
             r['mfma_busy_pmc'] = mb
@@ -243,133 +286,146 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--rays', type=int, default=4096, help='rays per GPU per step (weak scaling)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
-    ap.add_argument('--global-rays', type=int, default=65536, help='rays per step over all GPUs (strong scaling: BASELINE configs[3])')
+    ap.add_argument('--global-rays', type=int, default=None, help='rays per step over all GPUs (strong scaling; default 65536 = BASELINE '
+                    'configs[3], 131072 = configs[4] with --workload dtu)')
+    ap.add_argument('--workload', default='fern', choices=list(SCENES), help='scene geometry of `value` (BASELINE configs[1] / [3]: fern; '
+                    'configs[2]: realestate; configs[4]: dtu)')
     ap.add_argument('--precision', default='fp32', choices=list(ARITH), help='arithmetic of `value` (BASELINE configs[1] says fp32)')
-    ap.add_argument('--also', default='fp16x3,fp16', help='comma list of further arithmetics timed the same way ("" = none, "all")')
+    ap.add_argument('--also', default='fp16x3,fp16,bf16', help='comma list of further arithmetics timed the same way ("" = none, "all")')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-rays', type=int, default=4096)
     ap.add_argument('--no-render', action='store_true')
     ap.add_argument('--no-other-precisions', action='store_true', help='same as --also ""')
+    ap.add_argument('--no-configs4', action='store_true', help='skip the configs[4] block (DTU shard in bf16 / fp16)')
+    ap.add_argument('--configs4-rays', type=int, default=16384, help='rays per GPU of the configs[4] block (131,072 / 8)')
+    ap.add_argument('--force-dist', action='store_true', help='take the multi-rank code path (process group, broadcast, all-reduce, '
+                    'barriers) even with one rank')
     args = ap.parse_args()
 
     from vipnerf_hip import dist as vdist
     from vipnerf_hip import ops
-    rank, world, local = vdist.init_from_env()
+    rank, world, local = vdist.init_from_env(force=True if args.force_dist else None)
     if args.gpus != world and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     dev = torch.device(f'cuda:{local % torch.cuda.device_count()}')   # (one GPU per rank; the modulo only serves the
     torch.cuda.set_device(dev)                                        # 2-ranks-on-1-GPU gloo run of the N>1 code path)
+    collectives = vdist._active()
 
-    from oracle import vipnerf_oracle as vo       # synthetic-data generator + cpu_baseline leg only
     from models.ModelFactory import get_model
     from loss_functions.LossComputerHip01 import LossComputerHip
 
     strong = args.scaling == 'strong'
-    if strong and args.global_rays % world:
-        raise SystemExit(f'--global-rays {args.global_rays} does not split over {world} ranks')
-    rays = args.global_rays // world if strong else args.rays
-    cfg = model_configs()
-    cfg['model']['hip_precision'] = args.precision
-    torch.manual_seed(0)
-    model = get_model(cfg, None).to(dev)
-    vdist.broadcast_parameters(model)
-    model.train()
-    lossc = LossComputerHip(cfg)
-    opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.999), fused=True)   # same update, one kernel
-    bucket = vdist.FlatGradBucket(model.parameters())
-
-    n_batches = min(args.steps + args.warmup, 8 if rays > 8192 else 32)      # distinct resident batches, cycled
-    batches = [make_batch(vo, rays, 1000 + rank * 100003 + i, dev) for i in range(n_batches)]
-    # ray-sharded ranks draw the random numbers of their own rows of the global batch (Philox keyed by global ray index)
-    for b in batches:
-        b['rng_ray_base'] = rank * rays
-    torch.cuda.synchronize()
-    it_counter = [40000]
-
-    def step(i):
-        b = dict(batches[i % n_batches])
-        b['common_data'] = {'poses': batches[i % n_batches]['common_data']['poses']}
-        b['iter_num'] = it_counter[0]               # a new iteration number per step: new Philox offset (loss weights: > 30000)
-        it_counter[0] += 1
-        bucket.release()
-        out = model(b)
-        losses = lossc.compute_losses(b, out)
-        losses['TotalLoss'].backward()
-        bucket.all_reduce_mean()
-        opt.step()
+    global_rays = args.global_rays if args.global_rays is not None else (131072 if args.workload == 'dtu' else 65536)
+    if strong and global_rays % world:
+        raise SystemExit(f'--global-rays {global_rays} does not split over {world} ranks')
+    rays = global_rays // world if strong else args.rays
 
     def barrier():
-        if world > 1:
-            torch.distributed.barrier()
+        vdist.barrier()
         torch.cuda.synchronize()
-
-    INIT_STEPS = 2
-
-    def timed_run(prec):
-        """The contract's procedure for one arithmetic: [2 untimed initialisation passes: kernel loading, the caching
-        allocator's multi-GB workspace blocks, Adam's state] W warm-up steps, then EXACTLY K steps between barrier +
-        synchronize pairs; max over ranks."""
-        model.configs['model']['hip_precision'] = prec
-        torch.cuda.empty_cache()                 # the workspace sizes differ between the arithmetics
-        for i in range(INIT_STEPS):
-            step(i)
-        for i in range(args.warmup):
-            step(i)
-        ops.profile_enable(True)
-        ops.profile_read()
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        prof = ops.profile_read()
-        ops.profile_enable(False)
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            elapsed = float(t.item())
-        # shader clock under load: EVERY rank runs the extra steps (they contain the collective); rank 0 samples
-        cs = ClockSampler(dev) if rank == 0 else None
-        if cs is not None:
-            cs.__enter__()
-        for i in range(max(4, args.steps // 2)):
-            step(i)
-        torch.cuda.synchronize()
-        if cs is not None:
-            cs.__exit__(None, None, None)
-        barrier()
-        return elapsed, prof, (cs.median() if cs is not None else None)
-
-    elapsed, prof, sclk = timed_run(args.precision)
-    also = [] if (args.no_other_precisions or world > 1) else \
-        ([p for p in ARITH if p != args.precision] if args.also == 'all' else [p for p in args.also.split(',') if p and p != args.precision])
-    others = {p: timed_run(p) for p in also}
-    model.configs['model']['hip_precision'] = args.precision
 
     def max_over_ranks(x):
-        if world > 1:
+        if collectives:
             t = torch.tensor([x], dtype=torch.float64, device=dev)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             return float(t.item())
         return x
+
+    INIT_STEPS = 2
+
+    class Workload:
+        """One scene + ray count: model, optimizer, resident batches, and the contract's timing procedure per arithmetic."""
+
+        def __init__(self, scene, n_rays, precision):
+            self.scene, self.rays = scene, n_rays
+            self.n_sec = SCENES[scene][6] - 1
+            self.cfg = model_configs(SCENES[scene][5])
+            self.cfg['model']['hip_precision'] = precision
+            torch.manual_seed(0)
+            self.model = get_model(self.cfg, None).to(dev)
+            vdist.broadcast_parameters(self.model)
+            self.model.train()
+            self.lossc = LossComputerHip(self.cfg)
+            self.opt = torch.optim.Adam(self.model.parameters(), lr=5e-4, betas=(0.9, 0.999), fused=True)   # same update, one kernel
+            self.bucket = vdist.FlatGradBucket(self.model.parameters())
+            self.gen = make_scene(scene, dev)
+            self.n_batches = min(args.steps + args.warmup, 8 if n_rays > 8192 else 32)      # distinct resident batches, cycled
+            self.batches = [make_batch(self.gen, n_rays, 1000 + rank * 100003 + i) for i in range(self.n_batches)]
+            for b in self.batches:         # ray-sharded ranks draw the random numbers of their own rows of the global batch (Philox
+                b['rng_ray_base'] = rank * n_rays      # keyed by global ray index)
+            torch.cuda.synchronize()
+            self.it = 40000
+
+        def step(self, i):
+            src = self.batches[i % self.n_batches]
+            b = dict(src)
+            b['common_data'] = {'poses': src['common_data']['poses']}
+            b['iter_num'] = self.it                   # a new iteration number per step: new Philox offset (loss weights: > 30000)
+            self.it += 1
+            self.bucket.release()
+            out = self.model(b)
+            losses = self.lossc.compute_losses(b, out)
+            losses['TotalLoss'].backward()
+            self.bucket.all_reduce_mean()
+            self.opt.step()
+
+        def timed_run(self, prec):
+            """The contract's procedure for one arithmetic: [2 untimed initialisation passes: kernel loading, the caching
+            allocator's multi-GB workspace blocks, Adam's state] W warm-up steps, then EXACTLY K steps between barrier +
+            synchronize pairs; max over ranks."""
+            self.model.configs['model']['hip_precision'] = prec
+            torch.cuda.empty_cache()                 # the workspace sizes differ between the arithmetics
+            for i in range(INIT_STEPS):
+                self.step(i)
+            for i in range(args.warmup):
+                self.step(i)
+            ops.profile_enable(True)
+            ops.profile_read()
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                self.step(args.warmup + i)
+            barrier()
+            elapsed = time.perf_counter() - t0
+            prof = ops.profile_read()
+            ops.profile_enable(False)
+            elapsed = max_over_ranks(elapsed)
+            # shader clock under load: EVERY rank runs the extra steps (they contain the collective); rank 0 samples
+            cs = ClockSampler(dev) if rank == 0 else None
+            if cs is not None:
+                cs.__enter__()
+            for i in range(max(4, args.steps // 2)):
+                self.step(i)
+            torch.cuda.synchronize()
+            if cs is not None:
+                cs.__exit__(None, None, None)
+            barrier()
+            return elapsed, prof, (cs.median() if cs is not None else None)
+
+        def release(self):
+            self.model = self.opt = self.bucket = self.batches = self.gen = None
+            torch.cuda.empty_cache()
+
+    main_wl = Workload(args.workload, rays, args.precision)
+    model = main_wl.model
+    elapsed, prof, sclk = main_wl.timed_run(args.precision)
+    also = [] if (args.no_other_precisions or world > 1) else \
+        ([p for p in ARITH if p != args.precision] if args.also == 'all' else [p for p in args.also.split(',') if p and p != args.precision])
+    others = {p: main_wl.timed_run(p) for p in also}
+    model.configs['model']['hip_precision'] = args.precision
 
     def render_bench():
         # full-frame eval render, camera -> uint8 image on the GPU (SURVEY.md 8d: 756 x 1008 rays, no secondary views):
         # on-device ray generation -> coarse+fine eval pass -> post-processing (Tester01.predict_frame's job)
         # N > 1: the frame is cut into N strips of rows, one per rank, no data-path collective (SURVEY.md 8e); ms_per_frame is
         # the barrier-bracketed maximum over the ranks
-        from data_preprocessors.RayGeneratorHip01 import RayGeneratorHip, frame_strip, predict_frame
-        import numpy as np
+        from data_preprocessors.RayGeneratorHip01 import frame_strip, predict_frame
         model.eval()
-        K = np.array([[815.1316, 0, 504.], [0, 815.1316, 378.], [0, 0, 1.]], dtype=np.float32)
-        poses = np.tile(np.eye(4, dtype=np.float32), (2, 1, 1))
-        poses[:, 0, 3] = [-0.1, 0.1]
-        gen = RayGeneratorHip((756, 1008), K[None], poses, 1.0, 5.1731, True, dev)
-        n = 756 * 1008
-        rows = frame_strip(756, rank, world)
+        gen = main_wl.gen
+        n = gen.h * gen.w
+        rows = frame_strip(gen.h, rank, world)
         render = {}
-        for prec in [args.precision] + [p for p in also if p in ('fp16x3',)]:
+        for prec in [args.precision] + [p for p in also if p in ('fp16x3', 'bf16')]:
             model.configs['model']['hip_precision'] = prec
             torch.cuda.empty_cache()
             ops.profile_enable(True); ops.profile_read()
@@ -378,14 +434,12 @@ def main():
                 frame = predict_frame(model, gen, frame=0, rows=rows)
                 torch.cuda.synchronize(); rt = max_over_ranks(time.perf_counter() - t0)
             rp = ops.profile_read(); ops.profile_enable(False)
-            assert frame['image'].shape == (rows[1] - rows[0], 1008, 3) and frame['image'].dtype == torch.uint8
+            assert frame['image'].shape == (rows[1] - rows[0], gen.w, 3) and frame['image'].dtype == torch.uint8
             mlp_ms = sum(v[1] for k, v in rp.items() if k.startswith('mlp_fwd')) / 2 * world   # rank 0's strip x N: the frame's kernel time
-            eval_flop = 593536 * 2.0 * POINTS_PER_RAY * n          # 231.6 TFLOP per frame
+            eval_flop = (MAC_TRUNK + MAC_VIEW) * 2.0 * POINTS_PER_RAY * n          # 231.6 TFLOP per 756 x 1008 frame
             render[prec] = {'ms_per_frame': round(rt * 1e3, 1), 'rays_per_sec': round(n / rt, 1),
                             'mlp_kernel_ms': round(mlp_ms, 1), 'achieved_tflops': round(eval_flop / (mlp_ms * 1e-3) / 1e12, 1),
                             'frac': round(eval_flop / (mlp_ms * 1e-3) / 1e12 / ARITH[prec][1], 4),
-                            'frac_issued_of_sustained': round(eval_flop * ARITH[prec][2] / (mlp_ms * 1e-3) / 1e12 /
-                                                              (F16_MFMA_SUSTAINED_TFLOPS if ARITH[prec][1] == F16_MFMA_PEAK_TFLOPS else ARITH[prec][1]), 4),
                             'stage_ms': {k: round(v[1] / 2, 3) for k, v in sorted(rp.items())},
                             'row_strips': world}            # N > 1: one strip of rows per GPU, stage_ms = rank 0's strip
         model.configs['model']['hip_precision'] = args.precision
@@ -394,40 +448,63 @@ def main():
 
     render = None if args.no_render else render_bench()          # every rank: its strip of the frame
 
+    # BASELINE configs[4] at its per-GPU shard size (single-process runs only; the 8-GPU statement itself is
+    # `--workload dtu --scaling strong --precision bf16` under torch.distributed.run)
+    c4 = None
+    if world == 1 and not args.no_configs4 and not (args.workload == 'dtu' and rays == args.configs4_rays):
+        main_wl.release()
+        wl4 = Workload('dtu', args.configs4_rays, 'bf16')
+        c4 = {'workload': 'BASELINE configs[4] per-GPU shard: DTU geometry (non-NDC), 3 views (V = 2 secondary views), 131,072 / 8 = %d rays/iter x '
+                          '(64+128) samples, coarse+fine 8x256 MLP, mixed precision (16-bit MFMA operands and activation storage, fp32 master '
+                          'weights / accumulation / losses), fused Adam' % args.configs4_rays, 'rays_per_gpu': args.configs4_rays}
+        for p in ('bf16', 'fp16'):
+            el, pr, sc = wl4.timed_run(p)
+            pms = el / args.steps * 1e3
+            c4[p] = {'value': round(args.configs4_rays * args.steps / el, 1), 'unit': 'rays/s', 'ms_per_step': round(pms, 3), 'dtype': ARITH[p][0],
+                     'roofline': roofline_block(p, pr, args.steps, args.configs4_rays, pms, sc, n_sec=wl4.n_sec, workload='dtu')}
+        wl4.release()
+
     if rank != 0:
-        torch.distributed.barrier()              # rank 0 finishes its report, then everybody leaves together
+        vdist.barrier()                          # rank 0 finishes its report, then everybody leaves together
         torch.distributed.destroy_process_group()
         return
     ms = elapsed / args.steps * 1e3
     value = rays * world * args.steps / elapsed
-    cfg_name = 'configs[3] (65,536 rays/iter ray-sharded over the GPUs)' if strong else 'configs[1]'
+    n_sec = main_wl.n_sec
+    cfg_name = {'fern': 'configs[3] (65,536 rays/iter ray-sharded over the GPUs)' if strong else 'configs[1]',
+                'realestate': 'configs[2] geometry', 'dtu': 'configs[4] (131,072 rays/iter ray-sharded over the GPUs)' if strong else 'configs[4] geometry'}[args.workload]
     result = {
         'metric': 'train_rays_per_sec', 'value': round(value, 1), 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'init_steps': INIT_STEPS, 'ms_per_step': round(ms, 3), 'higher_is_better': True,
         'scaling': args.scaling, 'vs_baseline': None, 'dtype': ARITH[args.precision][0], 'data': 'synthetic',
-        'config': {'workload': 'BASELINE %s: LLFF-fern 2-view geometry, %d rays/iter/GPU x (64+128) samples, coarse+fine 8x256 MLP, '
-                               'V=1 secondary view, losses MSE+Visibility+VisibilityPrior, Adam; random numbers drawn on device'
-                               % (cfg_name, rays),
+        'config': {'workload': 'BASELINE %s: %s geometry (%s), %d views, %d rays/iter/GPU x (64+128) samples, coarse+fine 8x256 MLP, '
+                               'V=%d secondary view(s), losses MSE+Visibility+VisibilityPrior, Adam; rays generated and random numbers drawn on device'
+                               % (cfg_name, args.workload, 'NDC' if SCENES[args.workload][5] else 'non-NDC', SCENES[args.workload][6], rays, n_sec),
                    'rays_per_gpu': rays, 'global_rays': rays * world, 'parallelism': f'ray-sharded dp{world}',
                    'gemm_arithmetic': args.precision, 'arithmetic_note': ARITH[args.precision][3]},
-        'roofline': roofline_block(args.precision, prof, args.steps, rays, ms, sclk),
+        'roofline': roofline_block(args.precision, prof, args.steps, rays, ms, sclk, n_sec=n_sec, workload=args.workload),
     }
+    if collectives and world == 1:
+        result['config']['collectives'] = 'forced (%s, world_size 1)' % torch.distributed.get_backend()
     for p, (el, pr, sc) in others.items():
         pms = el / args.steps * 1e3
         result['value_' + p] = round(rays * args.steps / el, 1)
         result['ms_per_step_' + p] = round(pms, 3)
         result['dtype_' + p] = ARITH[p][0]
-        result['roofline_' + p] = roofline_block(p, pr, args.steps, rays, pms, sc)
+        result['roofline_' + p] = roofline_block(p, pr, args.steps, rays, pms, sc, n_sec=n_sec, workload=args.workload)
 
     if render is not None:
         result['render_ms_per_frame'] = render[args.precision]['ms_per_frame']
         result['render'] = render
+    if c4 is not None:
+        result['configs4_dtu'] = c4
 
     if world == 1 and not args.no_cpu_baseline:
+        from oracle import vipnerf_oracle as vo       # the checker, as the reported CPU baseline only
         result['cpu_baseline'] = cpu_baseline(vo, n_rays=args.cpu_rays)
     print(json.dumps(result), flush=True)
-    if world > 1:
-        torch.distributed.barrier()
+    if torch.distributed.is_initialized():
+        vdist.barrier()
         torch.distributed.destroy_process_group()
 
 

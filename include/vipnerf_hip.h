@@ -228,13 +228,16 @@ int32_t vipnerf_abi_version(void);
 int32_t vipnerf_last_error(char *buf, size_t n);
 
 /* ---- weights -------------------------------------------------------------------------------------------- */
-/* Bytes of the packed (MFMA fragment order) image of one MLP. */
+/* Bytes of the packed (MFMA fragment order) image of one MLP for precision FP32: the wide-layout image followed by the narrow-layout
+ * one (== vipnerf_packed_weights_bytes_p(VIPNERF_PREC_FP32)); valid for every entry point called with precision FP32. */
 size_t  vipnerf_packed_weights_bytes(void);
 /* Re-lay one MLP's nn.Linear tensors into the streaming order the kernels consume (forward image, transposed
  * image for dgrad, LDS-resident heads/biases).  Replaces nothing in the reference; it is what lets
  * MLP.forward (VipNeRF01.py:509-596) run as one kernel.  Call after every optimizer step. */
 int32_t vipnerf_pack_weights(const vipnerf_mlp_params *params, void *packed, vipnerf_stream_t stream);
-/* Same for a given precision: the buffer holds the fp32 image followed by the split-bf16 image (if precision != FP32). */
+/* Same for a given precision: the buffer holds the wide fp32 image followed by the image(s) of that precision's kernels
+ * ([fp32 wide][wide split-bf16, BF16X3 / BF16X6 only][narrow image of the precision]).  A buffer packed for one precision must be
+ * used with that precision (cfg.precision / the _p argument) only. */
 size_t  vipnerf_packed_weights_bytes_p(int32_t precision);
 int32_t vipnerf_pack_weights_p(const vipnerf_mlp_params *params, int32_t precision, void *packed, vipnerf_stream_t stream);
 /* The same by configuration: cfg->precision for the fused topology (== the _p calls); for any other topology the flat fp32
@@ -375,6 +378,11 @@ int32_t vipnerf_visibility_prior(const vipnerf_psv *psv, double *weights64, floa
  * z (N,S) sampling-space depths, rays->rays_o/rays_d/rays_o2 -> dirs2 (N,S,V,3) unit vectors. */
 int32_t vipnerf_secondary_dirs(const vipnerf_config *cfg, const vipnerf_rays *rays, int32_t n_samples, const float *z,
                                float *dirs2, vipnerf_stream_t stream);
+/* The secondary camera centres of every row (VipNeRF.render_rays' index glue, VipNeRF01.py:84-98): rays_o2[n][v] = translation of
+ * poses[v + (v >= frame(n))], frame(n) = pixel_id[n][0].  poses (n_frames,4,4) camera-to-world, pixel_id (N,3) int32 or int64
+ * -> rays_o2 (N, n_frames-1, 3), what vipnerf_rays.rays_o2 takes.  One launch instead of the reference's per-view gathers. */
+int32_t vipnerf_secondary_origins(int64_t n_rays, int32_t n_frames, const float *poses, const void *pixel_id, int32_t pixel_id_is_int64,
+                                  float *rays_o2, vipnerf_stream_t stream);
 /* The on-device generator behind vipnerf_rng (the reference draws torch.rand / torch.randn on the CPU generator,
  * VipNeRF01.py:200,242,551).  philox4x32_10: out[i] = Philox4x32-10(counter[i], key[i]) (Random123 known-answer
  * vectors).  rng_draw: the n numbers idx = first_idx .. first_idx+n-1 of stream `stream_id` (1 t_rand, 2 u, 3 sigma

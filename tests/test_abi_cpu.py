@@ -29,7 +29,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f'{n} declared in include/vipnerf_hip.h but not exported'
     assert set(names) == set(_lib.SYMBOLS), 'ctypes binding and header disagree'
     assert lib.vipnerf_abi_version() == 2
-    assert lib.vipnerf_packed_weights_bytes() == 4 * (72 * 8192 + 68 * 8192 + 7424)
+    wide = 4 * (72 * 8192 + 68 * 8192 + 7424)      # the unsuffixed pair = precision FP32: [wide image][narrow image]
+    assert lib.vipnerf_packed_weights_bytes() == lib.vipnerf_packed_weights_bytes_p(0) > wide
 
 
 def test_struct_sizes_match_header():

@@ -137,3 +137,17 @@ def test_row_class_aware_sharding():
     # ... which a contiguous split of the mixed batch does not give (ranks 0-1 would hold no sparse-depth row at all)
     with pytest.raises(ValueError):
         vdist.shard_rows(4095, 0, 2)
+
+
+def test_short_batches_trim_per_row_class_on_the_host():
+    """the short last batch of an epoch (or an odd number of sparse-depth pixels) used to raise mid-training with more
+    than one rank; the trainer now trims every row class to a multiple of the ranks, from host-side class counts (no device sync)."""
+    import torch
+    from vipnerf_hip import dist as vdist
+    batch = {'rays_o': torch.zeros(12, 3), 'row_class_counts': (7, 5)}
+    with pytest.raises(ValueError):
+        vdist.shard_row_ids(batch, 0, 2)
+    ids = [vdist.shard_row_ids(batch, r, 2, uneven='trim').tolist() for r in range(2)]
+    assert ids == [[0, 1, 2, 7, 8], [3, 4, 5, 9, 10]]
+    sh = vdist.shard_batch(dict(batch, target=torch.arange(12.)), 1, 2, uneven='trim')
+    assert sh['target'].tolist() == [3., 4., 5., 9., 10.] and sh['row_class_counts'] == (3, 2) and sh['rng_ray_ids'].tolist() == ids[1]

@@ -215,3 +215,88 @@ def test_frame_rendered_by_two_ranks_equals_one_process():
         for k, v in whole.items():
             assert np.array_equal(ret[r][k], v.cpu().numpy()), f'rank {r}: {k}'
     assert ret[0]['image'].shape == (31, 40, 3) and ret[0]['image'].dtype == np.uint8
+
+
+# ---------------------------------------------------------------------------------------------------- RCCL, first contact
+def _rccl_worker(rank, world, port, ret):
+    """WORLD_SIZE = 1 over the `nccl` (= RCCL) backend with the single-process shortcuts switched off (vipnerf_hip.dist.FORCE): backend
+    initialisation on the real GPU, parameter broadcast, the all-reduce of the flat gradient buffer the HIP backward hands over (in
+    place, on the adopted storage), the barrier pattern of bench.py, a second step on the reduced gradients."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                      VIPNERF_DIST_BACKEND='nccl', VIPNERF_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    from oracle import vipnerf_oracle as vo
+    from vipnerf_hip import dist as vdist
+    import test_hip_parity as tp
+    r, w, _ = vdist.init_from_env()
+    assert torch.distributed.is_initialized() and torch.distributed.get_backend() == 'nccl' and (r, w) == (0, 1) and vdist._active()
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    b, rb = _global_batch(dev)
+    model, cfg = tp.make_model(dev, True, vo.init_params(20, scale=1.6), sparse=True)
+    before = [p.detach().clone() for p in model.parameters()]
+    vdist.broadcast_parameters(model, src=0)
+    assert all(torch.equal(a, p.detach()) for a, p in zip(before, model.parameters()))
+    model.train()
+    bucket = vdist.FlatGradBucket(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4, fused=True)
+    shard = vdist.shard_batch(rb, r, w)
+    for it in range(2):
+        bucket.release()
+        _step(model, cfg, shard)
+        flat = bucket.adopted()
+        assert flat is not None and flat.numel() == 1191946
+        ref = flat.clone()
+        ptr = flat.data_ptr()
+        vdist.barrier()
+        torch.cuda.synchronize()
+        bucket.all_reduce_mean()                 # RCCL all-reduce (sum over one rank) + 1/world on the adopted buffer
+        vdist.barrier()
+        torch.cuda.synchronize()
+        assert bucket.params[0].grad.data_ptr() == ptr, 'reduced in place'
+        assert torch.equal(flat, ref), 'a one-rank all-reduce must return its input'
+        opt.step()
+    t = torch.tensor([3.5], dtype=torch.float64, device=dev)          # the max-over-ranks reduction of bench.py
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    ret['ok'] = float(t.item()) == 3.5
+    torch.distributed.destroy_process_group()
+
+
+def test_rccl_single_rank_collectives_on_the_adopted_gradient_buffer():
+    assert torch.cuda.is_available()
+    port = 33000 + (os.getpid() % 2000)
+    ret = mp.Manager().dict()
+    mp.spawn(_rccl_worker, args=(1, port, ret), nprocs=1, join=True)
+    assert ret.get('ok') is True
+
+
+def test_bench_force_dist_single_rank_rccl():
+    """bench.py --force-dist: the N > 1 code path of the benchmark (process group over RCCL, broadcast, all-reduce inside the timed
+    step, barriers, max-over-ranks) with one rank on the real GPU."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(34000 + (os.getpid() % 2000)), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('VIPNERF_DIST_BACKEND', None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--force-dist', '--steps', '3', '--warmup', '1', '--rays', '1024', '--also', '',
+           '--no-cpu-baseline', '--no-render']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 1 and res['value'] > 0 and res['config'].get('collectives') == 'forced (nccl, world_size 1)'
+
+
+def test_uneven_row_classes_trim_instead_of_raising():
+    """the short last batch of an epoch / an odd number of sparse-depth pixels must not stop a multi-rank run."""
+    from vipnerf_hip import dist as vdist
+    dev = torch.device('cuda:0')
+    n_nerf, n_sd = 7, 5
+    batch = {'rays_o': torch.zeros(n_nerf + n_sd, 3, device=dev), 'row_class_counts': (n_nerf, n_sd),
+             'indices_mask_nerf': torch.tensor([True] * n_nerf + [False] * n_sd, device=dev),
+             'indices_mask_sparse_depth': torch.tensor([False] * n_nerf + [True] * n_sd, device=dev)}
+    with pytest.raises(ValueError):
+        vdist.shard_row_ids(batch, 0, 2)
+    ids = [vdist.shard_row_ids(batch, r, 2, uneven='trim').cpu().tolist() for r in range(2)]
+    assert ids == [[0, 1, 2, 7, 8], [3, 4, 5, 9, 10]]
+    no_counts = {k: v for k, v in batch.items() if k != 'row_class_counts'}      # the device-mask path agrees
+    assert [vdist.shard_row_ids(no_counts, r, 2, uneven='trim').cpu().tolist() for r in range(2)] == ids

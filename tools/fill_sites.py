@@ -14,7 +14,7 @@ model = get_model(cfg, None).to(dev).train()
 lossc = LossComputerHip(cfg)
 opt = torch.optim.Adam(model.parameters(), lr=5e-4, fused=True)
 bucket = vdist.FlatGradBucket(model.parameters())
-b = bench.make_batch(vo, 4096, 1, dev)
+b = bench.make_batch_oracle(vo, 4096, 1, dev)
 def step(i):
     bb = dict(b); bb['iter_num'] = 40000 + i; bb['common_data'] = {'poses': b['common_data']['poses']}
     bucket.release()

@@ -1,7 +1,9 @@
-"""profiles/r02_pmc_traffic_<prec>.json from the per-counter summaries tools/profile_round.sh leaves (tools/pmc_summary.py
+"""profiles/r03_pmc_traffic_<prec>.json from the per-counter summaries tools/profile_round.sh leaves (tools/pmc_summary.py
 tables): HBM bytes per training step and stage, MFMA-pipe busy fraction and shader clock per kernel.
-    python tools/pmc_traffic.py gpurun_out/round fp32 profiles/r02_pmc_traffic_fp32.json"""
+    python tools/pmc_traffic.py gpurun_out/round fp32 profiles/r03_pmc_traffic_fp32.json"""
+import datetime
 import json
+import subprocess
 import sys
 
 
@@ -14,7 +16,7 @@ def table(path):
     return rows
 
 
-STAGES = {'mlp_fwd': ('k_mlp_fwd',), 'mlp_dgrad': ('k_mlp_bwd',), 'wgrad': ('k_wgrad',)}
+STAGES = {'mlp_fwd': ('k_mlp_fwd',), 'mlp_dgrad': ('k_mlp_bwd',), 'wgrad': ('k_wgrad', 'k_wg16')}
 
 
 def main(d, prec, out):
@@ -29,16 +31,18 @@ def main(d, prec, out):
         per[st] = {'read': int(rd), 'written': int(wr), 'total': int(rd + wr)}
     busy = {}
     for k, (calls, us, cyc) in m.items():
-        if 'vn::k_mlp' in k or 'k_wgrad_split16_256' in k or 'k_wgrad_bf16x3_256' in k or 'k_wgrad_h16_256' in k or 'k_wgrad<2, 8, 4>' in k or 'k_wgrad256_w8' in k:
+        if 'vn::k_mlp' in k or 'k_wgrad_split16_256' in k or 'k_wgrad_bf16x3_256' in k or 'k_wgrad_h16_256' in k or 'k_wgrad<2, 8, 4>' in k or 'k_wgrad256_w8' in k or 'k_wg16<' in k:
             bus = b.get(k)
             if not bus:
                 continue
             clk_ghz = bus[2] / bus[1] / 32 / 1e3            # SQ_BUSY_CYCLES is summed over the 32 shader engines
             busy[k] = {'sclk_ghz': round(clk_ghz, 2), 'mfma_busy_frac': round(cyc / (1024 * us * 1e-6 * clk_ghz * 1e9), 3)}
     res = {
-        'workload': {'rays_per_gpu': 4096, 'precision': prec, 'layout': 'narrow', 'steps_profiled': steps_profiled},
+        'workload': {'rays_per_gpu': 4096, 'precision': prec, 'scene': 'fern', 'layout': 'narrow', 'steps_profiled': steps_profiled},
+        'git_head': subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip() or 'unknown',
+        'date': datetime.date.today().isoformat(),
         'source': 'rocprofv3 --kernel-trace --pmc <COUNTER> (one counter per pass, tools/profile_round.sh) of `python bench.py --steps 3 '
-                  '--warmup 1 --precision %s`; profiles/r02_pmc_<COUNTER>_%s.txt' % (prec, prec),
+                  '--warmup 1 --precision %s`; profiles/r03_pmc_<COUNTER>_%s.txt' % (prec, prec),
         'corrections': 'FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md '
                        'HBM section); WRITE_SIZE taken as is (k_pack_bf16n, whose output size is known, reads 1.00x)',
         'bytes_per_step': per,

@@ -16,7 +16,7 @@ model = get_model(cfg, None).to(dev).train()
 lossc = LossComputerHip(cfg)
 opt = torch.optim.Adam(model.parameters(), lr=5e-4, fused=True)
 sizes = [1, 37, 256, 1000, 1024, 2048, 3000, 4096]
-batches = {(n, nf): bench.make_batch(vo, n, 7 + n + nf, dev) for n in sizes for nf in (2,)}
+batches = {(n, nf): bench.make_batch_oracle(vo, n, 7 + n + nf, dev) for n in sizes for nf in (2,)}
 for (n, nf), b in list(batches.items()):
     pass
 precs = ['fp32', 'fp16x3', 'fp16', 'bf16x3']

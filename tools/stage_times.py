@@ -5,17 +5,17 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'vip-nerf_amd')); sys.path.insert(0, os.path.join(ROOT, 'vip-nerf_amd', 'src'))
 import bench
-from oracle import vipnerf_oracle as vo
 from vipnerf_hip import ops
 from models.ModelFactory import get_model
 from loss_functions.LossComputerHip01 import LossComputerHip
 dev = torch.device('cuda:0')
-cfg = bench.model_configs()
+scene = os.environ.get('SCENE', 'fern')
+cfg = bench.model_configs(bench.SCENES[scene][5])
 cfg['model']['hip_precision'] = os.environ.get('HIP_PRECISION', 'fp32')
 torch.manual_seed(0)
 model = get_model(cfg, None).to(dev).train()
 lossc = LossComputerHip(cfg)
-b0 = bench.make_batch(vo, int(os.environ.get('RAYS', 4096)), 1000, dev)
+b0 = bench.make_batch(bench.make_scene(scene, dev), int(os.environ.get('RAYS', 4096)), 1000)
 def step():
     b = dict(b0); b['common_data'] = {'poses': b0['common_data']['poses']}
     model.zero_grad(set_to_none=True)

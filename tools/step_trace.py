@@ -13,7 +13,7 @@ model = get_model(cfg, None).to(dev); model.train()
 lossc = LossComputerHip(cfg)
 opt = torch.optim.Adam(model.parameters(), lr=5e-4, fused=True)
 bucket = vdist.FlatGradBucket(model.parameters())
-batches = [bench.make_batch(vo, 4096, 1000 + i, dev) for i in range(4)]
+batches = [bench.make_batch_oracle(vo, 4096, 1000 + i, dev) for i in range(4)]
 def step(i):
     b = dict(batches[i]); b['common_data'] = {'poses': batches[i]['common_data']['poses']}
     bucket.release(); out = model(b); losses = lossc.compute_losses(b, out); losses['TotalLoss'].backward(); opt.step()

@@ -190,9 +190,7 @@ int32_t vipnerf_last_error(char *buf, size_t n) {
     return VIPNERF_OK;
 }
 
-size_t vipnerf_packed_weights_bytes(void) { return PK_TOTAL_F * sizeof(float); }
-
-int32_t vipnerf_pack_weights(const vipnerf_mlp_params *params, void *packed, vipnerf_stream_t stream) {
+static int pack_wide_fp32(const vipnerf_mlp_params *params, void *packed, vipnerf_stream_t stream) {
     clear_stale_hip_error();
     if (!params || !packed) { set_error("pack_weights: NULL argument"); return VIPNERF_E_ARG; }
     for (int i = 0; i < VIPNERF_N_PARAMS; ++i)
@@ -202,9 +200,17 @@ int32_t vipnerf_pack_weights(const vipnerf_mlp_params *params, void *packed, vip
 
 size_t vipnerf_packed_weights_bytes_p(int32_t precision) { return packed_floats_all(precision) * sizeof(float); }
 
+// The unsuffixed pair is the FP32 case of the _p pair: [wide fp32 image][narrow fp32 image] -- every entry point that takes a packed
+// buffer (the render calls default to the narrow exact-fp32 kernels) accepts what it produces.
+size_t vipnerf_packed_weights_bytes(void) { return vipnerf_packed_weights_bytes_p(VIPNERF_PREC_FP32); }
+
+int32_t vipnerf_pack_weights(const vipnerf_mlp_params *params, void *packed, vipnerf_stream_t stream) {
+    return vipnerf_pack_weights_p(params, VIPNERF_PREC_FP32, packed, stream);
+}
+
 int32_t vipnerf_pack_weights_p(const vipnerf_mlp_params *params, int32_t precision, void *packed, vipnerf_stream_t stream) {
     if (precision < 0 || precision > VIPNERF_PREC_BF16) { set_error("pack_weights: precision=%d unsupported", precision); return VIPNERF_E_UNSUPPORTED; }
-    int rc = vipnerf_pack_weights(params, packed, stream);
+    int rc = pack_wide_fp32(params, packed, stream);
     if (rc) return rc;
     if (precision != VIPNERF_PREC_FP32 && precision < VIPNERF_PREC_FP16X3 &&
         (rc = launch_pack_bf16(params, precision, (float *)packed + PK_TOTAL_F, (hipStream_t)stream))) return rc;
@@ -547,6 +553,15 @@ int32_t vipnerf_secondary_dirs(const vipnerf_config *cfg, const vipnerf_rays *ra
     if (cfg->n_sec <= 0) { set_error("secondary_dirs: n_sec == 0"); return VIPNERF_E_ARG; }
     const PointSrc s = ray_points(cfg, rays, n_samples, z);
     return launch_secondary_dirs(s, dirs2, (hipStream_t)stream);
+}
+
+int32_t vipnerf_secondary_origins(int64_t n_rays, int32_t n_frames, const float *poses, const void *pixel_id, int32_t pixel_id_is_int64,
+                                  float *rays_o2, vipnerf_stream_t stream) {
+    clear_stale_hip_error();
+    if (n_rays < 0 || n_frames < 1 || (n_rays > 0 && n_frames > 1 && (!poses || !pixel_id || !rays_o2))) {
+        set_error("secondary_origins: bad argument"); return VIPNERF_E_ARG; }
+    ProfScope ps("secondary_origins", (hipStream_t)stream);
+    return launch_secondary_origins(n_rays, n_frames, poses, pixel_id, pixel_id_is_int64, rays_o2, (hipStream_t)stream);
 }
 
 int32_t vipnerf_philox4x32_10(int64_t n, const uint32_t *counters, const uint32_t *keys, uint32_t *out, vipnerf_stream_t stream) {

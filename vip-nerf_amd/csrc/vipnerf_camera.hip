@@ -102,6 +102,28 @@ __global__ void k_postprocess(int64_t n, const float *rgb, const float *depth, c
     if (depth_var_ndc && o_depth_var_ndc) o_depth_var_ndc[i] = fmaxf(depth_var_ndc[i], 0.f);
 }
 
+// rays_o2[n][v] = translation of pose[v + (v >= frame(n))]  (VipNeRF01.py:88-98): the centres of the other cameras, per row
+template <typename IDX>
+__global__ void k_secondary_origins(int64_t N, int nf, const float *poses, const IDX *pixel_id, float *rays_o2) {
+    const int V = nf - 1;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * V) return;
+    const int64_t n = i / V;
+    const int v = (int)(i % V);
+    const int f = (int)pixel_id[3 * n];
+    const int other = v + (v >= f ? 1 : 0);
+    const float *T = poses + (size_t)other * 16;
+    rays_o2[3 * i + 0] = T[3]; rays_o2[3 * i + 1] = T[7]; rays_o2[3 * i + 2] = T[11];
+}
+int launch_secondary_origins(int64_t N, int nf, const float *poses, const void *pixel_id, int idx64, float *rays_o2, hipStream_t st) {
+    if (N <= 0 || nf <= 1) return VIPNERF_OK;
+    const unsigned grid = (unsigned)((N * (nf - 1) + 255) / 256);
+    if (idx64) hipLaunchKernelGGL(k_secondary_origins<int64_t>, dim3(grid), dim3(256), 0, st, N, nf, poses, (const int64_t *)pixel_id, rays_o2);
+    else hipLaunchKernelGGL(k_secondary_origins<int32_t>, dim3(grid), dim3(256), 0, st, N, nf, poses, (const int32_t *)pixel_id, rays_o2);
+    VN_HIP(hipGetLastError());
+    return VIPNERF_OK;
+}
+
 int launch_gen_rays(const RayGenArgs &a, hipStream_t st) {
     if (a.N <= 0) return VIPNERF_OK;
     hipLaunchKernelGGL(k_gen_rays, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, st, a);

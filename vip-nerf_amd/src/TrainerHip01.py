@@ -58,7 +58,9 @@ class TrainerHip:
         """-> {loss name: 0-dim device tensor, summed over the sub-batches}; nothing here waits for the GPU."""
         batch = self.gen.get_next_batch(iter_num, scheduler=self.scheduler)
         if self.world > 1:
-            batch = vdist.shard_batch(batch, self.rank, self.world)
+            # a short last batch of an epoch / an odd number of sparse-depth pixels: each row class is trimmed to a multiple of the
+            # ranks (equal per-class counts keep the mean of the rank means exact) instead of stopping the run
+            batch = vdist.shard_batch(batch, self.rank, self.world, uneven='trim')
         self.bucket.release()                                # = optimizer.zero_grad(set_to_none=True)
         n = batch['rays_o'].shape[0]
         sub = int(self.configs.get('sub_batch_size', n)) or n
@@ -108,7 +110,19 @@ class TrainerHip:
         val_int = int(self.configs.get('validation_interval', 0))
         save_int = int(self.configs.get('model_save_interval', 0))
         start = self.load_model()
-        history = []
+        history, pending = [], []
+
+        def flush():
+            # one transfer per block of iterations: the loop never waits for the GPU per step, and a run of 250 k iterations neither keeps
+            # millions of 0-dim device tensors alive nor loses its whole log if it dies
+            if not pending:
+                return
+            keys = list(pending[0][0].keys())
+            table = torch.stack([torch.stack([h[0][k].float() for k in keys]) for h in pending]).cpu().numpy()
+            history.extend(dict(zip(keys, map(float, row)), **h[1]) for row, h in zip(table, pending))
+            pending.clear()
+
+        flush_every = int(self.configs.get('log_flush_interval', 256))
         self.model.train()
         for iter_num in range(start, total):
             lr = self.learning_rate(iter_num)
@@ -116,16 +130,14 @@ class TrainerHip:
                 g['lr'] = lr
             losses = self.train_one_iter(iter_num)
             entry = {'lr': lr}
-            history.append((losses, entry))
+            pending.append((losses, entry))
             if log_every and self.rank == 0 and (iter_num + 1) % log_every == 0:
                 print(f"iter {iter_num + 1}: " + ' '.join(f'{k} {float(v):.5f}' for k, v in losses.items()) + f' lr {lr:.3e}', flush=True)
             if val_int and (iter_num + 1) % val_int == 0:
                 entry['validation_psnr'] = float(numpy.mean([v.get('psnr', float('nan')) for v in self.run_validation().values()]))
             if save_int and (iter_num + 1) % save_int == 0:
                 self.save_model(iter_num + 1)
-        # one transfer for the whole history instead of one host wait per iteration and loss
-        if history:
-            keys = list(history[0][0].keys())
-            table = torch.stack([torch.stack([h[0][k].float() for k in keys]) for h in history]).cpu().numpy()
-            return [dict(zip(keys, map(float, row)), **h[1]) for row, h in zip(table, history)]
-        return []
+            if len(pending) >= flush_every or (val_int and (iter_num + 1) % val_int == 0) or (save_int and (iter_num + 1) % save_int == 0):
+                flush()
+        flush()
+        return history

@@ -200,6 +200,13 @@ class RayGeneratorHip:
             if scheduler is None:
                 raise L.VipNerfHipError('get_next_batch needs either ray indices or a BatchIndexScheduler')
             indices, row_is_sparse = scheduler.next(iter_num)
+        # host-side row-class counts (nerf rows first, then the sparse-depth rows): what vipnerf_hip.dist.shard_row_ids needs to cut a
+        # batch into per-rank shards without reading the device masks back
+        counts = None
+        if not (isinstance(indices, torch.Tensor) and indices.is_cuda) and not (isinstance(row_is_sparse, torch.Tensor) and row_is_sparse.is_cuda):
+            n_rows = int(len(indices))
+            n_sd = int(numpy.count_nonzero(numpy.asarray(row_is_sparse))) if row_is_sparse is not None else 0
+            counts = (n_rows - n_sd, n_sd)
         indices = self._upload(indices, torch.int64)
         sparse_on = self.sparse_depths is not None
         if row_is_sparse is None and sparse_on:
@@ -216,6 +223,8 @@ class RayGeneratorHip:
         else:
             b['indices_mask_nerf'] = torch.ones(indices.shape[0], dtype=torch.bool, device=self.device)
         b['common_data'] = {'poses': self.poses[None]}
+        if counts is not None and (sparse_on or counts[1] == 0):
+            b['row_class_counts'] = counts
         return b
 
     def _upload(self, x, dtype):

@@ -106,8 +106,9 @@ class VipNeRFHip(torch.nn.Module):
         would lose; ray_base = position of this call's ray 0 in the global batch (`rng_ray_base`, set by
         vipnerf_hip.dist.shard_batch for ray-sharded ranks: R ranks draw what one process would draw for the whole batch)."""
         seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
-        if getattr(self, '_is_replica', False) and dev.index:      # thread-per-device nn.DataParallel replicas see only
-            seed = (seed ^ (dev.index * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF   # their slice: decorrelate by device
+        replica = getattr(self, '_is_replica', False)            # multi-device nn.DataParallel rebuilds the replicas from the untouched
+        if replica and 'pixel_id' not in input_dict and dev.index:   # master on every forward: no module state survives there.  Rows are
+            seed = (seed ^ (dev.index * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF   # keyed by pixel (render_rays); without pixel ids: by device
         it = input_dict.get('iter_num')
         if it is None:
             offset = (1 << 62) | self._calls
@@ -142,15 +143,8 @@ class VipNeRFHip(torch.nn.Module):
         if sec_views_vis:
             if 'rays_o2' in input_dict:
                 o2 = input_dict['rays_o2']
-            else:                                               # VipNeRF01.py:88-98 (index glue)
-                poses = input_dict['common_data']['poses']
-                image_id = input_dict['pixel_id'][:, 0].long()
-                nf = int(input_dict['num_frames'])
-                cols = []
-                for i in range(nf - 1):
-                    other = i + (i >= image_id).long()
-                    cols.append(poses[other][:, :3, 3])
-                o2 = torch.stack(cols, dim=1)
+            else:                                               # VipNeRF01.py:88-98: the other cameras' centres per row, one launch
+                o2 = ops.secondary_origins(input_dict['common_data']['poses'], input_dict['pixel_id'], int(input_dict['num_frames']))
             V = o2.shape[1]
             batch['rays_o2'] = o2
         n_fine = m['fine_mlp']['num_samples'] if self.fine_mlp_needed else 0
@@ -170,6 +164,12 @@ class VipNeRFHip(torch.nn.Module):
             rng.setdefault('ray_base', ray_base)
             if input_dict.get('rng_ray_ids') is not None:
                 rng.setdefault('ray_ids', input_dict['rng_ray_ids'])
+            elif getattr(self, '_is_replica', False) and 'pixel_id' in input_dict and 'rng_ray_base' not in input_dict:
+                # thread-per-device DataParallel replica (reference Trainer01.py:517 with 'device': [0, 1]): the call sees an arbitrary
+                # slice of some sub-batch and keeps no state, so every row's streams are keyed by its pixel (frame, y, x) -- the same
+                # numbers however the trainer cuts the batch into sub-batches and devices
+                pid = input_dict['pixel_id'].long()
+                rng.setdefault('ray_ids', (pid[:, 0] << 40) | (pid[:, 2] << 20) | pid[:, 1])
         max_ws = m.get('hip_max_workspace_bytes', os.environ.get('VIPNERF_MAX_WORKSPACE_BYTES'))
         state = RenderState(cfg, batch, rng, self.injected_z_fine, None if max_ws is None else int(max_ws))
         params = self.coarse_model.ordered_params() + (self.fine_model.ordered_params() if self.fine_mlp_needed else [])

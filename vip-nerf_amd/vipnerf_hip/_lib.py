@@ -139,6 +139,7 @@ SYMBOLS = {
     'vipnerf_postprocess_frame': (C.c_int32, [C.c_int64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     'vipnerf_visibility_prior': (C.c_int32, [P(Psv), c_f, c_f, c_f, c_f]),
     'vipnerf_secondary_dirs': (C.c_int32, [P(Config), P(Rays), C.c_int32, c_f, c_f, c_f]),
+    'vipnerf_secondary_origins': (C.c_int32, [C.c_int64, C.c_int32, c_f, c_f, C.c_int32, c_f, c_f]),
     'vipnerf_philox4x32_10': (C.c_int32, [C.c_int64, c_f, c_f, c_f, c_f]),
     'vipnerf_rng_draw': (C.c_int32, [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int64, c_f, c_f]),
     'vipnerf_profile_enable': (C.c_int32, [C.c_int32]),

@@ -125,6 +125,10 @@ def _recompute_chunk(state: RenderState, n: int, acts_bytes: int, bwd_bytes: int
     very same random numbers: the Philox streams are keyed by global ray index (vipnerf_rng.ray_base / ray_ids)."""
     limit = state.max_workspace_bytes
     if limit is None:
+        # a workspace under a tenth of the device's memory is taken without asking the driver (mem_get_info is a host <-> driver round
+        # trip on every training forward); the allocator raises the usual out-of-memory error should even that not fit
+        if acts_bytes + bwd_bytes <= torch.cuda.get_device_properties(dev).total_memory // 10:
+            return 0
         free, _ = torch.cuda.mem_get_info(dev)
         cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
         limit = int(0.7 * (free + cached))      # one allocation (activation store + scratch) must fit next to what lives already

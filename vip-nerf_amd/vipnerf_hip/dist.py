@@ -15,12 +15,27 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: str = None):
+# A single process normally skips the process group and every collective.  FORCE (init_from_env(force=True), or VIPNERF_FORCE_DIST=1 in
+# the environment) makes a WORLD_SIZE=1 run take the multi-rank code path anyway -- backend initialisation, parameter broadcast, the
+# all-reduce of the adopted flat gradient buffer, barriers -- so that RCCL's first contact with this code does not have to wait for a
+# multi-GPU node (tests/test_hip_dist.py::test_rccl_single_rank_*, bench.py --force-dist).
+FORCE = False
+
+
+def _active() -> bool:
+    return dist.is_initialized() and (dist.get_world_size() > 1 or FORCE)
+
+
+def init_from_env(backend: str = None, force: bool = None):
     """torchrun-style initialisation.  Returns (rank, world_size, local_rank)."""
+    global FORCE
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if force is None:
+        force = os.environ.get('VIPNERF_FORCE_DIST', '0') not in ('', '0')
+    FORCE = bool(force)
+    if (world > 1 or FORCE) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get('VIPNERF_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -83,8 +98,8 @@ class FlatGradBucket:
         return torch.empty(0, dtype=torch.float32, device=g0.device).set_(st, g0.storage_offset(), (n,))
 
     def all_reduce_mean(self):
-        """sum over ranks, then 1/world, with ONE collective.  No-op in a single process."""
-        if not (dist.is_initialized() and dist.get_world_size() > 1):
+        """sum over ranks, then 1/world, with ONE collective.  No-op in a single process (unless FORCE)."""
+        if not _active():
             return
         flat = self.flat
         if self.params[0].grad is None or self.params[0].grad.data_ptr() != self.views[0].data_ptr():
@@ -98,53 +113,76 @@ class FlatGradBucket:
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0):
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         for p in module.parameters():
             dist.broadcast(p.data, src=src)
 
 
-def shard_rows(n_rows: int, rank: int, world: int):
-    """Equal contiguous shards of ONE row class (the caller keeps n_rows divisible by world so that loss means stay
-    exact).  Batches that mix row classes go through shard_batch."""
-    if n_rows % world:
+def barrier():
+    if _active():
+        dist.barrier()
+
+
+def shard_rows(n_rows: int, rank: int, world: int, uneven: str = 'raise'):
+    """Equal contiguous shards of ONE row class (every loss is a mean over its own rows: with equal per-rank counts the mean of
+    the rank means is the global mean).  A count that does not divide: uneven='raise' (default) refuses; 'trim' drops the last
+    n_rows % world rows -- what a trainer wants for the short last batch of an epoch.  Batches that mix row classes go through
+    shard_batch."""
+    if n_rows % world and uneven != 'trim':
         raise ValueError(f'{n_rows} rows do not split evenly over {world} ranks: every loss is a mean over its own rows, so '
                          f'unequal shards would make the mean of the rank means differ from the global mean')
     per = n_rows // world
     return slice(rank * per, (rank + 1) * per)
 
 
-def shard_row_ids(batch: dict, rank: int, world: int) -> torch.Tensor:
+def shard_row_ids(batch: dict, rank: int, world: int, uneven: str = 'raise') -> torch.Tensor:
     """Global row indices of rank `rank`'s share of a batch with the reference's layout -- nerf rows, then sparse-depth
     rows (select_batch_indices, DataPreprocessor01.py:544-563).  Each class is split separately into `world` equal
     contiguous parts, so that every rank holds N_nerf/R + N_sd/R rows: MSE / VisibilityPrior average over the nerf rows
     (MSE01.py:55-59, VisibilityPriorLoss01.py:74-80), SparseDepthMSE over the sparse-depth rows (SparseDepthMSE01.py:59-63)
     and VisibilityLoss over all rows -- with equal per-class counts on every rank the mean of the rank means IS the global
-    mean and averaging the gradients is exact."""
+    mean and averaging the gradients is exact.
+
+    `batch['row_class_counts'] = (n_nerf, n_sparse_depth)` (host integers; the batch builder knows them: nerf rows first, then the
+    sparse-depth rows) lets the ids be computed on the host without looking at the device masks -- no stream synchronisation per
+    iteration.  uneven='trim': a class whose count does not divide (the short last batch of an epoch, the arbitrary number of
+    sparse-depth pixels of a scene) loses its last count % world rows instead of raising."""
     n = batch['rays_o'].shape[0]
     dev = batch['rays_o'].device
+    counts = batch.get('row_class_counts')
+    if counts is not None:
+        n_nerf, n_sd = int(counts[0]), int(counts[1])
+        if n_nerf + n_sd != n:
+            raise ValueError(f'row_class_counts {tuple(counts)} do not add up to the {n} rows of the batch')
+        parts, start = [], 0
+        for cnt in (n_nerf, n_sd):
+            s = shard_rows(cnt, rank, world, uneven)
+            parts.append(torch.arange(start + s.start, start + s.stop, device=dev))
+            start += cnt
+        return torch.cat(parts)
     m_nerf = batch.get('indices_mask_nerf')
     m_sd = batch.get('indices_mask_sparse_depth')
     if m_sd is None and (m_nerf is None or bool(m_nerf.all())):
-        s = shard_rows(n, rank, world)
+        s = shard_rows(n, rank, world, uneven)
         return torch.arange(s.start, s.stop, device=dev)
     m_nerf = m_nerf.bool() if m_nerf is not None else torch.ones(n, dtype=torch.bool, device=dev)
     m_sd = m_sd.bool() if m_sd is not None else torch.zeros(n, dtype=torch.bool, device=dev)
     parts = []
     for name, m in (('nerf', m_nerf & ~m_sd), ('sparse-depth', m_sd), ('unclassified', ~m_nerf & ~m_sd)):
         ids = torch.nonzero(m, as_tuple=False)[:, 0]
-        if ids.numel() % world:
+        if ids.numel() % world and uneven != 'trim':
             raise ValueError(f'{ids.numel()} {name} rows do not split evenly over {world} ranks')
         per = ids.numel() // world
         parts.append(ids[rank * per:(rank + 1) * per])
     return torch.cat(parts)
 
 
-def shard_batch(batch: dict, rank: int, world: int) -> dict:
+def shard_batch(batch: dict, rank: int, world: int, uneven: str = 'raise') -> dict:
     """This rank's shard of a global batch dict (row-class aware, see shard_row_ids).  Every tensor whose first dimension is
     the row count is indexed; `common_data` and scalars are shared.  `rng_ray_ids` carries the rows' global indices so
     that the on-device Philox streams of the R shards are exactly the streams one process would draw for the whole batch."""
     n = batch['rays_o'].shape[0]
-    ids = shard_row_ids(batch, rank, world)
+    ids = shard_row_ids(batch, rank, world, uneven)
     out = {}
     for k, v in batch.items():
         if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == n and k != 'common_data':
@@ -153,5 +191,7 @@ def shard_batch(batch: dict, rank: int, world: int) -> dict:
             out[k] = dict(v)
         else:
             out[k] = v
+    if batch.get('row_class_counts') is not None:
+        out['row_class_counts'] = tuple(int(c) // world for c in batch['row_class_counts'])
     out['rng_ray_ids'] = ids if 'rng_ray_ids' not in batch else batch['rng_ray_ids'][ids.to(batch['rng_ray_ids'].device)]
     return out

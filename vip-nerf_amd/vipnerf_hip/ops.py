@@ -358,6 +358,23 @@ def secondary_dirs(cfg: L.Config, batch, z):
     return out
 
 
+def secondary_origins(poses: torch.Tensor, pixel_id: torch.Tensor, n_frames: int) -> torch.Tensor:
+    """VipNeRF.render_rays' index glue (VipNeRF01.py:84-98) in one launch: poses (nf,4,4), pixel_id (N,3) int32 / int64 ->
+    rays_o2 (N, nf-1, 3), the centres of the other cameras of every row."""
+    n = pixel_id.shape[0]
+    pc = f32c(poses)
+    pid = pixel_id if pixel_id.dtype in (torch.int32, torch.int64) else pixel_id.to(torch.int64)
+    pid = pid.contiguous()
+    out = torch.empty(n, max(n_frames - 1, 0), 3, dtype=torch.float32, device=pid.device)
+    if n and n_frames > 1:
+        if pc.shape[0] < n_frames:
+            raise L.VipNerfHipError(f'secondary_origins: {pc.shape[0]} poses for num_frames={n_frames}')
+        with on_device(pc, pid) as dev:
+            L.check(L.load().vipnerf_secondary_origins(n, int(n_frames), _p(pc), _p(pid, pid.dtype), int(pid.dtype == torch.int64), _p(out),
+                                                       _stream(dev)), 'vipnerf_secondary_origins')
+    return out
+
+
 def philox4x32_10(counters: torch.Tensor, keys: torch.Tensor) -> torch.Tensor:
     """counters (n,4), keys (n,2) int32 bit patterns on the GPU -> (n,4) int32 bit patterns."""
     n = counters.shape[0]

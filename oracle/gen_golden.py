@@ -259,13 +259,16 @@ def gen_f4():
     cfg = ref_configs(True, netchunk=2048, chunk=32)            # exercise both host loops
     params = vo.init_params(11, scale=1.6, sigma_bias=0.6)
     model = ref_model(cfg, params).eval()
+    slog = []
     with torch.no_grad():
-        out_plain = model(ref_batch(b, 0))                                   # retraw False, no secondary
+        with record_searchsorted(slog):                                      # the reference's own inverse-CDF indices, chunk by chunk
+            out_plain = model(ref_batch(b, 0))                               # retraw False, no secondary
         out_raw = model(ref_batch(b, 0), retraw=True, sec_views_vis=True)    # validation of a train frame
     keys_plain = sorted(out_plain.keys())
     d = pack_outputs(out_raw, ('coarse', 'fine'))
     npz('f4_eval_fern', seed_params=11, scale_params=1.6, sigma_bias=0.6, seed_batch=400, n=n,
-        keys_plain=np.array(keys_plain), **{'plain_' + k: v for k, v in out_plain.items()}, **d)
+        keys_plain=np.array(keys_plain), plain_sample_inds=torch.cat(slog, 0).to(torch.int32),
+        **{'plain_' + k: v for k, v in out_plain.items()}, **d)
 
 
 def gen_f5(tag, scene, nf, n, n_sparse, seed, depth=8, width=256, n_fine=128, pscale=1.6, white_bkgd=False, lindisp=False):
@@ -279,9 +282,9 @@ def gen_f5(tag, scene, nf, n, n_sparse, seed, depth=8, width=256, n_fine=128, ps
     model = ref_model(cfg, params).train()
     lossc = LossComputer(cfg)
     opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.999))
-    rlog = []
+    rlog, slog = [], []
     torch.manual_seed(seed)
-    with record_rng(rlog):
+    with record_rng(rlog), record_searchsorted(slog):
         out = model(ref_batch(b, 40000))
     rng = split_rng(rlog, n + n_sparse, 64, n_fine)
     l40k = lossc.compute_losses(ref_batch(b, 40000), out)
@@ -303,6 +306,7 @@ def gen_f5(tag, scene, nf, n, n_sparse, seed, depth=8, width=256, n_fine=128, ps
         d['adig_' + k] = digest(v)
     npz(f'f5_train_{tag}', scene=scene, nf=nf, n=n, n_sparse=n_sparse, seed_batch=seed, seed_params=seed + 1,
         scale_params=pscale, depth=depth, width=width, n_fine=n_fine, white_bkgd=white_bkgd, lindisp=lindisp,
+        **({'sample_inds': torch.cat(slog, 0).to(torch.int32)} if slog else {}),
         **{'rng_' + k: v for k, v in rng.items()}, **d)
 
 

@@ -231,6 +231,22 @@ def test_eval_render_golden(dev):
         assert sorted(plain.keys()) == sorted(str(k) for k in g['keys_plain'])     # the reference's eval key set
         inds = model.last_extras['sample_inds']
         assert inds.min() >= 1 and inds.max() <= 63
+        # FREE-RUNNING parity, measured (north_star: "bit-exact for sample indices"): the inverse-CDF indices of the free-running HIP
+        # render -- its own coarse MLP, weights, cdf -- against the indices the reference's own searchsorted returned in this render
+        # Measured (tools/free_running_diag.py): every index of the columns u < 1 agrees; the eval draw u = linspace(0, 1, 128) ends with
+        # u = 1.0 EXACTLY, and searchsorted(cdf, 1.0, right=True) there is decided by whether cdf[-1] -- a 63-term fp32 cumulative sum -- came
+        # out as 1 - 1 ulp, 1 or 1 + 1 ulp: a third of the rays differ by one in that single column (15 of 48 here), with no effect on the
+        # sample (t = 1 in one bin or t = 0 in the next: the same depth), which the fine depths below pin to 2e-6.
+        ref_inds = torch.from_numpy(g['plain_sample_inds'].astype(np.int64))
+        same = inds.cpu().long() == ref_inds
+        agree, agree_open = float(same.float().mean()), float(same[:, :-1].float().mean())
+        print(f'free-running sample indices equal to the reference\'s: {agree:.5f} of {ref_inds.numel()} ({agree_open:.5f} over the columns u < 1)')
+        assert agree_open >= 0.9995 and agree >= 0.99, (agree_open, agree)
+        assert int((inds.cpu().long() - ref_inds).abs().max()) <= 1
+        plain_raw = model(ref_batch(b, dev, 0), retraw=True)
+        dz = float((plain_raw['z_vals_fine'].cpu() - torch.from_numpy(g['out_z_vals_fine'])).abs().max())
+        print(f'free-running fine depths: max abs difference to the reference\'s {dz:.2e} (NDC, [0, 1])')
+        assert dz <= 2e-6
         model.injected_z_fine = cu(g['out_z_vals_fine'], dev)
         out = model(ref_batch(b, dev, 0), retraw=True, sec_views_vis=True)
         model.injected_z_fine = None
@@ -239,10 +255,12 @@ def test_eval_render_golden(dev):
             gk = f'out_{rk}_{lv}'
             if gk in g:
                 assert_close(out[f'{rk}_{lv}'], g[gk], what=f'{rk}_{lv}')
-    # free-running fine pass: report only (ill-conditioned sampler), but it must stay in the same ballpark
-    err = (plain['rgb_fine'].cpu() - torch.from_numpy(g['plain_rgb_fine'])).abs().max().item()
-    print(f'free-running rgb_fine max abs err {err:.3e}')
-    assert err < 5e-3
+    # free-running fine pass, measured against the claim (north_star: rendered RGB within 1e-4 of the reference): max error bounded by the
+    # reference's own fp32-vs-fp64 sensitivity (3e-4), and the share of rays beyond 1e-4 reported and bounded
+    e = (plain['rgb_fine'].cpu() - torch.from_numpy(g['plain_rgb_fine'])).abs().max(dim=-1).values
+    err, beyond = float(e.max()), float((e > 1e-4).float().mean())
+    print(f'free-running rgb_fine: max abs err {err:.3e}, rays beyond 1e-4: {beyond:.4f}')
+    assert err <= 3e-4 and beyond <= 0.05, (err, beyond)
     assert_close(plain['rgb_coarse'], g['plain_rgb_coarse'], what='plain rgb_coarse')
 
 
@@ -294,8 +312,40 @@ def test_train_step_golden(dev, tag):
         if 'grad_' + k in g:
             grad_close(p.grad.cpu().numpy(), g['grad_' + k], f'{tag} grad of {k}')
     opt.step()
+    # The first Adam update is -lr g / (|g| + 1e-8): +-5e-4 whatever the gradient's size, so a bound of one update proves nothing.  Elements
+    # whose reference gradient is above rounding level (|g| > 1e-6: the update's sign and size are then determined to < 1e-8) must land
+    # on the reference's parameter to 1e-6; only the others (an update whose gradient is at rounding level may flip sign) get the loose bound.
+    tight = total = 0
     for k, p in model.named_parameters():
-        np.testing.assert_allclose(digest(p)[2:], g['adig_' + k][2:], rtol=0, atol=1.1e-3, err_msg=f'{tag} Adam step of {k}')
+        after, ref_after, gref = digest(p)[2:], g['adig_' + k][2:], g['gdig_' + k][2:]
+        firm = np.abs(gref) > 1e-6
+        np.testing.assert_allclose(after[firm], ref_after[firm], rtol=0, atol=1e-6, err_msg=f'{tag} Adam step of {k}')
+        np.testing.assert_allclose(after[~firm], ref_after[~firm], rtol=0, atol=1.1e-3, err_msg=f'{tag} Adam step of {k} (rounding-level gradients)')
+        tight += int(firm.sum()); total += firm.size
+    assert tight > 0.5 * total, f'{tag}: only {tight} of {total} sampled parameters have a gradient above rounding level'
+
+
+@pytest.mark.parametrize('tag', ['llff', 'dtu'])
+def test_train_step_free_running_indices_golden(dev, tag):
+    """A TRAINING forward left free-running (the reference's recorded random draws injected, but NOT its fine depths): the inverse-CDF
+    indices the HIP path computes from its own coarse pass against the indices the reference's searchsorted returned (north_star:
+    bit-exact for sample indices), and the fine colour against the reference's."""
+    g = load(f'f5_train_{tag}')
+    b = vo.synthetic_batch(int(g['n']), int(g['seed_batch']), scene=str(g['scene']), nf=int(g['nf']), n_sparse=int(g['n_sparse']))
+    params = vo.init_params(int(g['seed_params']), scale=float(g['scale_params']))
+    model, cfg = make_model(dev, b['ndc'], params)
+    model.train()
+    model.injected_rng = {k[4:]: cu(v, dev) for k, v in g.items() if k.startswith('rng_')}
+    with torch.no_grad():
+        out = model(ref_batch(b, dev, 40000))
+    ref_inds = torch.from_numpy(g['sample_inds'].astype(np.int64))
+    inds = model.last_extras['sample_inds'].cpu().long()
+    agree = float((inds == ref_inds).float().mean())
+    e = (out['rgb_fine'].cpu() - torch.from_numpy(g['out_rgb_fine'])).abs().max(dim=-1).values
+    print(f'{tag}: free-running training indices equal to the reference\'s: {agree:.5f} of {ref_inds.numel()}; rgb_fine max abs err {float(e.max()):.3e}, '
+          f'rays beyond 1e-4: {float((e > 1e-4).float().mean()):.4f}')
+    assert agree >= 0.999
+    assert float(e.max()) <= 3e-4 and float((e > 1e-4).float().mean()) <= 0.05
 
 
 def test_gradients_arrive_in_one_flat_buffer(dev):

@@ -279,6 +279,46 @@ def test_train_step_vs_oracle_1024_rays(dev, prec, scene):
     print(f'{prec} {scene}: worst relative L2 gradient error over 48 tensors at 1024 rays: {worst:.2e}')
 
 
+# single-MFMA 16-bit modes (BASELINE configs[4]'s mixed precision) at 1024 rays: (output rtol, output floor relative to the tensor's max,
+# gradient rel. L2 per tensor, median gradient rel. L2 over the 48 tensors) -- the measured figures (printed by the test) x ~2
+# (measured on MI355X, fern / realestate / dtu: fp16 max output error 1.0e-4 / 1.0e-4 / 1.1e-4 of the tensor's max, gradients median 5e-4 / 1.4e-3 /
+# 2.0e-3, worst tensor 5.5e-3 / 2.6e-2 / 1.4e-2; bf16 outputs 1.9e-3 / 8.6e-4 / 9.8e-4, gradients median 3.4e-3 / 6.0e-3 / 6.8e-3, worst 1.7e-2 / 7.9e-2 / 3.7e-2)
+ARITH16 = {'fp16': (5e-3, 5e-4, 5e-2, 4e-3), 'bf16': (4e-2, 5e-3, 1.5e-1, 1.5e-2)}
+
+
+@pytest.mark.parametrize('prec', list(ARITH16))
+@pytest.mark.parametrize('scene', ['fern', 'realestate', 'dtu'])
+def test_16bit_train_step_vs_oracle_1024_rays(dev, prec, scene):
+    """The single-MFMA 16-bit modes against the CPU oracle at 25x the goldens' size -- fern (NDC, V = 1), realestate (NDC, V = 2, 512
+    sparse-depth rows) and BASELINE configs[4]'s DTU geometry (non-NDC, 3 views: V = 2): all outputs, the losses, every parameter
+    gradient, at the accuracy class of one 16-bit rounding per operand."""
+    nf, n_sparse = {'fern': (2, 0), 'realestate': (3, 512), 'dtu': (3, 0)}[scene]
+    n = 1024 - n_sparse
+    b = vo.synthetic_batch(n, 411, scene=scene, nf=nf, n_sparse=n_sparse)
+    params = vo.init_params(412, scale=1.6)
+    rng = vo.synthetic_rng(1024, 64, 128, 413)
+    cfg_o = {'ndc': b['ndc'], 'n_coarse': 64, 'n_fine': 128, 'noise_std': 1.0}
+    rtol, floor, gtol, gmed = ARITH16[prec]
+    (ref, lref, p), (out, lh, model) = _oracle_and_hip_step(dev, b, params, rng, {}, cfg_o, prec=prec, sparse=n_sparse > 0)
+    worst_out = 0.0
+    for k in ref:
+        if k in out and k not in ('z_vals_coarse', 'z_vals_fine'):
+            a, r = out[k].detach().cpu().double(), ref[k].detach().double()
+            worst_out = max(worst_out, float((a.reshape(r.shape) - r).abs().max() / r.abs().max().clamp_min(1e-30)))
+            if k.startswith('depth'):
+                assert_close_few_outliers(out[k], ref[k], rtol, f'{prec} {scene} {k}', floor=floor)
+            else:
+                tp.assert_close(out[k], ref[k], rtol=rtol, floor=floor, what=f'{prec} {scene} {k}')
+    tp.assert_close(lh['TotalLoss'], lref['TotalLoss'], rtol=4 * rtol, floor=1e-6, what=f'{prec} {scene} TotalLoss')
+    errs = []
+    for k, t in model.named_parameters():
+        tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{prec} {scene} grad {k}', l2_tol=gtol)
+        errs.append(float((t.grad.cpu() - p[k].grad).norm() / p[k].grad.norm()))
+    errs.sort()
+    print(f'{prec} {scene}: max output err / max|ref| {worst_out:.2e}; gradient rel. L2 at 1024 rays: median {errs[len(errs) // 2]:.2e}, worst {errs[-1]:.2e}')
+    assert errs[len(errs) // 2] <= gmed
+
+
 def test_depth_var_cotangents_vs_oracle(dev):
     """depth_var / depth_var_ndc are ordinary differentiable outputs in the reference (VipNeRF01.py:371-377): a loss on
     them must reach the parameters."""
@@ -429,8 +469,12 @@ def test_module_inside_the_reference_trainer_sequence(dev):
         np.testing.assert_allclose(results[True][0][k], results[False][0][k], rtol=2e-5, atol=1e-8, err_msg=k)
     d = float((results[True][3] - results[False][3]).norm() / results[False][3].norm())
     assert d < 1e-5, f'accumulated sub-batch gradients vs whole-batch gradients: {d:.2e}'
-    d = float((results[True][1] - results[False][1]).abs().max())
-    assert d < 1.1e-3, d       # one Adam step of lr 5e-4 (an update whose gradient is at rounding level may flip sign)
+    # one Adam step of lr 5e-4: an update whose gradient is at rounding level may flip sign (<= 2 lr apart), every other parameter
+    # (|g| > 1e-6 in both runs) must land on the same value to 1e-6 -- a bound of one whole update would pass without any step
+    dp = (results[True][1] - results[False][1]).abs()
+    firm = (results[True][3].abs() > 1e-6) & (results[False][3].abs() > 1e-6)
+    assert float(dp.max()) < 1.1e-3 and float(dp[firm].max()) < 1e-6, (float(dp.max()), float(dp[firm].max()))
+    assert float(firm.float().mean()) > 0.5
     sd = results[True][2].state_dict()
     assert all(k.startswith('module.coarse_model.') or k.startswith('module.fine_model.') for k in sd) and len(sd) == 48
 
@@ -565,7 +609,9 @@ def test_other_topologies_vs_oracle(dev, depth, width, scene, nf):
         ev = model(tp.ref_batch(b, dev, 0))
     ro = vo.render_rays(vo.params_to_torch(params), b, cfg_o, None, train=False, sec_views=False)
     tp.assert_close(ev['rgb_coarse'], ro['rgb_coarse'], what='eval rgb_coarse')
-    assert torch.isfinite(ev['rgb_fine']).all() and float((ev['rgb_fine'].cpu() - ro['rgb_fine']).abs().max()) < 5e-3
+    ef = (ev['rgb_fine'].cpu() - ro['rgb_fine']).abs().max(dim=-1).values       # free-running fine pass, measured: see test_eval_render_golden
+    print(f'{depth}x{width}: free-running eval rgb_fine max abs err {float(ef.max()):.3e}, rays beyond 1e-4: {float((ef > 1e-4).float().mean()):.4f}')
+    assert torch.isfinite(ev['rgb_fine']).all() and float(ef.max()) <= 3e-4 and float((ef > 1e-4).float().mean()) <= 0.05
 
 
 # ------------------------------------------------------------------------------------------------ ragged / tiny batches

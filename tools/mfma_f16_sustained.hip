@@ -5,6 +5,8 @@
 //   hipcc --offload-arch=gfx950 -O3 tools/mfma_f16_sustained.hip -o tools/bin/mfma_f16_sustained && tools/bin/mfma_f16_sustained
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -81,7 +83,79 @@ static void run(const char *name, F launch, double flop_per_launch, int seconds)
     }
     printf("  TFLOP/s per 1-s window (nominal 2500)\n");
 }
+// ---- burst mode (round 3: which ceiling applies to a 1-10 ms kernel?) --------------------------------------------------------------
+// `mfma_f16_sustained burst`: ONE launch of the 16x16x32 f16 loop per measurement, of 0.05 ... 1000 ms, after 200 ms of idle (the chip
+// starts cool, at full clock), with operands that are all ZERO (what a peak micro-benchmark typically multiplies: no operand bit toggles)
+// or data-like; then the same launch repeated back to back for 2 s with a duty cycle (burst, idle gap) like a kernel inside a training step.
+#include <chrono>
+#include <thread>
+template <bool ZERO>
+__global__ __launch_bounds__(512) void kburst(float *out, int iters) {
+    half8 a[4], b[4];
+    for (int i = 0; i < 4; ++i) {
+        a[i] = make_operand(threadIdx.x * 8 + i + blockIdx.x * 977); b[i] = make_operand(threadIdx.x * 8 + 4 + i);
+        if (ZERO) for (int e = 0; e < 8; ++e) { a[i][e] = (_Float16)(out[0] * 0.f); b[i][e] = a[i][e]; }     // (run-time zero: not folded away)
+    }
+    floatx4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = (floatx4)(0.f);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(i + u) & 3], b[(i >> 1) & 3], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+template <bool ZERO>
+static void bursts(float *out) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int grid = 256 * 8;
+    hipMemset(out, 0, 256 * 8 * 512 * sizeof(float));
+    hipLaunchKernelGGL(kburst<ZERO>, dim3(grid), dim3(512), 0, 0, out, 10); hipDeviceSynchronize();
+    printf("%s operands, one launch after 200 ms idle: ms -> TFLOP/s (3 repeats)\n", ZERO ? "ZERO" : "data-like");
+    for (int iters : {30, 100, 300, 1000, 3000, 10000, 30000, 100000, 600000}) {
+        const double flop = (double)grid * 8 * iters * 16 * 16384.0;
+        printf("  iters %6d:", iters);
+        for (int r = 0; r < 3; ++r) {
+            std::this_thread::sleep_for(std::chrono::milliseconds(200));
+            float ms = 0.f;
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(kburst<ZERO>, dim3(grid), dim3(512), 0, 0, out, iters);
+            hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+            printf("  %8.3f ms %5.0f", ms, flop / (ms * 1e-3) / 1e12);
+        }
+        printf("\n");
+    }
+    // duty cycle: a ~3 ms burst every ~10 ms for 2 s (the MLP kernel of a 16-bit training step), rate of the bursts themselves
+    for (int gap_ms : {0, 3, 7}) {
+        const int iters = 5000;
+        const double flop = (double)grid * 8 * iters * 16 * 16384.0;
+        double tot_ms = 0; int n = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        double last = 0;
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 2.0) {
+            float ms = 0.f;
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(kburst<ZERO>, dim3(grid), dim3(512), 0, 0, out, iters);
+            hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+            tot_ms += ms; ++n; last = ms;
+            if (gap_ms) std::this_thread::sleep_for(std::chrono::milliseconds(gap_ms));
+        }
+        printf("  duty cycle: %.2f ms bursts with %d ms gaps for 2 s: mean %5.0f TFLOP/s over %d bursts (last burst %5.0f)\n", tot_ms / n, gap_ms,
+               flop * n / (tot_ms * 1e-3) / 1e12, n, flop / (last * 1e-3) / 1e12);
+    }
+}
 int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "burst")) {
+        float *o;
+        hipMalloc(&o, 256 * 8 * 512 * sizeof(float));
+        bursts<true>(o);
+        bursts<false>(o);
+        return 0;
+    }
     const int seconds = argc > 1 ? atoi(argv[1]) : 6;
     float *out;
     hipMalloc(&out, 256 * 8 * 512 * sizeof(float));

@@ -148,6 +148,12 @@ __device__ __forceinline__ void split8(const float (&x)[8], f32q (&out)[NS]) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) out[e >> 2].v[e & 3] = x[e];
 }
+// NPT point tiles of one wave that share every A fragment (the 32-point single-MFMA layout, vipnerf_mlp_pt2.h): the B operand of a
+// k-step is NPT fragments, an accumulator tile NPT C/D tiles, and a cell is NPT MFMAs per A-fragment read
+template <typename FR, int NPT> struct BOp { FR v[NPT]; };
+template <int NPT> struct AccN { floatx4 v[NPT]; };
+template <typename T> struct FragTypeOf { typedef T type; static constexpr int npt = 1; };
+template <typename FR, int NPT> struct FragTypeOf<BOp<FR, NPT>> { typedef FR type; static constexpr int npt = NPT; };
 // MFMAs per (k-step, tile) cell
 template <typename FR, int NS> struct CellMfmas { static constexpr int value = NS * (NS + 1) / 2; };
 template <int NS> struct CellMfmas<f32q, NS> { static constexpr int value = 4 * NS; };
@@ -176,6 +182,14 @@ __device__ __forceinline__ ACC mfma_split(const FR (&a)[NS], const FR (&b)[NS], 
     return c;
 }
 
+template <int NS, typename FR, int NPT>
+__device__ __forceinline__ AccN<NPT> mfma_split(const FR (&a)[NS], const BOp<FR, NPT> (&b)[NS], AccN<NPT> c) {
+    static_assert(NS == 1, "point-tile pairs: single-MFMA modes");
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) c.v[pt] = mfma_bf(a[0], b[0].v[pt], c.v[pt]);
+    return c;
+}
+
 // Weight stream: a ring of NBUF LDS stage buffers filled by LDS-DMA NBUF-1 stages ahead of the consumer.
 //   wait():     counted s_waitcnt (this wave's DMA of the stage to consume has landed; with NBUF > 2 the younger
 //               stages' stay in flight: VM_CNT retires in issue order, stores included) + raw s_barrier (every
@@ -197,6 +211,8 @@ struct WStreamT {
     int lane, wave;
     int turn;              // ROTATE: the wave that issues the next stage's DMA
     int cturn;             // ROTATE: the wave that issued the stage about to be consumed
+    bool counted;          // false: this wave's YOUNGER bounds do not hold (a wave whose points are out of range skips its predicated
+                           // stores): it drains with vmcnt(0) instead
     static constexpr int SF = CH * CHUNK_F;
     static constexpr int PER_WAVE = ROTATE ? CH : CH / WAVES;
     static_assert(CH % WAVES == 0 && (NBUF == 2 || PER_WAVE * (NBUF - 2) <= 63), "vmcnt is a 6-bit counter");
@@ -216,7 +232,7 @@ struct WStreamT {
         fill = fill + 1 == NBUF ? 0 : fill + 1;
     }
     __device__ __forceinline__ void start(const float *stream, int n_stages, float *lds_buf, int lane_, int wave_) {
-        g = stream; buf = lds_buf; n_left = n_stages; in_flight = 0; cur = 0; fill = 0; lane = lane_; wave = wave_; turn = 0; cturn = 0;
+        g = stream; buf = lds_buf; n_left = n_stages; in_flight = 0; cur = 0; fill = 0; lane = lane_; wave = wave_; turn = 0; cturn = 0; counted = true;
 #pragma unroll
         for (int i = 0; i < NBUF - 1; ++i)
             if (n_left > 0) fetch();
@@ -237,7 +253,8 @@ struct WStreamT {
         if (NBUF == 2 && STAGGER) {
             // every wave drains its own share (counted: its younger stores stay in flight), bare barrier
             __builtin_amdgcn_sched_barrier(0);
-            if (YOUNGER_FIRST != YOUNGER && first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER_FIRST) : "memory");
+            if (!counted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (YOUNGER_FIRST != YOUNGER && first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER_FIRST) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -251,7 +268,8 @@ struct WStreamT {
             // after the issuer's drain publishes it.
             __builtin_amdgcn_sched_barrier(0);
             if (wave == cturn) {
-                if (YOUNGER_FIRST != YOUNGER && first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER_FIRST) : "memory");
+                if (!counted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (YOUNGER_FIRST != YOUNGER && first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER_FIRST) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
             }
             cturn = cturn + 1 == WAVES ? 0 : cturn + 1;
@@ -301,12 +319,13 @@ struct NoMid {
     template <int g, int NG> static constexpr bool active() { return false; }
     template <int g, int NG> __device__ __forceinline__ void at() const {}
 };
-template <int g, int NG, int NT, int NS, int G, int D, int NBUF, int NB, typename WS, typename ACC, typename FR, typename MIDF>
-__device__ __forceinline__ void gemm_groups_bf(const float *base, ACC (&acc)[NT], const FR (&B)[NB][NS], int ks0,
-                                               FR (&fr)[NBUF][G][NS], WS &ws, MIDF &mid) {
+template <int g, int NG, int NT, int NS, int G, int D, int NBUF, int NB, typename WS, typename ACC, typename BT, typename MIDF>
+__device__ __forceinline__ void gemm_groups_bf(const float *base, ACC (&acc)[NT], const BT (&B)[NB][NS], int ks0,
+                                               typename FragTypeOf<BT>::type (&fr)[NBUF][G][NS], WS &ws, MIDF &mid) {
+    typedef typename FragTypeOf<BT>::type FR;
     if constexpr (g < NG) {
         constexpr int R = (g + D < NG) ? G * NS : 0;           // ds_read_b128 in this group
-        constexpr int M = G * CellMfmas<FR, NS>::value;        // MFMAs in this group
+        constexpr int M = G * CellMfmas<FR, NS>::value * FragTypeOf<BT>::npt;        // MFMAs in this group
         if (g + D < NG) {
 #pragma unroll
             for (int tt = 0; tt < G; ++tt)
@@ -351,14 +370,16 @@ struct NoStream {
     __device__ __forceinline__ void prefetch() {}
     template <int g, int NG> __device__ __forceinline__ void prefetch_at() {}
 };
-template <int NT, int NKS, int NS, int NB, typename WS, typename ACC, typename FR, typename MIDF>
+template <int NT, int NKS, int NS, int NB, typename WS, typename ACC, typename BT, typename MIDF>
 __device__ __forceinline__ void gemm_stage_bf(const float *stage, int lane, ACC (&acc)[NT],
-                                              const FR (&B)[NB][NS], int ks0, WS &ws, MIDF &mid) {
+                                              const BT (&B)[NB][NS], int ks0, WS &ws, MIDF &mid) {
+    typedef typename FragTypeOf<BT>::type FR;
     // narrow layout (floatx4 accumulators, 256 registers per wave) in bf16x6: one tile per group, two groups ahead
     constexpr bool TIGHT = sizeof(ACC) == 16 && NS == 3;
     // single-MFMA modes (NS == 1): a cell is ONE 16-cycle MFMA, so groups of four tiles, two groups (128 cycles of this wave's
-    // MFMAs, twice that with its SIMD partner's in between) ahead of the LDS latency
-    constexpr int G = TIGHT ? 1 : (NS == 1 ? 4 : 2);
+    // MFMAs, twice that with its SIMD partner's in between) ahead of the LDS latency; with two point tiles per wave a cell is two
+    // MFMAs: groups of two tiles (the same 128 cycles, half the fragment registers)
+    constexpr int G = TIGHT ? 1 : (NS == 1 ? (FragTypeOf<BT>::npt == 2 ? 2 : 4) : 2);
     constexpr int D = (NS == 2 || TIGHT || NS == 1) ? 2 : 1;
     constexpr int NBUF = D + 1;
     constexpr int NG = NKS * NT / G;
@@ -374,9 +395,9 @@ __device__ __forceinline__ void gemm_stage_bf(const float *stage, int lane, ACC 
     __builtin_amdgcn_sched_barrier(0);
     gemm_groups_bf<0, NG, NT, NS, G, D, NBUF>(base, acc, B, ks0, fr, ws, mid);
 }
-template <int NT, int NKS, int NS, int NB, typename WS, typename ACC, typename FR>
+template <int NT, int NKS, int NS, int NB, typename WS, typename ACC, typename BT>
 __device__ __forceinline__ void gemm_stage_bf(const float *stage, int lane, ACC (&acc)[NT],
-                                              const FR (&B)[NB][NS], int ks0, WS &ws) {
+                                              const BT (&B)[NB][NS], int ks0, WS &ws) {
     NoMid none;
     gemm_stage_bf<NT, NKS, NS>(stage, lane, acc, B, ks0, ws, none);
 }

@@ -179,6 +179,8 @@ template <typename PL> struct StreamOf<PL, true> { typedef WStreamSkew<PL::CH> t
 // EVAL kernel (0.887 -> 0.903 of the fp32 peak: no stores whose latency that vmcnt(0) would sit out, and no single wave 64 pieces
 // behind at the barrier); neutral for the 16-bit eval kernels, and a loss for every training kernel (their stores)
 template <typename PL> struct StreamShared { typedef WStreamT<PL::CH, PL::NBUF, PL::WAVES, false, false> type; };
+template <typename WS> __device__ __forceinline__ void stream_counted(WS &w, bool on) { w.counted = on; }
+template <int CH> __device__ __forceinline__ void stream_counted(WStreamSkew<CH> &, bool) {}
 __device__ __forceinline__ void stream_begin(...) {}
 __device__ __forceinline__ void stream_end(...) {}
 template <int CH> __device__ __forceinline__ void stream_begin(WStreamSkew<CH> &w) { w.begin(); }
@@ -369,6 +371,65 @@ struct DeferredStores {
         }
     }
 };
+
+// ---- positional encodings in the narrow layout's slot order (forward kernels)
+__device__ __forceinline__ float pow2f(int l) { return __uint_as_float((unsigned)(127 + l) << 23); }
+
+// gamma(x) in the slot order of pe_feat16 (vipnerf_bf16n.h): lane group q evaluates levels (5q)>>1 .. +2 only.
+// out[s][e], u = 8s + e: u = 3 gg + d < 15 -> triple gg of this lane group, component d; u = 15 -> x[q] / unused
+__device__ __forceinline__ void encode_x16(const float v[3], int q, float (&out)[2][8]) {
+    const int lb = (5 * q) >> 1;
+    float S[3][3], C[3][3];
+#pragma unroll
+    for (int li = 0; li < 3; ++li) {
+        const float f = pow2f(lb + li);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+#if defined(VN_EXP) && VN_EXP == 7
+            S[li][d] = v[d] * f; C[li][d] = S[li][d] + 1.f;   // timing experiment only: no sincos
+#else
+            sincosf(v[d] * f, &S[li][d], &C[li][d]);
+#endif
+        }
+    }
+    const bool odd = q & 1;           // 5q even: triples are S0 C0 S1 C1 S2;  odd: C0 S1 C1 S2 C2
+    float val[16];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        val[0 + d] = odd ? C[0][d] : S[0][d];
+        val[3 + d] = odd ? S[1][d] : C[0][d];
+        val[6 + d] = odd ? C[1][d] : S[1][d];
+        val[9 + d] = odd ? S[2][d] : C[1][d];
+        val[12 + d] = odd ? C[2][d] : S[2][d];
+    }
+    val[15] = q == 0 ? v[0] : (q == 1 ? v[1] : (q == 2 ? v[2] : 0.f));
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[s][e] = val[8 * s + e];
+}
+// gamma(dir) in the slot order of dir_feat16: lane group q evaluates level q only
+__device__ __forceinline__ void encode_d16(const float v[3], int q, float (&out)[1][8]) {
+    const float f = pow2f(q);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) sincosf(v[d] * f, &out[0][d], &out[0][3 + d]);
+    out[0][6] = q == 0 ? v[0] : (q == 1 ? v[2] : 0.f);
+    out[0][7] = q == 0 ? v[1] : 0.f;
+}
+// natural-order rows of the activation store ([P][64] / [P][32], read by the weight-gradient GEMMs)
+__device__ __forceinline__ void store_x16(float *row, int q, const float (&pe)[2][8]) {
+#pragma unroll
+    for (int u = 0; u < 15; ++u) row[3 + 15 * q + u] = pe[u >> 3][u & 7];
+    row[q < 3 ? q : DPE] = pe[1][7];                       // x[q]; lane group 3 writes the zero pad column
+}
+__device__ __forceinline__ void store_d16(float *row, int q, const float (&pd)[1][8]) {
+#pragma unroll
+    for (int e = 0; e < 6; ++e) row[3 + 6 * q + e] = pd[0][e];
+    if (q == 0) { row[0] = pd[0][6]; row[1] = pd[0][7]; }
+    else if (q == 1) row[2] = pd[0][6];
+    else if (q == 2) { row[DVE] = 0.f; row[DVE + 1] = 0.f; }
+    else { row[DVE + 2] = 0.f; row[DVE + 3] = 0.f; row[DVE + 4] = 0.f; }
+}
 
 template <bool F16, bool F32 = false> struct FragOf { typedef bf16x8 type; };
 template <> struct FragOf<true, false> { typedef half8 type; };

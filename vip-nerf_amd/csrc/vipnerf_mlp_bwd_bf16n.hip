@@ -80,6 +80,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
 
     typename StreamOf<PL, PL::SKEW>::type ws;
     ws.start(a.packed + PL::PK_BWD, PL::B_STAGES, stage_buf, lane, wave);
+    stream_counted(ws, !T16 || valid);      // a wave beyond P skips its (predicated) T16 stores: its counted waits would not hold
     {
         const float4 *g4 = (const float4 *)(a.packed + PL::PK_RES);
         float4 *l4 = (float4 *)res;

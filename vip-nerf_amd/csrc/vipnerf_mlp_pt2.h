@@ -1,0 +1,43 @@
+// The single-MFMA 16-bit MLP kernels with two point tiles per wave (vipnerf_mlp_fwd_pt2.hip, vipnerf_mlp_bwd_pt2.hip): shared pieces.
+#pragma once
+#include "vipnerf_bf16n.h"
+#include "vipnerf_mlp.h"
+
+#ifndef VN_PT2
+#define VN_PT2 1            // 0: the 16-point kernels (k_mlp_fwd_bf16n / k_mlp_bwd_bf16n with NS = 1, H16 = 4) for VIPNERF_PREC_FP16 / BF16
+#endif
+
+namespace vn {
+
+constexpr int PT2_PTS_PER_WG = 256;       // 8 waves x 2 point tiles x 16 points
+
+#if defined(__HIPCC__)
+// The deferred T16 stores of one weight stage, both point tiles: the part-0 B fragments of NSTEP k-steps of the layer input (= the
+// previous layer's output, or the gradient the running GEMM consumes), behind the stage's last MFMA group.  4 NSTEP store
+// instructions per wave when both tiles are in range (what the counted waits of the stream assume; WStreamT::counted otherwise).
+template <typename FR, int NSTEP>
+struct DeferredT16 {
+    float *dst;
+    int64_t grp[2];
+    bool valid[2];
+    int j, q, s0;
+    const BOp<FR, 2> (*bin)[1];
+    template <int g, int NG> static constexpr bool active() { return g == NG - 1; }
+    template <int g, int NG>
+    __device__ __forceinline__ void at() const {
+        if (EXP_NO_STORES) return;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            if (valid[pt]) {
+#pragma unroll
+                for (int s = s0; s < s0 + NSTEP; ++s) store_t16(dst, grp[pt], 16, s, j, q, bin[s][0].v[pt]);
+            }
+        }
+    }
+};
+#endif
+
+int launch_mlp_fwd_pt2(const MlpFwdArgs &a, int precision, hipStream_t st);
+int launch_mlp_bwd_pt2(const MlpBwdArgs &a, int precision, hipStream_t st);
+
+}  // namespace vn

@@ -3,6 +3,7 @@
 // current dY; ReLU masks are the 64 bits per lane and layer the narrow forward wrote.
 #include "vipnerf_bf16n.h"
 #include "vipnerf_mlp.h"
+#include "vipnerf_mlp_pt2.h"
 
 #ifndef VN_F32_DEFER
 #define VN_F32_DEFER 1
@@ -268,6 +269,7 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
     if (precision == 0) return launch_one_bwd_n<2, false, VN_F32_DEFER ? 3 : 0, true>(a, grid, st);
     if (precision == 1) return launch_one_bwd_n<2>(a, grid, st);
     if (precision == 2) return launch_one_bwd_n<3>(a, grid, st);
+    if (precision == 6 && VN_PT2 && stores_t16(precision)) return launch_mlp_bwd_pt2(a, precision, st);     // two point tiles per wave
     if (precision == 6) return launch_one_bwd_n<1, false, VN_BF16_H16 ? (VN_T16 ? 4 : 1) : 0>(a, grid, st);
     if (precision == 3 || precision == 4 || precision == 5) {
         // the level's largest seed first (one pass over 5+V floats per point)
@@ -278,6 +280,7 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
         VN_HIP(hipGetLastError());
         MlpBwdArgs b = a;
         b.gmax = slot;
+        if (precision == 5 && VN_PT2 && stores_t16(precision)) return launch_mlp_bwd_pt2(b, precision, st);
         if (precision == 5) return launch_one_bwd_n<1, true, VN_T16 ? 4 : 1>(b, grid, st);
         return precision == 4 ? launch_one_bwd_n<2, true, 1>(b, grid, st) : launch_one_bwd_n<2, true, VN_F16_PRESPLIT ? 2 : 0>(b, grid, st);
     }

@@ -380,7 +380,10 @@ __device__ __forceinline__ void gemm_stage_bf(const float *stage, int lane, ACC 
     // MFMAs, twice that with its SIMD partner's in between) ahead of the LDS latency; with two point tiles per wave a cell is two
     // MFMAs: groups of two tiles (the same 128 cycles, half the fragment registers)
     constexpr int G = TIGHT ? 1 : (NS == 1 ? (FragTypeOf<BT>::npt == 2 ? 2 : 4) : 2);
-    constexpr int D = (NS == 2 || TIGHT || NS == 1) ? 2 : 1;
+#ifndef VN_PT2_D
+#define VN_PT2_D 2
+#endif
+    constexpr int D = FragTypeOf<BT>::npt == 2 ? VN_PT2_D : ((NS == 2 || TIGHT || NS == 1) ? 2 : 1);
     constexpr int NBUF = D + 1;
     constexpr int NG = NKS * NT / G;
     static_assert(NT % G == 0 && NG >= D, "group shape");

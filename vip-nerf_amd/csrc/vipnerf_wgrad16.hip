@@ -168,7 +168,7 @@ static int launch_wg16(const WgArgs &args, int n_desc, int n_chunks, hipStream_t
 
 template <bool BF>
 static int launch_all(const WgArgs &big, int nbig, int n_chunks, const WgArgs &pe, int npe, int n_pe, const WgArgs &vf, int nvf, const WgArgs &sg, int nsg,
-                      int n_single, const WgArgs &vd, int nvd, const WgArgs &oh, int noh, int n_thin, hipStream_t st) {
+                      int n_single, const WgArgs &vd, int nvd, int n_vd, const WgArgs &oh, int noh, int n_oh, hipStream_t st) {
     int rc;
     {
         ProfScope ps("wgrad_256x256", st);
@@ -178,17 +178,31 @@ static int launch_all(const WgArgs &big, int nbig, int n_chunks, const WgArgs &p
     if ((rc = launch_wg16<BF, 16, 4, 4, 1, 3>(pe, npe, n_pe, st))) return rc;
     if ((rc = launch_wg16<BF, 8, 16, 2, 2, 3>(vf, nvf, n_single, st))) return rc;
     if ((rc = launch_wg16<BF, 1, 16, 1, 4, 4>(sg, nsg, n_single, st))) return rc;
-    if ((rc = launch_wg16<BF, 8, 2, 4, 1, 4>(vd, nvd, n_thin, st))) return rc;
-    return launch_wg16<BF, 1, 8, 1, 4, 4>(oh, noh, n_thin, st);
+    if ((rc = launch_wg16<BF, 8, 2, 4, 1, 4>(vd, nvd, n_vd, st))) return rc;
+    return launch_wg16<BF, 1, 8, 1, 4, 4>(oh, noh, n_oh, st);
 }
 
 int launch_wgrad16(size_t P, int V, const float *acts, const ActLayout &al, float *bwd, const BwdLayout &bl,
                    const vipnerf_mlp_grads *G, int precision, hipStream_t st, const unsigned *gmax) {
     if (P == 0) return VIPNERF_OK;
     if (P % 32) { set_error("wgrad16: %zu points (a multiple of 32 is required)", P); return VIPNERF_E_UNSUPPORTED; }
-    const int n_chunks = wgrad_chunks(P), n_pe = wgrad_chunks_split(P, WGRAD_SPLIT_PE), n_thin = wgrad_chunks_split(P, WGRAD_SPLIT_THIN),
-              n_single = wgrad_chunks_split(P, WGRAD_SINGLE_SPLIT);
-    const int chunk_pts = wgrad_chunk_pts(P);
+    // Point chunks: ONE round of workgroups per launch where the level is large enough -- (workgroups a CU holds of the class) x 256 CUs
+    // over the launch's GEMMs -- and never more chunks than the plan the partial buffer was sized for (vipnerf_common.h): every chunk
+    // costs a partial product written and read back by the reduction (a 256 x 64 partial is 66 KB against 640 B of operands per point).
+    struct Plan { int n, pts; };
+    auto plan = [&](int n_old, int pts_old, int slots, int n_desc) {
+        const int target = slots / n_desc;
+        if (target >= n_old) return Plan{n_old, pts_old};
+        const int pts = (int)(((P + target - 1) / target + 31) / 32 * 32);
+        return Plan{(int)((P + pts - 1) / pts), pts};
+    };
+    const int cp0 = wgrad_chunk_pts(P);
+    const Plan pb = plan(wgrad_chunks(P), cp0, 256, 8);
+    const Plan pp = plan(wgrad_chunks_split(P, WGRAD_SPLIT_PE), cp0 / WGRAD_SPLIT_PE, 512, 2);
+    const Plan psg = plan(wgrad_chunks_split(P, WGRAD_SINGLE_SPLIT), cp0 / WGRAD_SINGLE_SPLIT, 512, 1);
+    const Plan pd = plan(wgrad_chunks_split(P, WGRAD_SPLIT_THIN), cp0 / WGRAD_SPLIT_THIN, 768, 1 + V);
+    const Plan po = plan(wgrad_chunks_split(P, WGRAD_SPLIT_THIN), cp0 / WGRAD_SPLIT_THIN, 1024, 1 + V);
+    const int n_chunks = pb.n, n_pe = pp.n, n_single = psg.n, n_vd = pd.n, n_oh = po.n;
     float *partial = bwd + bl.partial;
 
     WgArgs big, pe, vf, sg, vd, oh;            // 256x256 x8 | 256x64 (gamma(x) columns) x2 | 128x256 | sigma head 16x256 | 128x32 per direction | 16x128 per direction
@@ -198,8 +212,7 @@ int launch_wgrad16(size_t P, int V, const float *acts, const ActLayout &al, floa
     red.gmax = gmax;
     size_t off = 0;
     auto init = [&](WgArgs &w, int cp) { w.P = (int64_t)P; w.chunk_pts = cp; w.partial = partial; };
-    init(big, chunk_pts); init(pe, chunk_pts / WGRAD_SPLIT_PE); init(vf, chunk_pts / WGRAD_SINGLE_SPLIT); init(sg, chunk_pts / WGRAD_SINGLE_SPLIT);
-    init(vd, chunk_pts / WGRAD_SPLIT_THIN); init(oh, chunk_pts / WGRAD_SPLIT_THIN);
+    init(big, pb.pts); init(pe, pp.pts); init(vf, psg.pts); init(sg, psg.pts); init(vd, pd.pts); init(oh, po.pts);
     auto add = [&](WgArgs &w, int &n, int chunks, int Mp, int Np, const float *A, const float *B) {
         WgDesc &d = w.d[n++];
         d.A = A; d.lda = Mp; d.m_load = Mp; d.B = B; d.ldb = Np; d.k_load = Np;
@@ -251,20 +264,20 @@ int launch_wgrad16(size_t P, int V, const float *acts, const ActLayout &al, floa
     {   // view layer, direction columns (gamma(dir) in slot order) and the output head: one GEMM per direction, summed in order
         size_t first_d = 0, first_o = 0;
         for (int k = 0; k <= V; ++k) {
-            const size_t o = add(vd, nvd, n_thin, 128, 32, bwd + bl.dyv[k], acts + al.ped[k]);
+            const size_t o = add(vd, nvd, n_vd, 128, 32, bwd + bl.dyv[k], acts + al.ped[k]);
             if (k == 0) first_d = o;
         }
-        group(n_thin, first_d, 1 + V, 128, 32, WV, 32, G->g[P_VW], W + DVE, W, nullptr, 2);
+        group(n_vd, first_d, 1 + V, 128, 32, WV, 32, G->g[P_VW], W + DVE, W, nullptr, 2);
         for (int k = 0; k <= V; ++k) {
-            const size_t o = add(oh, noh, n_thin, 16, 128, bwd + bl.dq[k], acts + al.g[k]);
+            const size_t o = add(oh, noh, n_oh, 16, 128, bwd + bl.dq[k], acts + al.g[k]);
             if (k == 0) first_o = o;
         }
-        group(n_thin, first_o, 1 + V, 16, 128, 4, WV, G->g[P_OW], WV, 0, G->g[P_OB]);
+        group(n_oh, first_o, 1 + V, 16, 128, 4, WV, G->g[P_OW], WV, 0, G->g[P_OB]);
     }
     if (off > wgrad_partial_total(P, V)) { set_error("wgrad16: partial buffer plan mismatch"); return VIPNERF_E_ARG; }
 
-    int rc = precision == VIPNERF_PREC_BF16 ? launch_all<true>(big, nbig, n_chunks, pe, npe, n_pe, vf, nvf, sg, nsg, n_single, vd, nvd, oh, noh, n_thin, st)
-                                            : launch_all<false>(big, nbig, n_chunks, pe, npe, n_pe, vf, nvf, sg, nsg, n_single, vd, nvd, oh, noh, n_thin, st);
+    int rc = precision == VIPNERF_PREC_BF16 ? launch_all<true>(big, nbig, n_chunks, pe, npe, n_pe, vf, nvf, sg, nsg, n_single, vd, nvd, n_vd, oh, noh, n_oh, st)
+                                            : launch_all<false>(big, nbig, n_chunks, pe, npe, n_pe, vf, nvf, sg, nsg, n_single, vd, nvd, n_vd, oh, noh, n_oh, st);
     if (rc) return rc;
     ProfScope ps("wgrad_small", st);
     return launch_wgrad_reduce(red, ng, st);

@@ -29,6 +29,9 @@ __device__ __forceinline__ int wg_off(int f, int slot) {
     return row * 64 + ((slot ^ (((f & 3) ^ (f >> 4)) & 3)) << 4);
 }
 
+#ifndef VN_WGRAD_DMA
+#define VN_WGRAD_DMA 0          // exact-fp32 256 x 256 weight gradients: 1 = operand blocks HBM -> LDS by DMA instead of through registers -- built, correct, and measured SLOWER (9.10 vs 8.22 ms per step: DESIGN.md 5); off
+#endif
 #ifndef VN_WGRAD_W8
 #define VN_WGRAD_W8 2            // exact-fp32 256 x 256 weight gradients: 0 = the 4-wave k_wgrad<2,8,4>; 2 / 4 = k_wgrad256_w8 with 8 / 16 waves
 #endif
@@ -202,11 +205,34 @@ __global__ __launch_bounds__(256 * WK) void k_wgrad256_w8(WgArgs a) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) { la[tid + NTH * i] = ra[i]; lb[tid + NTH * i] = rb[i]; }
     };
-    if (nblk > 0) { gload(0); lstore(0); }
-    __syncthreads();
+    // VN_WGRAD_DMA (round 3): when both operands are whole [P][256] arrays and the chunk is whole 32-point blocks (the render path:
+    // always), a block's 32 KiB + 32 KiB are contiguous in HBM and go HBM -> LDS by DMA (global_load_lds_dwordx4; the row-major LDS
+    // tile IS the HBM image) instead of through registers: no ds_write_b128 phase in front of the block barrier, no staging registers.
+    const bool dma = VN_WGRAD_DMA && linA && linB && (p1 - p0) % 32 == 0;
+    auto issue = [&](int blk, int buf) {
+        const float *ga = d.A + (size_t)(p0 + (int64_t)blk * 32) * Mp + lane * 4, *gb = d.B + (size_t)(p0 + (int64_t)blk * 32) * Kp + lane * 4;
+        constexpr int PER_WAVE = 64 / (4 * WK);              // 1 KiB pieces per wave: 32 of A and 32 of B over 4 WK waves
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int pc = wave * PER_WAVE + i;              // pieces 0..31: A, 32..63: B
+            const float *src = pc < 32 ? ga + pc * 256 : gb + (pc - 32) * 256;
+            glds_chunks<1>(src, __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds + buf * TILE_F + pc * 256)));
+        }
+    };
+    if (dma) {
+        if (nblk > 0) issue(0, 0);
+    } else {
+        if (nblk > 0) { gload(0); lstore(0); }
+        __syncthreads();
+    }
     int cur = 0;
     for (int blk = 0; blk < nblk; ++blk) {
-        if (blk + 1 < nblk) gload(blk + 1);
+        if (dma) {
+            glds_drain();                                    // this wave's pieces of block blk (issued one block ago)
+            __builtin_amdgcn_s_barrier();                    // every wave's pieces are in, every wave is done with the other buffer
+            asm volatile("" ::: "memory");
+            if (blk + 1 < nblk) issue(blk + 1, cur ^ 1);
+        } else if (blk + 1 < nblk) gload(blk + 1);
         const float *la = lds + cur * TILE_F, *lb = la + 32 * Mp;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -222,8 +248,10 @@ __global__ __launch_bounds__(256 * WK) void k_wgrad256_w8(WgArgs a) {
                 for (int j = 0; j < KTW; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
             }
         }
-        if (blk + 1 < nblk) lstore(cur ^ 1);
-        __syncthreads();
+        if (!dma) {
+            if (blk + 1 < nblk) lstore(cur ^ 1);
+            __syncthreads();
+        }
         cur ^= 1;
     }
     float *part = a.partial + d.part_off + (size_t)blockIdx.x * d.part_stride;

@@ -409,8 +409,10 @@ def main():
     main_wl = Workload(args.workload, rays, args.precision)
     model = main_wl.model
     elapsed, prof, sclk = main_wl.timed_run(args.precision)
-    also = [] if (args.no_other_precisions or world > 1) else \
-        ([p for p in ARITH if p != args.precision] if args.also == 'all' else [p for p in args.also.split(',') if p and p != args.precision])
+    # N > 1 (the driver's scaling runs): `value` plus the configs[4] arithmetic only, unless --also is given explicitly
+    also_arg = args.also if (world == 1 or '--also' in sys.argv) else 'bf16'
+    also = [] if args.no_other_precisions else \
+        ([p for p in ARITH if p != args.precision] if also_arg == 'all' else [p for p in also_arg.split(',') if p and p != args.precision])
     others = {p: main_wl.timed_run(p) for p in also}
     model.configs['model']['hip_precision'] = args.precision
 
@@ -448,19 +450,20 @@ def main():
 
     render = None if args.no_render else render_bench()          # every rank: its strip of the frame
 
-    # BASELINE configs[4] at its per-GPU shard size (single-process runs only; the 8-GPU statement itself is
-    # `--workload dtu --scaling strong --precision bf16` under torch.distributed.run)
+    # BASELINE configs[4] at its per-GPU shard size, every rank its own 16,384 rays: at N = 8 this IS configs[4]'s statement (131,072 rays
+    # per iteration ray-sharded over 8 GPUs, one all-reduce per step); `--workload dtu --scaling strong --precision bf16` puts it into `value`
     c4 = None
-    if world == 1 and not args.no_configs4 and not (args.workload == 'dtu' and rays == args.configs4_rays):
+    if not args.no_configs4 and not (args.workload == 'dtu' and rays == args.configs4_rays):
         main_wl.release()
         wl4 = Workload('dtu', args.configs4_rays, 'bf16')
         c4 = {'workload': 'BASELINE configs[4] per-GPU shard: DTU geometry (non-NDC), 3 views (V = 2 secondary views), 131,072 / 8 = %d rays/iter x '
                           '(64+128) samples, coarse+fine 8x256 MLP, mixed precision (16-bit MFMA operands and activation storage, fp32 master '
-                          'weights / accumulation / losses), fused Adam' % args.configs4_rays, 'rays_per_gpu': args.configs4_rays}
-        for p in ('bf16', 'fp16'):
+                          'weights / accumulation / losses), fused Adam' % args.configs4_rays, 'rays_per_gpu': args.configs4_rays,
+              'global_rays': args.configs4_rays * world, 'n_gpus': world}
+        for p in (('bf16', 'fp16') if world == 1 else ('bf16',)):
             el, pr, sc = wl4.timed_run(p)
             pms = el / args.steps * 1e3
-            c4[p] = {'value': round(args.configs4_rays * args.steps / el, 1), 'unit': 'rays/s', 'ms_per_step': round(pms, 3), 'dtype': ARITH[p][0],
+            c4[p] = {'value': round(args.configs4_rays * world * args.steps / el, 1), 'unit': 'rays/s', 'ms_per_step': round(pms, 3), 'dtype': ARITH[p][0],
                      'roofline': roofline_block(p, pr, args.steps, args.configs4_rays, pms, sc, n_sec=wl4.n_sec, workload='dtu')}
         wl4.release()
 
@@ -488,7 +491,7 @@ def main():
         result['config']['collectives'] = 'forced (%s, world_size 1)' % torch.distributed.get_backend()
     for p, (el, pr, sc) in others.items():
         pms = el / args.steps * 1e3
-        result['value_' + p] = round(rays * args.steps / el, 1)
+        result['value_' + p] = round(rays * world * args.steps / el, 1)
         result['ms_per_step_' + p] = round(pms, 3)
         result['dtype_' + p] = ARITH[p][0]
         result['roofline_' + p] = roofline_block(p, pr, args.steps, rays, pms, sc, n_sec=n_sec, workload=args.workload)

@@ -268,6 +268,33 @@ def test_single_mfma_mlp_forward_golden(dev, prec, V):
 
 
 @pytest.mark.parametrize('prec', list(SINGLE))
+def test_single_mfma_mlp_forward_ragged_and_empty(dev, prec):
+    """The two-point-tile kernels (32 points per wave, 256 per workgroup) on point counts that cut a wave's first tile, its second tile, a
+    workgroup -- 1, 15, 17, 33, 255, 257, 300 -- with V = 1 secondary direction, and zero points: against the oracle at the mode's tolerance, and
+    every count's rows equal to the same rows of the 300-point call bit for bit (a lane beyond P must not disturb its wave)."""
+    ops = tp.hip_ops()
+    rtol, floor, _ = SINGLE[prec]
+    params = vo.init_params(9, levels=('coarse',))
+    pr = ops.PRECISIONS[prec]
+    pk = ops.pack_weights([tp.cu(params[f'coarse_model.{n}'], dev) for n in ops.PARAM_ORDER], precision=pr)
+    p = vo.params_to_torch(params)
+    rs = np.random.default_rng(1)
+    pts = torch.from_numpy(rs.uniform(-1, 1, size=(300, 3)).astype(np.float32))
+    vd = torch.nn.functional.normalize(torch.from_numpy(rs.standard_normal((300, 3)).astype(np.float32)), dim=-1)
+    vd2 = torch.nn.functional.normalize(torch.from_numpy(rs.standard_normal((300, 1, 3)).astype(np.float32)), dim=-1)
+    ref = vo.mlp_forward(p, 'coarse', pts, vd, vd2, None)
+    full = ops.mlp_forward(pk, pts.to(dev), vd.to(dev), vd2.to(dev), precision=pr)
+    for k in ('rgb', 'sigma', 'visibility', 'visibility2'):
+        tp.assert_close(full[k], ref[k], rtol=rtol, floor=floor, what=f'{prec} {k} P=300')
+    for P in (1, 15, 17, 33, 255, 257):
+        o = ops.mlp_forward(pk, pts[:P].to(dev), vd[:P].to(dev), vd2[:P].to(dev), precision=pr)
+        for k in ('rgb', 'sigma', 'visibility', 'visibility2'):
+            assert torch.equal(o[k], full[k][:P]), f'{prec} {k}: the {P}-point call differs from the first {P} rows of the 300-point call'
+    o = ops.mlp_forward(pk, torch.zeros(0, 3, device=dev), torch.zeros(0, 3, device=dev), precision=pr)
+    assert o['rgb'].shape == (0, 3)
+
+
+@pytest.mark.parametrize('prec', list(SINGLE))
 @pytest.mark.parametrize('tag', ['llff', 'realestate', 'dtu'])
 def test_single_mfma_train_step_golden(dev, prec, tag):
     from loss_functions.LossComputerHip01 import LossComputerHip

@@ -95,13 +95,17 @@ def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, VIPNERF_DIST_BACKEND='gloo')
     port = 32000 + (os.getpid() % 2000)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--rays', '1024']
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--configs4-rays', '512',
+           '--rays', '1024']
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
     res = json.loads(lines[0])
     assert res['n_gpus'] == 2 and res['scaling'] == 'weak' and res['value'] > 0 and res['config']['global_rays'] == 2048
+    # N > 1 lines carry the configs[4] arithmetic beside `value`, and the configs[4] block (every rank its own DTU shard)
+    assert res['value_bf16'] > 0 and res['configs4_dtu']['n_gpus'] == 2 and res['configs4_dtu']['global_rays'] == 1024
+    assert res['configs4_dtu']['bf16']['value'] > 0 and res['configs4_dtu']['bf16']['roofline']['bound'] == 'mfma'
     assert res['dtype'] == 'f32' and res['roofline']['bound'] == 'mfma' and 0 < res['roofline']['frac'] < 1
     # the render leg at N > 1: one strip of the 756-row frame per rank, barrier-bracketed maximum over the ranks
     assert res['render']['fp32']['row_strips'] == 2 and res['render_ms_per_frame'] > 0

@@ -298,6 +298,8 @@ def main():
     ap.add_argument('--no-other-precisions', action='store_true', help='same as --also ""')
     ap.add_argument('--no-configs4', action='store_true', help='skip the configs[4] block (DTU shard in bf16 / fp16)')
     ap.add_argument('--configs4-rays', type=int, default=16384, help='rays per GPU of the configs[4] block (131,072 / 8)')
+    ap.add_argument('--optimizer', default='flat', choices=['flat', 'torch-fused'], help='flat: vipnerf_hip.optim.FlatAdam (torch.optim.Adam\'s own '
+                    'update on the flat buffers, bit-identical, 6 launches); torch-fused: torch.optim.Adam(fused=True) (2 x ~100 us multi_tensor_apply)')
     ap.add_argument('--force-dist', action='store_true', help='take the multi-rank code path (process group, broadcast, all-reduce, '
                     'barriers) even with one rank')
     args = ap.parse_args()
@@ -346,7 +348,11 @@ def main():
             vdist.broadcast_parameters(self.model)
             self.model.train()
             self.lossc = LossComputerHip(self.cfg)
-            self.opt = torch.optim.Adam(self.model.parameters(), lr=5e-4, betas=(0.9, 0.999), fused=True)   # same update, one kernel
+            if args.optimizer == 'flat':         # torch's single-tensor Adam expressions on ONE flat parameter / moment / gradient buffer
+                from vipnerf_hip.optim import FlatAdam                       # (bit-identical to torch.optim.Adam; 6 launches per step)
+                self.opt = FlatAdam(self.model.parameters(), lr=5e-4, betas=(0.9, 0.999))
+            else:
+                self.opt = torch.optim.Adam(self.model.parameters(), lr=5e-4, betas=(0.9, 0.999), fused=True)
             self.bucket = vdist.FlatGradBucket(self.model.parameters())
             self.gen = make_scene(scene, dev)
             self.n_batches = min(args.steps + args.warmup, 8 if n_rays > 8192 else 32)      # distinct resident batches, cycled
@@ -484,7 +490,9 @@ def main():
                                'V=%d secondary view(s), losses MSE+Visibility+VisibilityPrior, Adam; rays generated and random numbers drawn on device'
                                % (cfg_name, args.workload, 'NDC' if SCENES[args.workload][5] else 'non-NDC', SCENES[args.workload][6], rays, n_sec),
                    'rays_per_gpu': rays, 'global_rays': rays * world, 'parallelism': f'ray-sharded dp{world}',
-                   'gemm_arithmetic': args.precision, 'arithmetic_note': ARITH[args.precision][3]},
+                   'gemm_arithmetic': args.precision, 'arithmetic_note': ARITH[args.precision][3],
+                   'optimizer': 'Adam(lr 5e-4, betas 0.9 / 0.999): ' + ('vipnerf_hip.optim.FlatAdam -- torch.optim.Adam\'s single-tensor update on one flat '
+                                 'parameter / moment / gradient buffer (bit-identical per parameter)' if args.optimizer == 'flat' else 'torch.optim.Adam(fused=True)')},
         'roofline': roofline_block(args.precision, prof, args.steps, rays, ms, sclk, n_sec=n_sec, workload=args.workload),
     }
     if collectives and world == 1:

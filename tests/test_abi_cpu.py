@@ -182,3 +182,39 @@ def test_philox_restatement_reproduces_random123_vectors():
     from oracle import philox_oracle as po
     for c, k, want in po.KAT:
         assert tuple(int(x) for x in po.philox4x32_10(np.array([c], np.uint32), np.array([k], np.uint32))[0]) == want
+
+
+def test_flat_adam_is_torch_adam():
+    """vipnerf_hip.optim.FlatAdam (one flat parameter / moment / gradient buffer, six elementwise kernels per step) takes, bit for bit, the
+    steps of torch.optim.Adam's single-tensor path -- the reference's optimizer (Trainer01.py:505-515) -- with gradients that are views of
+    one buffer (the HIP backward's layout) as well as with separate gradient tensors and a missing one."""
+    import torch
+    from vipnerf_hip.optim import FlatAdam
+    torch.manual_seed(0)
+    shapes = [(256, 63), (256,), (256, 319), (4, 128), (1,)]
+    ref = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    o_ref = torch.optim.Adam(ref, lr=5e-4, betas=(0.9, 0.999), foreach=False, fused=False)
+    o_mine = FlatAdam(mine, lr=5e-4, betas=(0.9, 0.999))
+    n = sum(p.numel() for p in ref)
+    for it in range(5):
+        flat = torch.randn(n) * 10 ** (-it)                 # gradients of very different sizes from step to step
+        off = 0
+        for k, (a, b) in enumerate(zip(ref, mine)):
+            g = flat[off:off + a.numel()].view(a.shape)
+            off += a.numel()
+            if it == 3 and k == 1:
+                a.grad, b.grad = None, None                  # torch skips a parameter without a gradient; FlatAdam sees a zero gradient --
+                continue                                     # different by design (moments decay), so give both an explicit zero instead
+            a.grad = g.clone()
+            b.grad = g if it % 2 == 0 else g.clone()         # even steps: views of ONE buffer (adopted, no copy); odd steps: separate tensors
+        if it == 3:
+            ref[1].grad = torch.zeros_like(ref[1])
+        for grp in o_ref.param_groups:
+            grp['lr'] = 5e-4 * 0.9 ** it
+        o_mine.param_groups[0]['lr'] = 5e-4 * 0.9 ** it
+        o_ref.step()
+        o_mine.step()
+        for a, b in zip(ref, mine):
+            assert torch.equal(a.detach(), b.detach()), f'step {it}'
+    assert all(p.data_ptr() == o_mine.flat[sum(q.numel() for q in mine[:i]):].data_ptr() for i, p in enumerate(mine))

@@ -74,3 +74,40 @@ def test_shard_size_properties(scene, n, prec, add_tol):
     err = float((g_sum / 2 - g_a).norm() / g_a.norm())
     print(f'{scene} {n} rays {prec}: gradient additivity over two halves, relative L2 {err:.2e}')
     assert err <= add_tol
+
+
+def test_flat_adam_trains_like_torch_adam():
+    """vipnerf_hip.optim.FlatAdam on the device: three training steps (on-device batches and random numbers, the HIP backward's flat gradient
+    buffer adopted without a copy) end with parameters bit-identical to torch.optim.Adam's single-tensor path on a second copy of the model;
+    the parameters keep their identity / names / shapes, only their storage moves into one buffer (which pack_weights reads through)."""
+    import bench
+    import test_hip_parity as tp
+    from oracle import vipnerf_oracle as vo
+    from vipnerf_hip.optim import FlatAdam
+    dev = torch.device('cuda:0')
+    torch.manual_seed(11)
+    gen = bench.make_scene('fern', dev, seed=5)
+    batches = [bench.make_batch(gen, 512, 900 + i) for i in range(3)]
+    finals = []
+    for kind in ('torch', 'flat'):
+        model, cfg = tp.make_model(dev, True, vo.init_params(41, scale=1.6))
+        model.train()
+        names = [k for k, _ in model.named_parameters()]
+        opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.999), foreach=False, fused=False) if kind == 'torch' \
+            else FlatAdam(model.parameters(), lr=5e-4, betas=(0.9, 0.999))
+        from loss_functions.LossComputerHip01 import LossComputerHip
+        lossc = LossComputerHip(cfg)
+        for i, b0 in enumerate(batches):
+            b = dict(b0)
+            b['common_data'] = {'poses': b0['common_data']['poses']}
+            b['iter_num'] = 40000 + i
+            model._last_iter = None
+            opt.zero_grad(set_to_none=True)
+            out = model(b)
+            lossc.compute_losses(b, out)['TotalLoss'].backward()
+            opt.step()
+        assert [k for k, _ in model.named_parameters()] == names
+        finals.append(torch.cat([p.detach().flatten() for p in model.parameters()]).clone())
+        if kind == 'flat':
+            assert opt._flat_grad().data_ptr() == next(iter(model.parameters())).grad.data_ptr(), 'the adopted gradient buffer is used as it is'
+    assert torch.equal(finals[0], finals[1])

@@ -56,9 +56,11 @@ extern "C" {
 /* Single-pass 16-bit modes (BASELINE configs[4] style mixed precision): ONE MFMA per product in the forward and
  * data-gradient GEMMs, operands rounded once to fp16 (11-bit significand; power-of-two scaling as in FP16X3) or bf16
  * (8 bits, fp32's range), fp32 accumulation, fp32 master weights / biases / encodings / heads / compositing / losses.
- * FP16 also stores the trunk activations and gradients as fp16 and runs the 256x256 weight-gradient GEMMs as single fp16
- * MFMAs (as FP16X3H); BF16 keeps them in fp32 (weight gradients: bf16 hi/lo, 3 MFMAs).  Errors ~1e-3 (fp16) / ~1e-2 (bf16)
- * relative -- a separate accuracy class from everything above. */
+ * Both store EVERY operand of the weight-gradient GEMMs (activations, gradients, encodings, head seeds) as 16-bit values in
+ * 16-point x 16-feature tiles inside the `acts` / `bwd_ws` workspaces (vip-nerf_amd/csrc/vipnerf_bf16n.h: store_t16) and run all
+ * weight-gradient GEMMs as single 16-bit MFMAs fed by DMA + ds_read_b64_tr_b16 (vipnerf_wgrad16.hip): 26 GB of HBM traffic per
+ * 4096-ray step instead of 55.  Training calls need n_rays * samples to be a multiple of 32 (always true: samples are).  Errors
+ * ~1e-3 (fp16) / ~1e-2 (bf16) relative -- a separate accuracy class from everything above (BASELINE configs[4]). */
 #define VIPNERF_PREC_FP16   5
 #define VIPNERF_PREC_BF16   6
 

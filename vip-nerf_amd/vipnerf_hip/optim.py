@@ -67,6 +67,9 @@ class FlatAdam:
 
     @torch.no_grad()
     def step(self):
+        if self.params[0].data_ptr() != self.flat.data_ptr() or self.params[-1].data_ptr() != self.flat[self.flat.numel() - self.params[-1].numel():].data_ptr():
+            raise RuntimeError('FlatAdam: the parameters no longer live in the flat buffer (module.to() / load into new tensors after the optimizer '
+                               'was built?) -- build the optimizer after the model is on its device')
         grp = self.param_groups[0]
         lr, (b1, b2), eps = grp['lr'], grp['betas'], grp['eps']
         g = self._flat_grad()

@@ -175,7 +175,7 @@ int launch_rng_draw(int kind, uint64_t seed, uint64_t offset, uint32_t stream, u
 
 struct LevelWs { size_t acts_off, bwd_off; };   // float offsets of the fine level inside the workspaces
 
-static size_t bwd_total(size_t P, int V, bool h16) { return bwd_layout(P, V, h16).total; }
+static size_t bwd_total(size_t P, int V, bool h16, bool t16) { return bwd_layout(P, V, h16, t16).total; }
 
 }  // namespace vn
 
@@ -248,10 +248,11 @@ int32_t vipnerf_query_workspace(const vipnerf_config *cfg, int64_t n_rays, size_
         return VIPNERF_OK;
     }
     if (acts_bytes)
-        *acts_bytes = cfg->save_acts ? (act_layout(Pc, cfg->n_sec).total + (Pf ? act_layout(Pf, cfg->n_sec).total : 0)) * sizeof(float) : 0;
+        *acts_bytes = cfg->save_acts ? (act_layout(Pc, cfg->n_sec, stores_t16(cfg->precision)).total + (Pf ? act_layout(Pf, cfg->n_sec, stores_t16(cfg->precision)).total : 0)) * sizeof(float) : 0;
     if (bwd_bytes) {
         const bool h16 = stores_high16(cfg->precision);       // the modes with an fp32 copy of dY_5 in the workspace
-        const size_t a = bwd_total(Pc, cfg->n_sec, h16), b = Pf ? bwd_total(Pf, cfg->n_sec, h16) : 0;
+        const bool t16 = stores_t16(cfg->precision);
+        const size_t a = bwd_total(Pc, cfg->n_sec, h16, t16), b = Pf ? bwd_total(Pf, cfg->n_sec, h16, t16) : 0;
         *bwd_bytes = (a > b ? a : b) * sizeof(float);       // levels run one after the other
     }
     return VIPNERF_OK;
@@ -388,8 +389,8 @@ int32_t vipnerf_render_forward(const vipnerf_config *cfg, const vipnerf_rays *ra
         ma.sigma = L.raw_sigma; ma.rgb = L.raw_rgb; ma.vis = L.raw_vis; ma.vis2 = L.raw_vis2;
         if (cfg->save_acts) {
             const size_t Pc = (size_t)N * Sc;
-            ma.al = act_layout((size_t)N * S, V);
-            ma.acts = (float *)acts + (lv ? act_layout(Pc, V).total : 0);
+            ma.al = act_layout((size_t)N * S, V, stores_t16(cfg->precision));
+            ma.acts = (float *)acts + (lv ? act_layout(Pc, V, stores_t16(cfg->precision)).total : 0);
         }
         if (generic) {
             const GenTopo t = cfg_topo(cfg);
@@ -455,7 +456,7 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
             if ((rc = launch_gen_bwd(t, src, (const float *)(lv ? packed_fine : packed_coarse), L.raw_sigma, ga, bw, gb, G, st))) return rc;
             continue;
         }
-        const BwdLayout bl = bwd_layout(P, V, stores_high16(cfg->precision));
+        const BwdLayout bl = bwd_layout(P, V, stores_high16(cfg->precision), stores_t16(cfg->precision));
         // 1. compositing backward -> dLoss/d(raw network outputs)
         CompositeBwdArgs cb;
         memset(&cb, 0, sizeof(cb));
@@ -473,8 +474,8 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
         mb.src = ray_points(cfg, rays, S, L.z_vals);
         mb.packed = (const float *)(lv ? packed_fine : packed_coarse);
         mb.sigma = L.raw_sigma; mb.rgb = L.raw_rgb; mb.vis = L.raw_vis; mb.vis2 = L.raw_vis2;
-        mb.al = act_layout(P, V);
-        mb.acts = (const float *)acts + (lv ? act_layout((size_t)N * Sc, V).total : 0);
+        mb.al = act_layout(P, V, stores_t16(cfg->precision));
+        mb.acts = (const float *)acts + (lv ? act_layout((size_t)N * Sc, V, stores_t16(cfg->precision)).total : 0);
         mb.bwd = bw; mb.bl = bl;
         {
             ProfScope ps(lv ? "mlp_dgrad_fine" : "mlp_dgrad_coarse", st);

@@ -107,14 +107,17 @@ struct ActLayout {
     size_t ped[1 + VIPNERF_MAX_SEC];  // [P][32]  gamma(dir), zero padded, per direction
     size_t total;
 };
-__host__ __device__ inline ActLayout act_layout(size_t P, int V) {
+__host__ __device__ inline ActLayout act_layout(size_t P, int V, bool t16 = false) {
+    // t16 (single-MFMA 16-bit modes, T16 operand storage): every array holds 16-bit values -- half the floats; the view hidden's slot
+    // also carries its ReLU bits ([P][4] words behind the tiles)
     ActLayout a; size_t o = 0;
-    for (int i = 0; i < D; ++i) { a.h[i] = o; o += P * W; }
+    const size_t d = t16 ? 2 : 1;
+    for (int i = 0; i < D; ++i) { a.h[i] = o; o += P * W / d; }
     for (int i = 0; i < D; ++i) { a.hm[i] = o; o += P * 8; }
-    a.feat = o; o += P * W;
-    for (int k = 0; k <= VIPNERF_MAX_SEC; ++k) { a.g[k] = o; if (k <= V) o += P * WV; }
-    a.pex = o; o += P * DPE_PAD;
-    for (int k = 0; k <= VIPNERF_MAX_SEC; ++k) { a.ped[k] = o; if (k <= V) o += P * DVE_PAD; }
+    a.feat = o; o += P * W / d;
+    for (int k = 0; k <= VIPNERF_MAX_SEC; ++k) { a.g[k] = o; if (k <= V) o += t16 ? P * (WV / 2 + 4) : P * WV; }
+    a.pex = o; o += P * DPE_PAD / d;
+    for (int k = 0; k <= VIPNERF_MAX_SEC; ++k) { a.ped[k] = o; if (k <= V) o += P * DVE_PAD / d; }
     a.total = o;
     return a;
 }
@@ -170,12 +173,13 @@ __host__ __device__ inline size_t wgrad_partial_total(size_t P, int V) {
     return (size_t)wgrad_chunks(P) * big + (size_t)wgrad_chunks_split(P, WGRAD_SPLIT_PE) * pe +
            (size_t)wgrad_chunks_split(P, WGRAD_SINGLE_SPLIT) * single + (size_t)wgrad_chunks_split(P, WGRAD_SPLIT_THIN) * thin;
 }
-__host__ __device__ inline BwdLayout bwd_layout(size_t P, int V, bool h16 = false) {
+__host__ __device__ inline BwdLayout bwd_layout(size_t P, int V, bool h16 = false, bool t16 = false) {
     BwdLayout b; size_t o = 0;
-    for (int i = 0; i < D; ++i) { b.dy[i] = o; o += P * W; }
-    b.dyf = o; o += P * W;
-    for (int k = 0; k <= VIPNERF_MAX_SEC; ++k) { b.dyv[k] = o; if (k <= V) o += P * WV; }
-    b.dyvsum = o; o += P * WV;
+    const size_t d = t16 ? 2 : 1;                // T16 storage: 16-bit gradients, half the floats
+    for (int i = 0; i < D; ++i) { b.dy[i] = o; o += P * W / d; }
+    b.dyf = o; o += P * W / d;
+    for (int k = 0; k <= VIPNERF_MAX_SEC; ++k) { b.dyv[k] = o; if (k <= V) o += P * WV / d; }
+    b.dyvsum = o; o += P * WV / d;
     for (int k = 0; k <= VIPNERF_MAX_SEC; ++k) { b.dq[k] = o; if (k <= V) o += P * 8; }
     b.dsig = o; o += P;
     b.drgb = o; o += 3 * P;

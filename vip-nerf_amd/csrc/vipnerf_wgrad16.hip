@@ -51,15 +51,21 @@ __device__ __forceinline__ float dot_ones(const bf16x8 &v, float s) {
     s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, w.z), one, s, false);
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, w.w), one, s, false);
 }
+#ifndef VN_WG16_SIGMA_FUSED
+#define VN_WG16_SIGMA_FUSED 1      // the sigma head rides in the feature layer's GEMM (XA below); 0: its own 16 x 256 launch
+#endif
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // M = 16 MT, N = 16 NT; WM x WN waves, wave (wm, wn) owns MT / WM x NT / WN tiles; NB 32-point blocks resident in LDS.
-template <bool BF, int MT, int NT, int WM, int WN, int NB>
+// XA: a GEMM descriptor may carry ONE extra 16-row A tile (WgDesc::wcol = a 16-wide T16 array) against the same B -- the sigma head
+// (row 4 of direction 0's head-seed tile against h_8) rides in the feature layer's GEMM instead of reading h_8 a second time: one more
+// 1 KiB piece per block, one more MFMA per column tile for the waves of the first row block, its partial [16][N] + 16 sums behind the rest.
+template <bool BF, int MT, int NT, int WM, int WN, int NB, bool XA = false>
 __global__ __launch_bounds__(64 * WM * WN) void k_wg16(WgArgs a) {
     typedef typename FragOf<!BF>::type FR;
     constexpr int NW = WM * WN, TM = MT / WM, TN = NT / WN;
     constexpr int PIECES = MT + NT;                  // 1 KiB DMA pieces per block: the block's A bytes, then its B bytes
-    constexpr int BLK = PIECES * 1024;
+    constexpr int BLK = (PIECES + (XA ? 1 : 0)) * 1024;
     constexpr int PW = (PIECES + NW - 1) / NW;       // pieces per wave and block: PW, or PW - 1 for the last waves
     constexpr int MINP = PIECES / NW;                // what the waits count (conservative for the waves that issue PW)
     static_assert(MT % WM == 0 && NT % WN == 0 && NB >= 2 && NB <= 4 && (NB - 1) * PW <= 63 && MINP >= 1, "shape");
@@ -84,6 +90,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wg16(WgArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (floatx4)(0.f);
     }
+    const bool has_x = XA && d.wcol != nullptr;      // (workgroup-uniform)
+    const char *gX = has_x ? (const char *)d.wcol + (size_t)(p0 >> 4) * 512 + lane * 16 : nullptr;
+    floatx4 accx[XA ? TN : 1];
+    float bsumx = 0.f;
+#pragma unroll
+    for (int j = 0; j < (XA ? TN : 1); ++j) accx[j] = (floatx4)(0.f);
 
     auto issue = [&](int b, int slot) {
 #pragma unroll
@@ -94,6 +106,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wg16(WgArgs a) {
                 glds_chunks<1>((const float *)src, __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds + slot * BLK + pc * 1024)));
             }
         }
+        if (XA && has_x && wave == NW - 1)           // the extra tile's block (2 groups x 512 B); one more load than MINP counts: still a lower bound
+            glds_chunks<1>((const float *)(gX + (size_t)b * 1024), __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds + slot * BLK + PIECES * 1024)));
     };
     int fill = 0;
 #pragma unroll
@@ -121,16 +135,21 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wg16(WgArgs a) {
             const int t = wm * TM + i;
             af[i] = frag16<FR>(A + t * 512, A + (MT + t) * 512, lane);
         }
+        FR ax;
+        const bool do_x = XA && has_x && wm == 0;    // (wave-uniform)
+        if (do_x) ax = frag16<FR>(A + PIECES * 1024, A + PIECES * 1024 + 512, lane);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int t = wn * TN + j;
             const FR bf = frag16<FR>(B + t * 512, B + (NT + t) * 512, lane);
 #pragma unroll
             for (int i = 0; i < TM; ++i) acc[i][j] = mfma_bf(af[i], bf, acc[i][j]);
+            if (XA) { if (do_x) accx[j] = mfma_bf(ax, bf, accx[j]); }
         }
         if (wn == 0) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) bsum[i] = dot_ones(af[i], bsum[i]);
+            if (XA) { if (do_x) bsumx = dot_ones(ax, bsumx); }
         }
     }
 
@@ -154,14 +173,31 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wg16(WgArgs a) {
             if (lane < 16) part[(size_t)Mp * Np + 16 * tm + lane] = s;
         }
     }
+    if (XA) {
+        if (has_x && wm == 0) {                      // the extra tile's partial: [16][Np] and its 16 column sums, behind the bias sums
+            float *px = part + (size_t)Mp * Np + Mp;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int tn = wn * TN + j;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) px[(size_t)(4 * qr + r) * Np + 16 * tn + jn] = accx[j][r];
+            }
+            if (wn == 0) {
+                float s = bsumx;
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                if (lane < 16) px[(size_t)16 * Np + lane] = s;
+            }
+        }
+    }
 }
 
-template <bool BF, int MT, int NT, int WM, int WN, int NB>
+template <bool BF, int MT, int NT, int WM, int WN, int NB, bool XA = false>
 static int launch_wg16(const WgArgs &args, int n_desc, int n_chunks, hipStream_t st) {
     if (n_desc == 0) return VIPNERF_OK;
-    const size_t ldsb = (size_t)NB * (MT + NT) * 1024;
-    VN_HIP(hipFuncSetAttribute((const void *)k_wg16<BF, MT, NT, WM, WN, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-    hipLaunchKernelGGL((k_wg16<BF, MT, NT, WM, WN, NB>), dim3(n_chunks, n_desc), dim3(64 * WM * WN), ldsb, st, args);
+    const size_t ldsb = (size_t)NB * (MT + NT + (XA ? 1 : 0)) * 1024;
+    VN_HIP(hipFuncSetAttribute((const void *)k_wg16<BF, MT, NT, WM, WN, NB, XA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    hipLaunchKernelGGL((k_wg16<BF, MT, NT, WM, WN, NB, XA>), dim3(n_chunks, n_desc), dim3(64 * WM * WN), ldsb, st, args);
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;
 }
@@ -172,7 +208,7 @@ static int launch_all(const WgArgs &big, int nbig, int n_chunks, const WgArgs &p
     int rc;
     {
         ProfScope ps("wgrad_256x256", st);
-        if ((rc = launch_wg16<BF, 16, 16, 2, 4, 4>(big, nbig, n_chunks, st))) return rc;
+        if ((rc = launch_wg16<BF, 16, 16, 2, 4, 4, VN_WG16_SIGMA_FUSED != 0>(big, nbig, n_chunks, st))) return rc;
     }
     ProfScope ps("wgrad_small", st);
     if ((rc = launch_wg16<BF, 16, 4, 4, 1, 3>(pe, npe, n_pe, st))) return rc;
@@ -250,9 +286,22 @@ int launch_wgrad16(size_t P, int V, const float *acts, const ActLayout &al, floa
     }
     {   // feature_linear
         const size_t o = add(big, nbig, n_chunks, 256, 256, bwd + bl.dyf, acts + al.h[D - 1]);
-        group(n_chunks, o, 1, 256, 256, W, W, G->g[P_FW], W, 0, G->g[P_FB]);
+        WgGroup &gf = group(n_chunks, o, 1, 256, 256, W, W, G->g[P_FW], W, 0, G->g[P_FB]);
+        if (VN_WG16_SIGMA_FUSED) {
+            // + the sigma head as an extra A tile of this GEMM (the head-seed tile of direction 0, row 4, against the same h_8): its partial
+            // [16][256] + 16 sums follows the GEMM's own in every chunk
+            WgDesc &d = big.d[nbig - 1];
+            constexpr size_t X = (size_t)16 * 256 + 16;
+            d.wcol = bwd + bl.dq[0];
+            d.part_stride += X;
+            off += (size_t)n_chunks * X;
+            gf.part_stride = d.part_stride; gf.desc_stride = (size_t)n_chunks * d.part_stride;
+            WgGroup &g = group(n_chunks, o + (size_t)256 * 256 + 256 + 4 * 256, 1, 16, 256, 1, W, G->g[P_SW], W, 0, G->g[P_SB]);
+            g.part_stride = d.part_stride; g.desc_stride = gf.desc_stride;
+            g.bias_off = (size_t)16 * 256 + 4 - 4 * 256;
+        }
     }
-    {   // sigma head: row 4 of the head-seed tile of direction 0 against h_8
+    if (!VN_WG16_SIGMA_FUSED) {   // sigma head on its own: row 4 of the head-seed tile of direction 0 against h_8 (a second pass over h_8)
         const size_t o = add(sg, nsg, n_single, 16, 256, bwd + bl.dq[0], acts + al.h[D - 1]);
         WgGroup &g = group(n_single, o + 4 * 256, 1, 16, 256, 1, W, G->g[P_SW], W, 0, G->g[P_SB]);
         g.bias_off = (size_t)16 * 256 + 4 - 4 * 256;

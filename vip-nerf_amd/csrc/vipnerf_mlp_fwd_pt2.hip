@@ -124,9 +124,9 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
                 FR t1[NS];
                 split_pair<NS>(x[0], x[1], t1);
                 bin[s][0].v[pt] = t1[0];
-                if (SAVE && layer == 8 && valid[pt]) store_t16(dst, grp[pt], 16, s, j, q, t1[0]);     // the feature (h_1..h_8 leave from the next layer's stages)
+                if (SAVE && layer == 8 && valid[pt] && !EXP_NO_EXTRAS) store_t16(dst, grp[pt], 16, s, j, q, t1[0]);     // the feature (h_1..h_8 leave from the next layer's stages)
             }
-            if (SAVE && layer < 8) *(uint2 *)(a.acts + a.al.hm[layer] + ((size_t)p[pt] * 4 + q) * 2) = make_uint2(mk0, mk1);
+            if (SAVE && layer < 8 && !EXP_NO_STORES) *(uint2 *)(a.acts + a.al.hm[layer] + ((size_t)p[pt] * 4 + q) * 2) = make_uint2(mk0, mk1);
         }
     };
 
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
         if (SAVE) {
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) {
-                if (valid[pt]) {           // gamma(x), slot order: column 16 q + u of a 64-wide T16 array = tile q
+                if (valid[pt] && !EXP_NO_PE) {           // gamma(x), slot order: column 16 q + u of a 64-wide T16 array = tile q
                     typedef unsigned u4 __attribute__((ext_vector_type(4)));
                     char *row = (char *)(a.acts + a.al.pex) + ((size_t)grp[pt] * 4 + q) * 512 + j * 32;
                     __builtin_nontemporal_store(__builtin_bit_cast(u4, bpe[0][0].v[pt]), (u4 *)row);
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
             for (int t = 0; t < 8; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) g[t][r] = relu_lo<true>(g[t][r] * AU, 0.f);
-            if (SAVE && valid[pt]) {
+            if (SAVE && valid[pt] && !EXP_NO_EXTRAS) {
                 unsigned gm = 0u;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {

@@ -22,15 +22,28 @@ struct DeferredT16 {
     bool valid[2];
     int j, q, s0;
     const BOp<FR, 2> (*bin)[1];
-    template <int g, int NG> static constexpr bool active() { return g == NG - 1; }
+    // VN_PT2_SPREAD = 1: all of a stage's stores behind its last MFMA group; = NSTEP (4, the default): one k-step's stores (4 instructions)
+    // behind every NG / NSTEP-th group, so that the stage's 16 store instructions per wave do not queue at the vector-memory port at once --
+    // measured on one box (bf16, 4096 rays): forward 1.66 -> 1.60 ms, data gradients 1.73 -> 1.61; 8 parts (one point tile's k-step each):
+    // forward 1.63, data gradients 2.15 (the extra scheduling barriers cost registers: spills)
+#ifndef VN_PT2_SPREAD
+#define VN_PT2_SPREAD 4
+#endif
+    // (VN_PT2_SPREAD = 2 NSTEP: one k-step of ONE point tile -- two instructions -- behind every NG / (2 NSTEP)-th group)
+    static constexpr int PARTS = VN_PT2_SPREAD > 1 ? (VN_PT2_SPREAD >= 2 * NSTEP ? 2 * NSTEP : NSTEP) : 1;
+    template <int g, int NG> static constexpr bool active() { return (g + 1) % (NG / PARTS) == 0; }
     template <int g, int NG>
     __device__ __forceinline__ void at() const {
         if (EXP_NO_STORES) return;
+        constexpr int part = (g + 1) / (NG / PARTS) - 1;
+        constexpr bool split_pt = PARTS == 2 * NSTEP;
+        constexpr int per = PARTS == 1 ? NSTEP : 1, sfirst = PARTS == 1 ? 0 : (split_pt ? part / 2 : part);
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
+            if (split_pt && pt != (part & 1)) continue;
             if (valid[pt]) {
 #pragma unroll
-                for (int s = s0; s < s0 + NSTEP; ++s) store_t16(dst, grp[pt], 16, s, j, q, bin[s][0].v[pt]);
+                for (int s = s0 + sfirst; s < s0 + sfirst + per; ++s) store_t16(dst, grp[pt], 16, s, j, q, bin[s][0].v[pt]);
             }
         }
     }

@@ -106,7 +106,6 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
                 sigma_raw[pt] = s + rf[PL::N_BHEAD];
             }
         }
-        float *dst = SAVE ? a.acts + (layer < 8 ? a.al.h[layer] : a.al.feat) : nullptr;
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
             unsigned mk0 = 0u, mk1 = 0u;
@@ -124,7 +123,6 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
                 FR t1[NS];
                 split_pair<NS>(x[0], x[1], t1);
                 bin[s][0].v[pt] = t1[0];
-                if (SAVE && layer == 8 && valid[pt] && !EXP_NO_EXTRAS) store_t16(dst, grp[pt], 16, s, j, q, t1[0]);     // the feature (h_1..h_8 leave from the next layer's stages)
             }
             if (SAVE && layer < 8 && !EXP_NO_STORES) *(uint2 *)(a.acts + a.al.hm[layer] + ((size_t)p[pt] * 4 + q) * 2) = make_uint2(mk0, mk1);
         }
@@ -202,10 +200,15 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
         const floatx4 b = {b4.x, b4.y, b4.z, b4.w};
         vb[t].v[0] = b; vb[t].v[1] = b;
     }
-#pragma unroll
-    for (int jj = 0; jj < PL::ST_VIEW_F; ++jj) {
-        const float *st = jj == 0 ? ws.template wait<SAVE ? 16 : 0>() : ws.template wait<0>();   // behind the feature layer's epilogue stores
-        gemm_stage_bf<8, PL::KSV, NS>(st, lane, vb, bin, PL::KSV * jj, ws);
+    static_assert(PL::ST_VIEW_F == 1, "the feature's deferred stores assume one view stage");
+    {
+        const float *st = ws.template wait<SAVE ? 4 * S_PER_STAGE : 0>();      // behind the deferred stores of the feature layer's last stage
+        if (SAVE) {          // the feature (= this GEMM's B operand) leaves from inside the stage like h_1..h_8
+            DeferredT16<FR, 8> ds{a.acts + a.al.feat, {grp[0], grp[1]}, {valid[0], valid[1]}, j, q, 0, bin};
+            gemm_stage_bf<8, PL::KSV, NS>(st, lane, vb, bin, 0, ws, ds);
+        } else {
+            gemm_stage_bf<8, PL::KSV, NS>(st, lane, vb, bin, 0, ws);
+        }
     }
 
     // ... then per point tile and direction a K = 32 GEMM from the LDS-resident direction columns, ReLU, the 128 -> 4 head

@@ -15,7 +15,7 @@ constexpr int PT2_PTS_PER_WG = 256;       // 8 waves x 2 point tiles x 16 points
 // The deferred T16 stores of one weight stage, both point tiles: the part-0 B fragments of NSTEP k-steps of the layer input (= the
 // previous layer's output, or the gradient the running GEMM consumes), behind the stage's last MFMA group.  4 NSTEP store
 // instructions per wave when both tiles are in range (what the counted waits of the stream assume; WStreamT::counted otherwise).
-template <typename FR, int NSTEP>
+template <typename FR, int NSTEP, int TILES = 16>       // TILES: width of the stored array in 16-feature tiles
 struct DeferredT16 {
     float *dst;
     int64_t grp[2];
@@ -43,7 +43,7 @@ struct DeferredT16 {
             if (split_pt && pt != (part & 1)) continue;
             if (valid[pt]) {
 #pragma unroll
-                for (int s = s0 + sfirst; s < s0 + sfirst + per; ++s) store_t16(dst, grp[pt], 16, s, j, q, bin[s][0].v[pt]);
+                for (int s = s0 + sfirst; s < s0 + sfirst + per; ++s) store_t16(dst, grp[pt], TILES, s, j, q, bin[s][0].v[pt]);
             }
         }
     }

@@ -304,6 +304,12 @@ def main():
                     'barriers) even with one rank')
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line, from rank 0, and nothing else: fd 1 is pointed at stderr for the whole run (what a native library prints
+    # there -- RCCL's version banner under the platform's NCCL_DEBUG=VERSION, once per rank, buffered until exit -- lands on stderr), and the
+    # JSON line is written to the saved original stdout
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     from vipnerf_hip import dist as vdist
     from vipnerf_hip import ops
     rank, world, local = vdist.init_from_env(force=True if args.force_dist else None)
@@ -513,7 +519,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         from oracle import vipnerf_oracle as vo       # the checker, as the reported CPU baseline only
         result['cpu_baseline'] = cpu_baseline(vo, n_rays=args.cpu_rays)
-    print(json.dumps(result), flush=True)
+    os.write(json_fd, (json.dumps(result) + '\n').encode())
     if torch.distributed.is_initialized():
         vdist.barrier()
         torch.distributed.destroy_process_group()

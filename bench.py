@@ -273,6 +273,12 @@ def roofline_block(prec, prof, steps, rays, ms_per_step, sclk_mhz, n_sec=1, work
         r['traffic_note'] = 'HBM bytes per step (dominant kernel / whole step): FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc ' \
                             'passes of this command, profiles/%s (profiled at commit %s on %s -- NOT a measurement of this run); traffic_ratio ' \
                             '= whole step / SURVEY 8d algorithmic bytes' % (name, tr.get('git_head', 'unknown'), tr.get('date', 'unknown'))
+        try:                                     # is the quoted profile one of the CURRENT kernel sources?
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            from pmc_traffic import csrc_sha16
+            r['traffic_profile_is_of_current_kernels'] = tr.get('csrc_sha16') == csrc_sha16()
+        except Exception:
+            r['traffic_profile_is_of_current_kernels'] = None
         mb = tr.get('mfma_busy', {})
         if mb:
             r['mfma_busy_pmc'] = mb

@@ -19,6 +19,16 @@ def table(path):
 STAGES = {'mlp_fwd': ('k_mlp_fwd',), 'mlp_dgrad': ('k_mlp_bwd',), 'wgrad': ('k_wgrad', 'k_wg16')}
 
 
+def csrc_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources: bench.py recomputes it and says whether the profile is of the current kernels."""
+    import glob, hashlib, os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'vip-nerf_amd', 'csrc')
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, '*.hip')) + glob.glob(os.path.join(root, '*.h'))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def main(d, prec, out):
     f, w = table(f'{d}/pmc_FETCH_SIZE_{prec}.txt'), table(f'{d}/pmc_WRITE_SIZE_{prec}.txt')
     # steps in the profiled run (timed + warm-up + initialisation): the MLP forward kernel runs twice per step (coarse, fine)
@@ -41,6 +51,7 @@ def main(d, prec, out):
         'workload': {'rays_per_gpu': 4096, 'precision': prec, 'scene': 'fern', 'layout': 'narrow', 'steps_profiled': steps_profiled},
         'git_head': subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip() or 'unknown',
         'date': datetime.date.today().isoformat(),
+        'csrc_sha16': csrc_sha16(),
         'source': 'rocprofv3 --kernel-trace --pmc <COUNTER> (one counter per pass, tools/profile_round.sh) of `python bench.py --steps 3 '
                   '--warmup 1 --precision %s`; profiles/r03_pmc_<COUNTER>_%s.txt' % (prec, prec),
         'corrections': 'FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md '

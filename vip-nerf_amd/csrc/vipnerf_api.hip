@@ -136,7 +136,7 @@ static int launch_mlp_fwd_any(MlpFwdArgs &a, int precision, hipStream_t st, int 
     if (precision == VIPNERF_PREC_FP32 && !bf16_narrow(layout, precision)) return launch_mlp_fwd(a, st);
     if (bf16_narrow(layout, precision)) {
         a.packed += packed_total_floats(precision);   // [fp32][wide] precede the narrow image
-        if (VN_PT2 && stores_t16(precision)) return launch_mlp_fwd_pt2(a, precision, st);     // single-MFMA modes: two point tiles per wave
+        if (VN_PT2 && single_mfma_t16(precision)) return launch_mlp_fwd_pt2(a, precision, st);     // single-MFMA modes: two point tiles per wave
         return launch_mlp_fwd_bf16n(a, precision, st);
     }
     a.packed += PK_TOTAL_F;                       // the wide split-bf16 image follows the fp32 image

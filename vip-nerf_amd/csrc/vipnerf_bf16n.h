@@ -264,8 +264,10 @@ __device__ __forceinline__ floatx4 load_tile16(const float *base, int64_t p, int
 #define VN_T16 1
 #endif
 __host__ __device__ inline bool stores_t16(int precision) {
-    return VN_T16 && (precision == VIPNERF_PREC_FP16 || (precision == VIPNERF_PREC_BF16 && VN_BF16_H16));
+    return VN_T16 && (precision == VIPNERF_PREC_FP16 || precision == VIPNERF_PREC_FP16X3H || (precision == VIPNERF_PREC_BF16 && VN_BF16_H16));
 }
+// ... of which the single-MFMA ones run the two-point-tile MLP kernels (vipnerf_mlp_pt2.h); FP16X3H keeps the 16-point fp16x3 kernels
+__host__ __device__ inline bool single_mfma_t16(int precision) { return stores_t16(precision) && precision != VIPNERF_PREC_FP16X3H; }
 __host__ __device__ inline bool stores_high16(int precision) {
     if (stores_t16(precision)) return false;
     return precision == VIPNERF_PREC_FP16X3H || precision == VIPNERF_PREC_FP16 || (precision == VIPNERF_PREC_BF16 && VN_BF16_H16);

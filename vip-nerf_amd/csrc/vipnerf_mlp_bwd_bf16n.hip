@@ -63,7 +63,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
     // direction and their sum, the head seeds as one 16-column tile per direction -- and the view hidden's ReLU comes from the 32 bits per
     // lane the forward left (no fp32 copy of dY_5, no read of the view hidden)
     constexpr bool T16 = H16 == 4;
-    static_assert(!T16 || NS == 1, "T16 storage: single-MFMA modes");
+    static_assert(!T16 || NS == 1 || (NS == 2 && F16), "T16 storage: the single-MFMA modes, and FP16X3H (high parts only)");
     constexpr int S_PER_STAGE = 8 / PL::ST_256;
     const float gs = (F16 && a.gmax) ? grad_scale_from_max(*a.gmax) : 1.f;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -269,7 +269,7 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
     if (precision == 0) return launch_one_bwd_n<2, false, VN_F32_DEFER ? 3 : 0, true>(a, grid, st);
     if (precision == 1) return launch_one_bwd_n<2>(a, grid, st);
     if (precision == 2) return launch_one_bwd_n<3>(a, grid, st);
-    if (precision == 6 && VN_PT2 && stores_t16(precision)) return launch_mlp_bwd_pt2(a, precision, st);     // two point tiles per wave
+    if (precision == 6 && VN_PT2 && single_mfma_t16(precision)) return launch_mlp_bwd_pt2(a, precision, st);     // two point tiles per wave
     if (precision == 6) return launch_one_bwd_n<1, false, VN_BF16_H16 ? (VN_T16 ? 4 : 1) : 0>(a, grid, st);
     if (precision == 3 || precision == 4 || precision == 5) {
         // the level's largest seed first (one pass over 5+V floats per point)
@@ -280,9 +280,9 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
         VN_HIP(hipGetLastError());
         MlpBwdArgs b = a;
         b.gmax = slot;
-        if (precision == 5 && VN_PT2 && stores_t16(precision)) return launch_mlp_bwd_pt2(b, precision, st);
+        if (precision == 5 && VN_PT2 && single_mfma_t16(precision)) return launch_mlp_bwd_pt2(b, precision, st);
         if (precision == 5) return launch_one_bwd_n<1, true, VN_T16 ? 4 : 1>(b, grid, st);
-        return precision == 4 ? launch_one_bwd_n<2, true, 1>(b, grid, st) : launch_one_bwd_n<2, true, VN_F16_PRESPLIT ? 2 : 0>(b, grid, st);
+        return precision == 4 ? launch_one_bwd_n<2, true, VN_T16 ? 4 : 1>(b, grid, st) : launch_one_bwd_n<2, true, VN_F16_PRESPLIT ? 2 : 0>(b, grid, st);
     }
     set_error("mlp_bwd_bf16n: precision %d", precision);
     return VIPNERF_E_ARG;

@@ -28,7 +28,7 @@ template <bool SAVE, int NS, bool F16, int H16 = 0, bool F32 = false>
 __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) {
     typedef BnPlan<NS> PL;
     typedef typename FragOf<F16, F32>::type FR;
-    static_assert(!(F16 && F32) && (!F32 || (NS == 2 && (H16 == 0 || H16 == 3))) && (F32 || H16 != 3) && (H16 != 4 || NS == 1), "arithmetic");
+    static_assert(!(F16 && F32) && (!F32 || (NS == 2 && (H16 == 0 || H16 == 3))) && (F32 || H16 != 3) && (H16 != 4 || NS == 1 || (NS == 2 && F16)), "arithmetic");
     constexpr bool T16 = SAVE && H16 == 4;
     constexpr float XS = F16 ? F16_XSCALE : 1.f;           // B operands are split as XS * x
     constexpr float AU = F16 ? F16_ACC_UNSCALE : 1.f;
@@ -298,9 +298,9 @@ int launch_mlp_fwd_bf16n(const MlpFwdArgs &a, int precision, hipStream_t st) {
     if (precision == 1) return a.acts ? launch_one_n<true, 2>(a, grid, st) : launch_one_n<false, 2>(a, grid, st);
     if (precision == 2) return a.acts ? launch_one_n<true, 3>(a, grid, st) : launch_one_n<false, 3>(a, grid, st);
     if (precision == 3) return a.acts ? launch_one_n<true, 2, true, VN_F16_PRESPLIT ? 2 : 0>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);
-    if (precision == 4) return a.acts ? launch_one_n<true, 2, true, 1>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);
+    if (precision == 4) return a.acts ? launch_one_n<true, 2, true, VN_T16 ? 4 : 1>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);
     constexpr int H5 = VN_T16 ? 4 : 1, H6 = VN_BF16_H16 ? (VN_T16 ? 4 : 1) : 0;
-    if ((precision == 5 || precision == 6) && a.acts && stores_t16(precision) && a.src.P % 16) {
+    if (a.acts && stores_t16(precision) && a.src.P % 16) {
         set_error("mlp_fwd: the 16-bit training kernels need a multiple of 16 points (got %lld)", (long long)a.src.P); return VIPNERF_E_UNSUPPORTED; }
     if (precision == 5) return a.acts ? launch_one_n<true, 1, true, H5>(a, grid, st) : launch_one_n<false, 1, true>(a, grid, st);
     if (precision == 6) return a.acts ? launch_one_n<true, 1, false, H6>(a, grid, st) : launch_one_n<false, 1>(a, grid, st);

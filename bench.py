@@ -476,7 +476,7 @@ def main():
         wl4 = Workload('dtu', args.configs4_rays, 'bf16')
         c4 = {'workload': 'BASELINE configs[4] per-GPU shard: DTU geometry (non-NDC), 3 views (V = 2 secondary views), 131,072 / 8 = %d rays/iter x '
                           '(64+128) samples, coarse+fine 8x256 MLP, mixed precision (16-bit MFMA operands and activation storage, fp32 master '
-                          'weights / accumulation / losses), fused Adam' % args.configs4_rays, 'rays_per_gpu': args.configs4_rays,
+                          'weights / accumulation / losses), Adam' % args.configs4_rays, 'rays_per_gpu': args.configs4_rays,
               'global_rays': args.configs4_rays * world, 'n_gpus': world}
         for p in (('bf16', 'fp16') if world == 1 else ('bf16',)):
             el, pr, sc = wl4.timed_run(p)

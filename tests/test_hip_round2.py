@@ -390,6 +390,44 @@ def test_rerendering_backward_equals_plain(dev, device_rng, prec, tol):
 
 
 # ------------------------------------------------------------------------------------------------ the drop-in claim
+def test_two_dataparallel_replicas_on_one_device(dev):
+    """The reference's multi-GPU mode (Trainer01.py:517 with 'device': [0, 1]: torch.nn.DataParallel replicates the module, scatters the
+    batch, runs the replicas in threads, gathers the per-ray outputs) -- exercised with BOTH replicas on this one GPU
+    (device_ids=[0, 0]; a second device is not available here): the replica branch of VipNeRFHip (replicas are rebuilt from the master on
+    every forward and keep no state: their random streams are keyed by the rows' pixel ids), two threads inside the library at once, the
+    gathered outputs, and the gradients reduced back onto the master parameters -- against the plain module on the whole batch drawing the
+    same pixel-keyed streams: outputs bit for bit, gradients to summation order.  NOT covered: two physical devices."""
+    from loss_functions.LossComputerHip01 import LossComputerHip
+    n = 192
+    b = vo.synthetic_batch(n, 711, scene='fern', nf=2)
+    params = vo.init_params(712, scale=1.6)
+
+    def batch(num_gpus):
+        rb = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items() if k not in ('poses', 'ndc')}
+        rb['common_data'] = {'poses': b['poses'][None].repeat(num_gpus, 1, 1, 1).to(dev)}      # tiled per GPU (DataPreprocessor01.py:524-529)
+        rb['iter_num'] = 40000
+        return rb
+
+    res = {}
+    for wrap in (True, False):
+        model, cfg = tp.make_model(dev, b['ndc'], params)
+        model.train()
+        torch.manual_seed(3)
+        net = torch.nn.DataParallel(model, device_ids=[0, 0]) if wrap else model
+        rb = batch(2 if wrap else 1)
+        if not wrap:                                   # the streams a replica keys by pixel: (frame << 40) | (y << 20) | x
+            pid = rb['pixel_id'].long()
+            rb['rng_ray_ids'] = (pid[:, 0] << 40) | (pid[:, 2] << 20) | pid[:, 1]
+        out = net(rb)
+        assert out['rgb_fine'].shape == (n, 3) and out['visibility2_fine'].shape == (n, 1)
+        LossComputerHip(cfg).compute_losses(rb, out)['TotalLoss'].backward()
+        res[wrap] = ({k: v.detach().clone() for k, v in out.items()}, torch.cat([p.grad.flatten() for p in model.parameters()]).clone())
+    for k in res[False][0]:
+        assert torch.equal(res[True][0][k], res[False][0][k]), f'{k}: two replicas vs the plain module'
+    d = float((res[True][1] - res[False][1]).norm() / res[False][1].norm())
+    assert d < 1e-5, f'gradients reduced from two replicas vs the plain module: {d:.2e}'
+
+
 def _merge_chunks(chunks):
     """What the reference's validation does with the per-chunk dicts (Trainer01.py:147-172): tensors with more than one
     element are concatenated, one-element tensors averaged, nested dicts walked; anything else is an error."""

@@ -60,8 +60,15 @@ class MLPParams(torch.nn.Module):
         self.predict_visibility = True
 
     def ordered_params(self):
-        sd = dict(self.named_parameters())
-        return [sd[n] for n in ops.param_order(self.topology[0])]
+        """The parameter tensors in the ABI's order, by attribute path: on a torch.nn.DataParallel REPLICA the weights are plain (non-leaf)
+        tensor attributes -- the broadcast copies autograd reduces back onto the master -- and named_parameters() is empty there."""
+        out = []
+        for name in ops.param_order(self.topology[0]):
+            t = self
+            for part in name.split('.'):
+                t = getattr(t, part)
+            out.append(t)
+        return out
 
 
 class VipNeRFHip(torch.nn.Module):

@@ -130,9 +130,14 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
 
     __syncthreads();                         // resident block visible
     // ---------------------------------------------------------------- layer 0: gamma(x) only (the first two k-steps of a stage whose other two are zero padding)
+#ifndef VN_PT2_EVAL_KEEP
+#define VN_PT2_EVAL_KEEP 1       // eval: 1 = gamma(x)'s fragments stay in 16 registers from layer 0 to layer 5 (measured: fp16 1023 -> 1080, bf16 1181 -> 1226 TFLOP/s); 0 = evaluated again at layer 5
+#endif
+    BT bpe_keep[2][NS];
     {
         BT bpe[2][NS];
         encode_pe(bpe);
+        if (!SAVE && VN_PT2_EVAL_KEEP) { bpe_keep[0][0] = bpe[0][0]; bpe_keep[1][0] = bpe[1][0]; }
         if (SAVE) {
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) {
@@ -174,6 +179,8 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
                     bpe[0][0].v[pt] = __builtin_bit_cast(FR, *(const u4 *)row);
                     bpe[1][0].v[pt] = __builtin_bit_cast(FR, *(const u4 *)(row + 16));
                 }
+            } else if (VN_PT2_EVAL_KEEP) {
+                bpe[0][0] = bpe_keep[0][0]; bpe[1][0] = bpe_keep[1][0];
             } else {
                 encode_pe(bpe);              // eval: evaluated again rather than held in 16 registers across layers 1..4
             }

@@ -130,6 +130,9 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
 
     __syncthreads();                         // resident block visible
     // ---------------------------------------------------------------- layer 0: gamma(x) only (the first two k-steps of a stage whose other two are zero padding)
+#ifndef VN_PT2_TRAIN_KEEP
+#define VN_PT2_TRAIN_KEEP 0      // training: 0 = reloaded from the activation store at layer 5; 1 = kept in registers too (21 spilled registers instead of 7: forward 1.55 -> 1.67 ms per step, not kept)
+#endif
 #ifndef VN_PT2_EVAL_KEEP
 #define VN_PT2_EVAL_KEEP 1       // eval: 1 = gamma(x)'s fragments stay in 16 registers from layer 0 to layer 5 (measured: fp16 1023 -> 1080, bf16 1181 -> 1226 TFLOP/s); 0 = evaluated again at layer 5
 #endif
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
     {
         BT bpe[2][NS];
         encode_pe(bpe);
-        if (!SAVE && VN_PT2_EVAL_KEEP) { bpe_keep[0][0] = bpe[0][0]; bpe_keep[1][0] = bpe[1][0]; }
+        if ((!SAVE && VN_PT2_EVAL_KEEP) || (SAVE && VN_PT2_TRAIN_KEEP)) { bpe_keep[0][0] = bpe[0][0]; bpe_keep[1][0] = bpe[1][0]; }
         if (SAVE) {
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) {
@@ -171,7 +174,9 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
         }
         if (layer == SKIP_LAYER) {           // gamma(x) columns last: h's operand registers are dead by then
             BT bpe[2][NS];
-            if (SAVE) {                      // training: the fragments come back from the activation store (written in exactly this form)
+            if (SAVE && VN_PT2_TRAIN_KEEP) {
+                bpe[0][0] = bpe_keep[0][0]; bpe[1][0] = bpe_keep[1][0];
+            } else if (SAVE) {               // training: the fragments come back from the activation store (written in exactly this form)
                 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt) {

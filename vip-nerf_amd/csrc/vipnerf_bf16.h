@@ -379,7 +379,10 @@ __device__ __forceinline__ void gemm_stage_bf(const float *stage, int lane, ACC 
     // single-MFMA modes (NS == 1): a cell is ONE 16-cycle MFMA, so groups of four tiles, two groups (128 cycles of this wave's
     // MFMAs, twice that with its SIMD partner's in between) ahead of the LDS latency; with two point tiles per wave a cell is two
     // MFMAs: groups of two tiles (the same 128 cycles, half the fragment registers)
-    constexpr int G = TIGHT ? 1 : (NS == 1 ? (FragTypeOf<BT>::npt == 2 ? 2 : 4) : 2);
+#ifndef VN_PT2_G
+#define VN_PT2_G 1
+#endif
+    constexpr int G = TIGHT ? 1 : (NS == 1 ? (FragTypeOf<BT>::npt == 2 ? VN_PT2_G : 4) : 2);
 #ifndef VN_PT2_D
 #define VN_PT2_D 2
 #endif

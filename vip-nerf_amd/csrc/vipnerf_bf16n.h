@@ -319,12 +319,31 @@ __device__ __forceinline__ void store_pair_f32(float *, int64_t, int, int, int, 
 // store instruction of the wave writes one whole tile = 512 contiguous bytes (no partially written lines).  The weight-gradient
 // kernels copy 32-point blocks of these arrays into LDS by DMA and read their MFMA fragments (lane = feature, 4 consecutive points)
 // with ds_read_b64_tr_b16.  Wave-uniformly predicated by the caller (P is a multiple of 16 in the render path).
+// VN_T16_X4 (default): ONE 16-byte store per lane and k-step instead of two 8-byte ones.  The 32 features of a k-step are then laid out
+// as two 16 x 16 tiles BY LANE GROUP -- stored tile 2s + (q >> 1), row j, columns 8 (q & 1) + e -- rather than by C/D tile: a fixed
+// permutation of the feature index inside every 32-feature block (t16_feature below), which the weight-gradient kernels never see (any
+// consistent order of an operand's features is a valid GEMM) and the chunk reduction undoes on the way into the nn.Linear layout.  Each
+// store instruction of the wave then writes two whole tiles = 1 KiB contiguous, and a layer costs 8 store instructions per wave and
+// point tile instead of 16.
+#ifndef VN_T16_X4
+#define VN_T16_X4 1
+#endif
+// stored feature index i (tile i >> 4, column i & 15) of a T16 array written from C/D fragments -> the feature it holds
+__host__ __device__ inline int t16_feature(int i) {
+    if (!VN_T16_X4) return i;
+    const int T = i >> 4, c = i & 15, s = T >> 1, q = 2 * (T & 1) + (c >> 3), e = c & 7;
+    return 32 * s + 16 * (e >> 2) + 4 * q + (e & 3);
+}
 template <typename FR>
 __device__ __forceinline__ void store_t16(float *base, int64_t grp, int tiles, int s, int j, int q, const FR &v) {
     static_assert(sizeof(FR) == 16, "a 16-byte fragment part");
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
     const u4 w = __builtin_bit_cast(u4, v);
+    if (VN_T16_X4) {
+        __builtin_nontemporal_store(w, (u4 *)((char *)base + ((size_t)grp * tiles + 2 * s + (q >> 1)) * 512 + j * 32 + (q & 1) * 16));
+        return;
+    }
     char *t0 = (char *)base + ((size_t)grp * tiles + 2 * s) * 512 + j * 32 + q * 8;
     const u2 lo = {w[0], w[1]}, hi = {w[2], w[3]};
     __builtin_nontemporal_store(lo, (u2 *)t0);

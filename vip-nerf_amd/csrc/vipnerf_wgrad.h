@@ -36,7 +36,9 @@ struct WgGroup {
     float *dW; int ldw; int col_off;
     float *dbias;                             // NULL = no bias output
     size_t bias_off;                          // float offset of the column sums inside a chunk's partial block (default Mp * Kp)
-    int colperm;                              // 0: partial column k is feature k; 1 / 2: the slot order of gamma(x) / gamma(dir) in T16 storage
+    int colperm;                              // 0: partial column k is feature k; 1 / 2: the slot order of gamma(x) / gamma(dir) in T16 storage;
+                                              // 3: the stored order of a T16 array written from C/D fragments (t16_feature)
+    int rowperm;                              // 0 / 3: the same for the partial's rows (the A operand's features)
 };
 constexpr int WG_MAX_GROUP = 24;
 struct WgReduceArgs {
@@ -50,6 +52,7 @@ struct WgReduceArgs {
 __host__ __device__ inline int wg_colperm(int mode, int k) {
     if (mode == 1) return pe_feat16(0, k >> 4, k & 15);      // gamma(x) slots: column 16 q + u
     if (mode == 2) return dir_feat16(k >> 3, k & 7);         // gamma(dir) slots: column 8 q + e
+    if (mode == 3) return t16_feature(k);
     return k;
 }
 

@@ -1210,12 +1210,12 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgReduceArgs a) {
             if (e < n_w) {
                 const int m = e / g.k_valid, k = e % g.k_valid;
                 off = (size_t)m * g.Kp + k;
-                const int kn = wg_colperm(g.colperm, k);         // slot-ordered columns (gamma(x) / gamma(dir) in T16) -> feature
-                dst = kn >= 0 ? g.dW + (size_t)m * g.ldw + g.col_off + kn : nullptr;
+                const int kn = wg_colperm(g.colperm, k);         // stored column / row order (T16 storage) -> feature
+                dst = kn >= 0 ? g.dW + (size_t)wg_colperm(g.rowperm, m) * g.ldw + g.col_off + kn : nullptr;
             } else {
                 const int m = e - n_w;
                 off = g.bias_off + m;
-                dst = g.dbias + m;
+                dst = g.dbias + wg_colperm(g.rowperm, m);
             }
             for (int dd = 0; dd < (dst ? g.n_desc : 0); ++dd) {
                 const float *pp = a.partial + g.part_off + (size_t)dd * g.desc_stride + off;
@@ -1296,7 +1296,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
         g.n_chunks = chunks;
         g.desc_stride = (size_t)g.n_chunks * g.part_stride;
         g.Mp = Mp; g.Kp = Kp; g.m_valid = m_valid; g.k_valid = k_valid; g.dW = dW; g.ldw = ldw; g.col_off = col_off; g.dbias = dbias;
-        g.bias_off = (size_t)Mp * Kp; g.colperm = 0;
+        g.bias_off = (size_t)Mp * Kp; g.colperm = 0; g.rowperm = 0;
     };
     const float *pex = acts + al.pex;
     // trunk

@@ -51,6 +51,11 @@ __device__ __forceinline__ float dot_ones(const bf16x8 &v, float s) {
     s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, w.z), one, s, false);
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, w.w), one, s, false);
 }
+#ifndef VN_WG16_BIG_WM
+#define VN_WG16_BIG_WM 2           // wave grid and ring depth of the 256 x 256 kernel
+#define VN_WG16_BIG_WN 4
+#define VN_WG16_BIG_NB 4
+#endif
 #ifndef VN_WG16_SIGMA_FUSED
 #define VN_WG16_SIGMA_FUSED 1      // the sigma head rides in the feature layer's GEMM (XA below); 0: its own 16 x 256 launch
 #endif
@@ -208,7 +213,7 @@ static int launch_all(const WgArgs &big, int nbig, int n_chunks, const WgArgs &p
     int rc;
     {
         ProfScope ps("wgrad_256x256", st);
-        if ((rc = launch_wg16<BF, 16, 16, 2, 4, 4, VN_WG16_SIGMA_FUSED != 0>(big, nbig, n_chunks, st))) return rc;
+        if ((rc = launch_wg16<BF, 16, 16, VN_WG16_BIG_WM, VN_WG16_BIG_WN, VN_WG16_BIG_NB, VN_WG16_SIGMA_FUSED != 0>(big, nbig, n_chunks, st))) return rc;
     }
     ProfScope ps("wgrad_small", st);
     if ((rc = launch_wg16<BF, 16, 4, 4, 1, 3>(pe, npe, n_pe, st))) return rc;
@@ -259,12 +264,12 @@ int launch_wgrad16(size_t P, int V, const float *acts, const ActLayout &al, floa
         return o;
     };
     auto group = [&](int chunks, size_t part_off, int n_desc, int Mp, int Np, int m_valid, int k_valid, float *dW, int ldw, int col_off, float *dbias,
-                     int colperm = 0) -> WgGroup & {
+                     int colperm = 0, int rowperm = 3) -> WgGroup & {
         WgGroup &g = red.g[ng++];
         g.part_off = part_off; g.part_stride = (size_t)Mp * Np + Mp; g.n_desc = n_desc; g.n_chunks = chunks;
         g.desc_stride = (size_t)chunks * g.part_stride;
         g.Mp = Mp; g.Kp = Np; g.m_valid = m_valid; g.k_valid = k_valid; g.dW = dW; g.ldw = ldw; g.col_off = col_off; g.dbias = dbias;
-        g.bias_off = (size_t)Mp * Np; g.colperm = colperm;
+        g.bias_off = (size_t)Mp * Np; g.colperm = colperm; g.rowperm = rowperm;
         return g;
     };
     const float *pex = acts + al.pex;
@@ -278,15 +283,15 @@ int launch_wgrad16(size_t P, int V, const float *acts, const ActLayout &al, floa
             const size_t o1 = add(pe, npe, n_pe, 256, 64, dy, pex);
             group(n_pe, o1, 1, 256, 64, W, 64, dW, W + DPE, 0, nullptr, 1);
             const size_t o2 = add(big, nbig, n_chunks, 256, 256, dy, acts + al.h[i - 1]);
-            group(n_chunks, o2, 1, 256, 256, W, W, dW, W + DPE, DPE, db);
+            group(n_chunks, o2, 1, 256, 256, W, W, dW, W + DPE, DPE, db, 3);
         } else {
             const size_t o = add(big, nbig, n_chunks, 256, 256, dy, acts + al.h[i - 1]);
-            group(n_chunks, o, 1, 256, 256, W, W, dW, W, 0, db);
+            group(n_chunks, o, 1, 256, 256, W, W, dW, W, 0, db, 3);
         }
     }
     {   // feature_linear
         const size_t o = add(big, nbig, n_chunks, 256, 256, bwd + bl.dyf, acts + al.h[D - 1]);
-        WgGroup &gf = group(n_chunks, o, 1, 256, 256, W, W, G->g[P_FW], W, 0, G->g[P_FB]);
+        WgGroup &gf = group(n_chunks, o, 1, 256, 256, W, W, G->g[P_FW], W, 0, G->g[P_FB], 3);
         if (VN_WG16_SIGMA_FUSED) {
             // + the sigma head as an extra A tile of this GEMM (the head-seed tile of direction 0, row 4, against the same h_8): its partial
             // [16][256] + 16 sums follows the GEMM's own in every chunk
@@ -296,19 +301,19 @@ int launch_wgrad16(size_t P, int V, const float *acts, const ActLayout &al, floa
             d.part_stride += X;
             off += (size_t)n_chunks * X;
             gf.part_stride = d.part_stride; gf.desc_stride = (size_t)n_chunks * d.part_stride;
-            WgGroup &g = group(n_chunks, o + (size_t)256 * 256 + 256 + 4 * 256, 1, 16, 256, 1, W, G->g[P_SW], W, 0, G->g[P_SB]);
+            WgGroup &g = group(n_chunks, o + (size_t)256 * 256 + 256 + 4 * 256, 1, 16, 256, 1, W, G->g[P_SW], W, 0, G->g[P_SB], 3, 0);
             g.part_stride = d.part_stride; g.desc_stride = gf.desc_stride;
             g.bias_off = (size_t)16 * 256 + 4 - 4 * 256;
         }
     }
     if (!VN_WG16_SIGMA_FUSED) {   // sigma head on its own: row 4 of the head-seed tile of direction 0 against h_8 (a second pass over h_8)
         const size_t o = add(sg, nsg, n_single, 16, 256, bwd + bl.dq[0], acts + al.h[D - 1]);
-        WgGroup &g = group(n_single, o + 4 * 256, 1, 16, 256, 1, W, G->g[P_SW], W, 0, G->g[P_SB]);
+        WgGroup &g = group(n_single, o + 4 * 256, 1, 16, 256, 1, W, G->g[P_SW], W, 0, G->g[P_SB], 3, 0);
         g.bias_off = (size_t)16 * 256 + 4 - 4 * 256;
     }
     {   // view layer, feature columns: A = sum over directions of dYv
         const size_t o = add(vf, nvf, n_single, 128, 256, bwd + bl.dyvsum, acts + al.feat);
-        group(n_single, o, 1, 128, 256, WV, W, G->g[P_VW], W + DVE, 0, G->g[P_VB]);
+        group(n_single, o, 1, 128, 256, WV, W, G->g[P_VW], W + DVE, 0, G->g[P_VB], 3);
     }
     {   // view layer, direction columns (gamma(dir) in slot order) and the output head: one GEMM per direction, summed in order
         size_t first_d = 0, first_o = 0;
@@ -321,7 +326,7 @@ int launch_wgrad16(size_t P, int V, const float *acts, const ActLayout &al, floa
             const size_t o = add(oh, noh, n_oh, 16, 128, bwd + bl.dq[k], acts + al.g[k]);
             if (k == 0) first_o = o;
         }
-        group(n_oh, first_o, 1 + V, 16, 128, 4, WV, G->g[P_OW], WV, 0, G->g[P_OB]);
+        group(n_oh, first_o, 1 + V, 16, 128, 4, WV, G->g[P_OW], WV, 0, G->g[P_OB], 3, 0);
     }
     if (off > wgrad_partial_total(P, V)) { set_error("wgrad16: partial buffer plan mismatch"); return VIPNERF_E_ARG; }
 

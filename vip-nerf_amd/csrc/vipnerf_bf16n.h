@@ -328,6 +328,7 @@ __device__ __forceinline__ void store_pair_f32(float *, int64_t, int, int, int, 
 #ifndef VN_T16_X4
 #define VN_T16_X4 1
 #endif
+constexpr int T16_SPK = VN_T16_X4 ? 1 : 2;       // store instructions store_t16 issues per k-step (what the counted stream waits assume)
 // stored feature index i (tile i >> 4, column i & 15) of a T16 array written from C/D fragments -> the feature it holds
 __host__ __device__ inline int t16_feature(int i) {
     if (!VN_T16_X4) return i;

@@ -214,8 +214,9 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
             // younger than the stage's DMA -- first stage of a layer: the epilogue before it (>= 16 gradient tile stores;
             // with deferred stores only those behind the previous GEMM's last stage, and nothing before the first layer);
             // later stages: the deferred stores behind the stage before
-            const float *st = jj == 0 ? ws.template wait<DEFER ? 2 * S_PER_STAGE : 16, DEFER ? 0 : 16>(it == 0)
-                                      : ws.template wait<DEFER ? 2 * S_PER_STAGE : 0>();
+            constexpr int DEF_SPK = H16 == 4 ? T16_SPK : 2;          // deferred store instructions per operand k-step
+            const float *st = jj == 0 ? ws.template wait<DEFER ? DEF_SPK * S_PER_STAGE : 16, DEFER ? 0 : 16>(it == 0)
+                                      : ws.template wait<DEFER ? DEF_SPK * S_PER_STAGE : 0>();
             if (DEFER) {                                 // bin = the fp16 parts of the gradient this GEMM consumes
                 DeferredStores<H16, NS, FR, S_PER_STAGE> ds{a.bwd + (it == 0 ? a.bl.dyf : a.bl.dy[layer + 1]), p, q, wave, S_PER_STAGE * jj, bin, grp, j, valid};
                 gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws, ds);

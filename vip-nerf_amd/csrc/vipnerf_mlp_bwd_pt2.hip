@@ -157,7 +157,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_bwd_pt2(MlpBwdArgs a) {
 #pragma unroll
         for (int jj = 0; jj < PL::ST_256; ++jj) {
             // younger than the stage's DMA: the deferred stores behind the stage before (nothing reliable before the first layer)
-            const float *st = jj == 0 ? ws.template wait<4 * S_PER_STAGE, 0>(it == 0) : ws.template wait<4 * S_PER_STAGE>();
+            const float *st = jj == 0 ? ws.template wait<2 * T16_SPK * S_PER_STAGE, 0>(it == 0) : ws.template wait<2 * T16_SPK * S_PER_STAGE>();
             DeferredT16<FR, S_PER_STAGE> ds{a.bwd + (it == 0 ? a.bl.dyf : a.bl.dy[layer + 1]), {grp[0], grp[1]}, {valid[0], valid[1]}, j, q, S_PER_STAGE * jj, bin};
             gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws, ds);
         }

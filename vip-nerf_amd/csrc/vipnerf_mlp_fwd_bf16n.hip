@@ -33,7 +33,8 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
     constexpr float XS = F16 ? F16_XSCALE : 1.f;           // B operands are split as XS * x
     constexpr float AU = F16 ? F16_ACC_UNSCALE : 1.f;
     constexpr bool DEFER = SAVE && H16 != 0 && VN_DEFER_STORES;   // h_1..h_8 leave from the next layer's stages (vipnerf_bf16n.h)
-    constexpr int EPI_STORES = SAVE ? 16 : 0;              // vector-memory instructions every wave issues per layer epilogue (lower bound)
+    constexpr int EPI_STORES = SAVE ? (H16 == 4 ? 8 * T16_SPK : 16) : 0;   // vector-memory instructions every wave issues per layer epilogue (lower bound; T16: the feature's)
+    constexpr int DEF_SPK = H16 == 4 ? T16_SPK : 2;        // deferred store instructions per operand k-step
     constexpr int S_PER_STAGE = 8 / PL::ST_256;            // operand k-steps a stage's deferred stores cover (2 stores each)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *res = lds;
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             for (int jj = 0; jj < PL::ST_256; ++jj) {
                 // younger than the stage's DMA -- first stage: the previous layer's epilogue (>= 16 tile stores, or just
                 // the mask store when the tiles are deferred); later stages: the deferred stores behind the stage before
-                const float *st = jj == 0 ? ws.template wait<DEFER ? 1 : EPI_STORES>() : ws.template wait<DEFER ? 2 * S_PER_STAGE : 0>();
+                const float *st = jj == 0 ? ws.template wait<DEFER ? 1 : EPI_STORES>() : ws.template wait<DEFER ? DEF_SPK * S_PER_STAGE : 0>();
                 if (DEFER) {                             // bin = the fp16 parts of h_layer, the output of layer - 1
                     DeferredStores<H16, NS, FR, S_PER_STAGE> ds{a.acts + a.al.h[layer - 1], p, q, wave, S_PER_STAGE * jj, bin, grp, j, valid};
                     gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws, ds);

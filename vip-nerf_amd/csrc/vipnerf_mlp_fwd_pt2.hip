@@ -164,7 +164,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
 #pragma unroll
         for (int jj = 0; jj < PL::ST_256; ++jj) {
             // younger than this stage's DMA: the mask stores of the previous epilogue (first stage), the deferred stores behind the stage before
-            const float *st = jj == 0 ? ws.template wait<SAVE ? 2 : 0>() : ws.template wait<SAVE ? 4 * S_PER_STAGE : 0>();
+            const float *st = jj == 0 ? ws.template wait<SAVE ? 2 : 0>() : ws.template wait<SAVE ? 2 * T16_SPK * S_PER_STAGE : 0>();
             if (SAVE) {
                 DeferredT16<FR, S_PER_STAGE> ds{a.acts + a.al.h[layer - 1], {grp[0], grp[1]}, {valid[0], valid[1]}, j, q, S_PER_STAGE * jj, bin};
                 gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws, ds);
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
             } else {
                 encode_pe(bpe);              // eval: evaluated again rather than held in 16 registers across layers 1..4
             }
-            const float *st = ws.template wait<SAVE ? 4 * S_PER_STAGE : 0>();      // behind the deferred stores of the stage before
+            const float *st = ws.template wait<SAVE ? 2 * T16_SPK * S_PER_STAGE : 0>();      // behind the deferred stores of the stage before
             gemm_stage_bf<16, 2, NS>(st, lane, acc, bpe, 0, ws);
         }
         epilogue(layer);
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
     }
     static_assert(PL::ST_VIEW_F == 1, "the feature's deferred stores assume one view stage");
     {
-        const float *st = ws.template wait<SAVE ? 4 * S_PER_STAGE : 0>();      // behind the deferred stores of the feature layer's last stage
+        const float *st = ws.template wait<SAVE ? 2 * T16_SPK * S_PER_STAGE : 0>();      // behind the deferred stores of the feature layer's last stage
         if (SAVE) {          // the feature (= this GEMM's B operand) leaves from inside the stage like h_1..h_8
             DeferredT16<FR, 8> ds{a.acts + a.al.feat, {grp[0], grp[1]}, {valid[0], valid[1]}, j, q, 0, bin};
             gemm_stage_bf<8, PL::KSV, NS>(st, lane, vb, bin, 0, ws, ds);

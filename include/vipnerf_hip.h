@@ -17,9 +17,10 @@
  *     allocated (sizes from vipnerf_query_workspace).
  *   - every function returns 0 on success, <0 on error (VIPNERF_E_*); vipnerf_last_error() gives the text
  *     (thread local).  Nothing throws, nothing synchronises the device.
- *   - re-entrant; all state is in the arguments.  One MLP topology is supported: 8x256 trunk, skip into
+ *   - re-entrant; all state is in the arguments.  The hand-written MFMA kernels serve ONE MLP topology: 8x256 trunk, skip into
  *     layer 5, positional-encoding degrees 10 (points) / 4 (directions), 128-wide view branch with an
- *     rgb(3)+visibility(1) head -- the only topology any shipped reference config uses.
+ *     rgb(3)+visibility(1) head -- the only topology any shipped reference config uses.  Every other one
+ *     MLP.__init__ can build (vipnerf_config.netdepth / netwidth / pe_degrees / head_variant) runs generic per-layer kernels, fp32.
  */
 #ifndef VIPNERF_HIP_H
 #define VIPNERF_HIP_H
@@ -31,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VIPNERF_ABI_VERSION 2
+#define VIPNERF_ABI_VERSION 3
 
 #define VIPNERF_OK             0
 #define VIPNERF_E_ARG         (-1)   /* null / inconsistent argument */
@@ -70,6 +71,10 @@ extern "C" {
 #define VIPNERF_LAYOUT_WIDE    1
 #define VIPNERF_LAYOUT_NARROW  2
 
+/* vipnerf_config.head_variant: which outputs the trunk head / the view branch predict (MLP.__init__, VipNeRF01.py:467-491) */
+#define VIPNERF_HEAD_RGB_TRUNK     1   /* mlp 'view_dependent_rgb' = False: pts_output_linear is [sigma, rgb(3)], the view branch predicts visibility only */
+#define VIPNERF_HEAD_NO_VISIBILITY 2   /* mlp 'predict_visibility' = False: no visibility outputs, n_sec must be 0; with RGB_TRUNK: no view branch at all */
+
 #define VIPNERF_MAX_SEC 3            /* secondary views V = nf-1 <= 3 (reference configs use nf in {2,3,4}) */
 #define VIPNERF_N_PARAMS 24          /* tensors of one MLP */
 
@@ -100,6 +105,8 @@ typedef struct vipnerf_config {
     int32_t netdepth;     /* 0 -> 8 */
     int32_t netwidth;     /* 0 -> 256 */
     int32_t pe_degrees;   /* points degree | views degree << 8;  0 -> 10 | 4 << 8 */
+    int32_t head_variant; /* VIPNERF_HEAD_* bits; 0 = sigma | rgb + visibility (every shipped / BASELINE config).  Any other value runs the
+                             generic per-layer kernels (fp32), whatever the trunk's size; the parameter tensors a variant lacks are NULL */
 } vipnerf_config;
 
 /* One ray batch (render_rays' input_dict, src/models/VipNeRF01.py:74-98).  N = n_rays. */

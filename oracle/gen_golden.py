@@ -72,17 +72,20 @@ def record_searchsorted(log):
         torch.searchsorted = s0
 
 
-def ref_configs(ndc, depth=8, width=256, n_coarse=64, n_fine=128, netchunk=4096, chunk=4096, sparse=False):
+def ref_configs(ndc, depth=8, width=256, n_coarse=64, n_fine=128, netchunk=4096, chunk=4096, sparse=False,
+                view_dep_rgb=True, predict_vis=True):
     def mlp(ns):
         return {'num_samples': ns, 'netdepth': depth, 'netwidth': width,
                 'points_positional_encoding_degree': 10, 'views_positional_encoding_degree': 4,
-                'use_view_dirs': True, 'view_dependent_rgb': True, 'predict_visibility': True}
+                'use_view_dirs': True, 'view_dependent_rgb': view_dep_rgb, 'predict_visibility': predict_vis}
     model = {'name': 'VipNeRF01', 'coarse_mlp': mlp(n_coarse), 'chunk': chunk, 'lindisp': False,
              'netchunk': netchunk, 'perturb': True, 'raw_noise_std': 1.0, 'white_bkgd': False}
     if n_fine > 0:
         model['fine_mlp'] = mlp(n_fine)
     losses = [{'name': 'MSE01', 'weight': 1}, {'name': 'VisibilityLoss01', 'weight': 0.1},
               {'name': 'VisibilityPriorLoss01', 'iter_weights': {'0': 0, '30000': 0.001}}]
+    if not predict_vis:
+        losses = losses[:1]                      # the visibility losses read visibility2_*, which such a model does not output
     if sparse:
         losses.append({'name': 'SparseDepthMSE01', 'weight': 0.1})
     return {'data_loader': {'ndc': ndc}, 'model': model, 'losses': losses, 'device': [0]}
@@ -271,14 +274,15 @@ def gen_f4():
         **{'plain_' + k: v for k, v in out_plain.items()}, **d)
 
 
-def gen_f5(tag, scene, nf, n, n_sparse, seed, depth=8, width=256, n_fine=128, pscale=1.6, white_bkgd=False, lindisp=False):
+def gen_f5(tag, scene, nf, n, n_sparse, seed, depth=8, width=256, n_fine=128, pscale=1.6, white_bkgd=False, lindisp=False,
+           view_dep_rgb=True, predict_vis=True):
     b = vo.synthetic_batch(n, seed, scene=scene, nf=nf, n_sparse=n_sparse)
     ndc = b['ndc']
     levels = ('coarse', 'fine') if n_fine > 0 else ('coarse',)
     cfg = ref_configs(ndc, depth=depth, width=width, n_fine=n_fine, netchunk=1024, chunk=4096,
-                      sparse=n_sparse > 0)
+                      sparse=n_sparse > 0, view_dep_rgb=view_dep_rgb, predict_vis=predict_vis)
     cfg['model'].update(white_bkgd=white_bkgd, lindisp=lindisp)      # branches no shipped config takes (VipNeRF01.py:190-193, 379-380)
-    params = vo.init_params(seed + 1, depth=depth, width=width, levels=levels, scale=pscale)
+    params = vo.init_params(seed + 1, depth=depth, width=width, levels=levels, scale=pscale, view_dep_rgb=view_dep_rgb, predict_vis=predict_vis)
     model = ref_model(cfg, params).train()
     lossc = LossComputer(cfg)
     opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.999))
@@ -306,6 +310,7 @@ def gen_f5(tag, scene, nf, n, n_sparse, seed, depth=8, width=256, n_fine=128, ps
         d['adig_' + k] = digest(v)
     npz(f'f5_train_{tag}', scene=scene, nf=nf, n=n, n_sparse=n_sparse, seed_batch=seed, seed_params=seed + 1,
         scale_params=pscale, depth=depth, width=width, n_fine=n_fine, white_bkgd=white_bkgd, lindisp=lindisp,
+        **({} if view_dep_rgb and predict_vis else {'view_dep_rgb': view_dep_rgb, 'predict_vis': predict_vis, 'out_keys': np.array(sorted(out.keys()))}),
         **({'sample_inds': torch.cat(slog, 0).to(torch.int32)} if slog else {}),
         **{'rng_' + k: v for k, v in rng.items()}, **d)
 
@@ -472,6 +477,10 @@ if __name__ == '__main__':
     gen_f5('dtu', 'dtu', 3, 24, 0, 520)
     gen_f5('toy', 'toy', 2, 64, 0, 530, depth=4, width=64, n_fine=0, pscale=1.0)
     gen_f5('dtu4wl', 'dtu', 4, 20, 0, 540, white_bkgd=True, lindisp=True)      # V = 3 secondary views, white background, lindisp
+    # head variants no shipped config uses (MLP.__init__, VipNeRF01.py:467-491): rgb from the trunk head / no visibility / neither
+    gen_f5('toy_rgbtrunk', 'toy', 2, 48, 0, 550, depth=4, width=64, n_fine=0, pscale=1.0, view_dep_rgb=False)
+    gen_f5('dtu_novis', 'dtu', 3, 16, 0, 560, depth=6, width=64, n_fine=32, pscale=1.3, predict_vis=False)
+    gen_f5('fern_plain', 'fern', 2, 16, 0, 570, depth=8, width=32, n_fine=64, pscale=1.6, view_dep_rgb=False, predict_vis=False)
     gen_f6()
     gen_f6b()
     gen_f7()

@@ -43,12 +43,17 @@ EPS_PDF = 1e-5  # importance-sampling weight floor and denominator switch
 
 
 # ----------------------------------------------------------------------------------------------- parameters
-def mlp_param_shapes(depth: int = 8, width: int = 256, l_pts: int = 10, l_view: int = 4):
+def mlp_param_shapes(depth: int = 8, width: int = 256, l_pts: int = 10, l_view: int = 4,
+                     view_dep_rgb: bool = True, predict_vis: bool = True):
     """Names and shapes of one MLP's parameters, in the reference's construction order
     (VipNeRF01.py:472-491): pts_linears[0..D-1], views_linears[0], pts_output_linear, feature_linear,
-    views_output_linear.  nn.Linear layout: weight[out, in], bias[out]."""
+    views_output_linear.  nn.Linear layout: weight[out, in], bias[out].  view_dep_rgb / predict_vis: the mlp configs'
+    `view_dependent_rgb` / `predict_visibility` (VipNeRF01.py:467-469, 477-491): rgb moves to the trunk head, visibility is
+    dropped, and without either there is no view branch."""
     d_pts = 3 + 6 * l_pts
     d_view = 3 + 6 * l_view
+    n_trunk = 1 + (0 if view_dep_rgb else 3)
+    n_view = (3 if view_dep_rgb else 0) + (1 if predict_vis else 0)
     shapes = []
     for i in range(depth):
         if i == 0:
@@ -59,30 +64,33 @@ def mlp_param_shapes(depth: int = 8, width: int = 256, l_pts: int = 10, l_view: 
             k = width
         shapes.append((f'pts_linears.{i}.weight', (width, k)))
         shapes.append((f'pts_linears.{i}.bias', (width,)))
-    shapes.append(('views_linears.0.weight', (width // 2, width + d_view)))
-    shapes.append(('views_linears.0.bias', (width // 2,)))
-    shapes.append(('pts_output_linear.weight', (1, width)))
-    shapes.append(('pts_output_linear.bias', (1,)))
-    shapes.append(('feature_linear.weight', (width, width)))
-    shapes.append(('feature_linear.bias', (width,)))
-    shapes.append(('views_output_linear.weight', (4, width // 2)))
-    shapes.append(('views_output_linear.bias', (4,)))
+    if n_view:
+        shapes.append(('views_linears.0.weight', (width // 2, width + d_view)))
+        shapes.append(('views_linears.0.bias', (width // 2,)))
+    shapes.append(('pts_output_linear.weight', (n_trunk, width)))
+    shapes.append(('pts_output_linear.bias', (n_trunk,)))
+    if n_view:
+        shapes.append(('feature_linear.weight', (width, width)))
+        shapes.append(('feature_linear.bias', (width,)))
+        shapes.append(('views_output_linear.weight', (n_view, width // 2)))
+        shapes.append(('views_output_linear.bias', (n_view,)))
     return shapes
 
 
 def init_params(seed: int, depth: int = 8, width: int = 256, l_pts: int = 10, l_view: int = 4,
-                levels=('coarse', 'fine'), scale: float = 1.0, sigma_bias: float = 0.0) -> Dict[str, np.ndarray]:
+                levels=('coarse', 'fine'), scale: float = 1.0, sigma_bias: float = 0.0,
+                view_dep_rgb: bool = True, predict_vis: bool = True) -> Dict[str, np.ndarray]:
     """Deterministic, platform-independent parameter set (numpy PCG64), U(-1/sqrt(in), 1/sqrt(in)) like
     nn.Linear's default.  Keys follow the reference's state_dict: `coarse_model.pts_linears.0.weight`, ..."""
     rng = np.random.default_rng(seed)
     out = {}
+    shapes = mlp_param_shapes(depth, width, l_pts, l_view, view_dep_rgb, predict_vis)
     for level in levels:
-        for name, shape in mlp_param_shapes(depth, width, l_pts, l_view):
-            fan_in = shape[1] if len(shape) == 2 else dict(mlp_param_shapes(depth, width, l_pts, l_view))[
-                name.replace('bias', 'weight')][1]
+        for name, shape in shapes:
+            fan_in = shape[1] if len(shape) == 2 else dict(shapes)[name.replace('bias', 'weight')][1]
             bound = scale / math.sqrt(fan_in)
             out[f'{level}_model.{name}'] = rng.uniform(-bound, bound, size=shape).astype(np.float32)
-        out[f'{level}_model.pts_output_linear.bias'] += np.float32(sigma_bias)   # lets eval-mode tests see non-zero density
+        out[f'{level}_model.pts_output_linear.bias'][0] += np.float32(sigma_bias)   # lets eval-mode tests see non-zero density
     return out
 
 
@@ -109,9 +117,10 @@ def _linear(p, prefix, h):
 def mlp_forward(p: Dict[str, torch.Tensor], level: str, pts: torch.Tensor, view_dirs: torch.Tensor,
                 view_dirs2: Optional[torch.Tensor], noise: Optional[torch.Tensor],
                 depth: int = 8, l_pts: int = 10, l_view: int = 4, noise_std: float = 1.0,
-                want_feature: bool = False):
+                want_feature: bool = False, view_dep_rgb: bool = True, predict_vis: bool = True):
     """pts (P,3), view_dirs (P,3), view_dirs2 (P,V,3) or None, noise (P,) or None ->
-    dict(sigma (P,), rgb (P,3), visibility (P,), visibility2 (P,V))."""
+    dict(sigma (P,), rgb (P,3), visibility (P,) [if predicted], visibility2 (P,V) [if predicted and view_dirs2 given]).
+    MLP.forward, VipNeRF01.py:509-596."""
     pre = f'{level}_model.'
     g = positional_encode(pts, l_pts)
     h = g
@@ -119,10 +128,15 @@ def mlp_forward(p: Dict[str, torch.Tensor], level: str, pts: torch.Tensor, view_
         h = torch.relu(_linear(p, f'{pre}pts_linears.{i}', h))
         if i == 4:
             h = torch.cat([g, h], dim=-1)
-    s_raw = _linear(p, f'{pre}pts_output_linear', h)[..., 0]
+    trunk = _linear(p, f'{pre}pts_output_linear', h)
+    s_raw = trunk[..., 0]
     if noise is not None:
         s_raw = s_raw + noise * noise_std
-    sigma = torch.relu(s_raw)
+    out = {'sigma': torch.relu(s_raw)}
+    if not view_dep_rgb:
+        out['rgb'] = torch.sigmoid(trunk[..., 1:4])
+    if not (view_dep_rgb or predict_vis):
+        return out
     feat = _linear(p, f'{pre}feature_linear', h)
 
     def head(dirs):
@@ -132,15 +146,19 @@ def mlp_forward(p: Dict[str, torch.Tensor], level: str, pts: torch.Tensor, view_
         return torch.sigmoid(_linear(p, f'{pre}views_output_linear', hv))
 
     q = head(view_dirs)
-    out = {'sigma': sigma, 'rgb': q[..., 0:3], 'visibility': q[..., 3]}
-    if view_dirs2 is not None:
-        out['visibility2'] = head(view_dirs2)[..., 3]
+    c = 0
+    if view_dep_rgb:
+        out['rgb'] = q[..., 0:3]
+        c = 3
+    if predict_vis:
+        out['visibility'] = q[..., c]
+        if view_dirs2 is not None:
+            out['visibility2'] = head(view_dirs2)[..., c]
     if want_feature:
         out['feature'] = feat
     return out
 
 
-# ----------------------------------------------------------------------------------------------- sampling
 def coarse_depths(near: torch.Tensor, far: torch.Tensor, n_samples: int, t_rand: Optional[torch.Tensor],
                   lindisp: bool = False) -> torch.Tensor:
     """near, far (N,1) -> (N,S).  t_rand (N,S) in [0,1) switches stratified jitter on."""
@@ -274,11 +292,11 @@ def render_rays(p: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], cfg:
         o_s, d_s, near, far = o, d, batch['near'], batch['far']
     vdir = batch['view_dirs']
     o2 = None
-    if sec_views:
+    if sec_views and cfg.get('predict_vis', True):
         o2 = batch['rays_o2'] if 'rays_o2' in batch else secondary_origins(
             batch['poses'], batch['pixel_id'][:, 0].long(), int(batch['num_frames']))
     kw = dict(depth=cfg.get('depth', 8), l_pts=cfg.get('l_pts', 10), l_view=cfg.get('l_view', 4),
-              noise_std=cfg.get('noise_std', 1.0))
+              noise_std=cfg.get('noise_std', 1.0), view_dep_rgb=cfg.get('view_dep_rgb', True), predict_vis=cfg.get('predict_vis', True))
     use_noise = train and rng is not None and cfg.get('noise_std', 1.0) > 0 and 'noise_coarse' in rng
     ret = {}
 
@@ -303,8 +321,9 @@ def render_rays(p: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], cfg:
             ret[f'{k}_{level}'] = v
         ret[f'raw_sigma_{level}'] = net['sigma'][..., None]
         ret[f'raw_rgb_{level}'] = net['rgb']
-        ret[f'raw_rgb_view_dependent_{level}'] = net['rgb']
-        ret[f'raw_visibility_{level}'] = net['visibility'][..., None]
+        ret[f"raw_rgb_view_{'dependent' if cfg.get('view_dep_rgb', True) else 'independent'}_{level}"] = net['rgb']
+        if 'visibility' in net:
+            ret[f'raw_visibility_{level}'] = net['visibility'][..., None]
         if 'visibility2' in net:
             ret[f'raw_visibility2_{level}'] = net['visibility2'][..., None]
         return comp

@@ -2,6 +2,7 @@
 declares, argument validation works without a GPU, and the product path refuses to run without the library / on
 CPU tensors (no silent fallback)."""
 import ctypes as C
+import math
 import os
 import re
 import sys
@@ -28,14 +29,14 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f'{n} declared in include/vipnerf_hip.h but not exported'
     assert set(names) == set(_lib.SYMBOLS), 'ctypes binding and header disagree'
-    assert lib.vipnerf_abi_version() == 2
+    assert lib.vipnerf_abi_version() == 3
     wide = 4 * (72 * 8192 + 68 * 8192 + 7424)      # the unsuffixed pair = precision FP32: [wide image][narrow image]
     assert lib.vipnerf_packed_weights_bytes() == lib.vipnerf_packed_weights_bytes_p(0) > wide
 
 
 def test_struct_sizes_match_header():
     from vipnerf_hip import _lib
-    assert C.sizeof(_lib.Config) == 16 * 4
+    assert C.sizeof(_lib.Config) == 17 * 4
     assert C.sizeof(_lib.Rays) == 8 + 8 * 8
     assert C.sizeof(_lib.LevelOut) == 15 * 8
     assert C.sizeof(_lib.Outputs) == 2 * 15 * 8 + 16
@@ -98,9 +99,25 @@ def test_product_path_has_no_cpu_fallback():
     with pytest.raises(_lib.VipNerfHipError):
         get_model({'data_loader': {'ndc': False}, 'model': {'name': 'VipNeRFHip01', 'hip_precision': 'fp16x3',
                                                              'coarse_mlp': dict(mlp, netwidth=64, netdepth=4)}}, None)
-    for bad in (dict(mlp, netwidth=100), dict(mlp, netdepth=9), dict(mlp, use_view_dirs=False), dict(mlp, predict_visibility=False)):
+    for bad in (dict(mlp, netwidth=100), dict(mlp, netdepth=9), dict(mlp, use_view_dirs=False)):
         with pytest.raises(_lib.VipNerfHipError):
             get_model({'data_loader': {'ndc': False}, 'model': {'name': 'VipNeRFHip01', 'coarse_mlp': bad}}, None)
+    # the head variants (view_dependent_rgb / predict_visibility = False, VipNeRF01.py:467-491): the reference's parameter set (the oracle's
+    # shapes are pinned to the reference by goldens F5 toy_rgbtrunk / dtu_novis / fern_plain), generic kernels, fp32 only
+    from oracle import vipnerf_oracle as vo
+    from vipnerf_hip import ops
+    for vd, pv in ((False, True), (True, False), (False, False)):
+        m = get_model({'data_loader': {'ndc': False}, 'model': {'name': 'VipNeRFHip01', 'coarse_mlp': dict(mlp, view_dependent_rgb=vd, predict_visibility=pv)}}, None)
+        want = [('coarse_model.' + k, s) for k, s in vo.mlp_param_shapes(view_dep_rgb=vd, predict_vis=pv)]
+        assert [(k, tuple(p.shape)) for k, p in m.named_parameters()] == want
+        topo = m.topology
+        assert topo[4] == (0 if vd else ops.HEAD_RGB_TRUNK) | (0 if pv else ops.HEAD_NO_VISIBILITY)
+        assert ops.param_order(topo) == [k for k, _ in vo.mlp_param_shapes(view_dep_rgb=vd, predict_vis=pv)]
+        assert ops.param_shapes(topo) == [s for _, s in vo.mlp_param_shapes(view_dep_rgb=vd, predict_vis=pv)]
+        assert len(ops.param_slots(topo)) == len(want) and m.predict_visibility == pv
+        with pytest.raises(_lib.VipNerfHipError):
+            get_model({'data_loader': {'ndc': False}, 'model': {'name': 'VipNeRFHip01', 'hip_precision': 'bf16',
+                                                                 'coarse_mlp': dict(mlp, view_dependent_rgb=vd, predict_visibility=pv)}}, None)
 
 
 def test_oracle_is_not_imported_by_the_product():
@@ -218,3 +235,55 @@ def test_flat_adam_is_torch_adam():
         for a, b in zip(ref, mine):
             assert torch.equal(a.detach(), b.detach()), f'step {it}'
     assert all(p.data_ptr() == o_mine.flat[sum(q.numel() for q in mine[:i]):].data_ptr() for i, p in enumerate(mine))
+
+
+def test_flat_adam_state_dict_is_torch_adams():
+    """FlatAdam.state_dict() / load_state_dict() use torch.optim.Adam's format: a run checkpointed with one optimizer resumes with the
+    other and continues bit for bit (the `optimizer_state_dict` of the reference's checkpoints, Trainer01.py:352-381)."""
+    import io
+    import torch
+    from vipnerf_hip.optim import FlatAdam
+    torch.manual_seed(1)
+    shapes = [(64, 63), (64,), (4, 32), (1,)]
+    n = sum(math.prod(s) for s in shapes)
+    grads = [torch.randn(n) * 0.1 for _ in range(6)]
+
+    def run(params, opt, its):
+        for it in its:
+            off = 0
+            for p in params:
+                p.grad = grads[it][off:off + p.numel()].view(p.shape).clone()
+                off += p.numel()
+            opt.step()
+
+    def through_file(sd):
+        f = io.BytesIO()
+        torch.save(sd, f)
+        f.seek(0)
+        return torch.load(f, weights_only=False)
+
+    init = [torch.randn(s) for s in shapes]
+    straight = [torch.nn.Parameter(t.clone()) for t in init]
+    run(straight, torch.optim.Adam(straight, lr=5e-4, foreach=False, fused=False), range(6))
+
+    a = [torch.nn.Parameter(t.clone()) for t in init]                     # torch -> FlatAdam -> torch
+    oa = torch.optim.Adam(a, lr=5e-4, foreach=False, fused=False)
+    run(a, oa, range(2))
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    ob = FlatAdam(b, lr=1.0)
+    ob.load_state_dict(through_file(oa.state_dict()))
+    assert ob.t == 2 and ob.param_groups[0]['lr'] == 5e-4
+    run(b, ob, range(2, 4))
+    c = [torch.nn.Parameter(p.detach().clone()) for p in b]
+    oc = torch.optim.Adam(c, lr=1.0, foreach=False, fused=False)
+    oc.load_state_dict(through_file(ob.state_dict()))
+    run(c, oc, range(4, 6))
+    for x, y in zip(straight, c):
+        assert torch.equal(x.detach(), y.detach())
+
+    fresh = FlatAdam([torch.nn.Parameter(t.clone()) for t in init])        # before the first step: empty state, like torch
+    assert fresh.state_dict()['state'] == {}
+    ob.load_state_dict(fresh.state_dict())
+    assert ob.t == 0 and float(ob.exp_avg.abs().max()) == 0
+    with pytest.raises(ValueError):
+        ob.load_state_dict(torch.optim.Adam(a[:2]).state_dict())

@@ -607,6 +607,118 @@ def test_toy_config_golden(dev):
     opt.step()
 
 
+@pytest.mark.parametrize('tag', ['toy_rgbtrunk', 'dtu_novis', 'fern_plain'])
+def test_head_variants_golden(dev, tag):
+    """mlp `view_dependent_rgb` / `predict_visibility` = False (MLP.__init__, VipNeRF01.py:467-491; no shipped config): rgb from the trunk
+    head (visibility-only view branch), no visibility (rgb-only view branch, MSE only, no secondary views), neither (no feature / view
+    layers at all) -- one training step against goldens captured from the reference: the reference's key set and parameter set, outputs,
+    losses, parameter gradients; then the same weights in eval mode against the oracle."""
+    from loss_functions.LossComputerHip01 import LossComputerHip
+    from models.ModelFactory import get_model
+    g = tp.load(f'f5_train_{tag}')
+    depth, width, n_fine = int(g['depth']), int(g['width']), int(g['n_fine'])
+    heads = dict(view_dep_rgb=bool(g['view_dep_rgb']), predict_vis=bool(g['predict_vis']))
+    levels = ('coarse', 'fine') if n_fine else ('coarse',)
+    b = vo.synthetic_batch(int(g['n']), int(g['seed_batch']), scene=str(g['scene']), nf=int(g['nf']))
+    params = vo.init_params(int(g['seed_params']), depth=depth, width=width, levels=levels, scale=float(g['scale_params']), **heads)
+    _, cfg = tp.make_model(dev, b['ndc'], None, n_fine=n_fine)
+    for k in ('coarse_mlp', 'fine_mlp'):
+        if k in cfg['model']:
+            cfg['model'][k].update(netdepth=depth, netwidth=width, view_dependent_rgb=heads['view_dep_rgb'], predict_visibility=heads['predict_vis'])
+    if not heads['predict_vis']:
+        cfg['losses'] = cfg['losses'][:1]
+    model = get_model(cfg, None)
+    assert [k for k, _ in model.named_parameters()] == list(params.keys()), 'parameter names / order of the variant'
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()}, strict=True)
+    model = model.to(dev).train()
+    model.injected_rng = {k[4:]: tp.cu(v, dev) for k, v in g.items() if k.startswith('rng_')}
+    if n_fine:
+        model.injected_z_fine = tp.cu(g['out_z_vals_fine'], dev)       # teacher-forced fine depths, like the other train-step goldens
+    rb = tp.ref_batch(b, dev, 40000)
+    out = model(rb)
+    ref_keys = {str(k) for k in g['out_keys']}
+    assert set(out.keys()) == ref_keys, sorted(set(out.keys()) ^ ref_keys)
+    for lv in levels:
+        for rk in tp.KEYMAP:
+            gk = f'out_{rk}_{lv}'
+            if gk in g:
+                if rk.startswith('depth'):
+                    assert_close_few_outliers(out[f'{rk}_{lv}'], torch.from_numpy(g[gk]), 1e-4, f'{tag} {rk}_{lv}', max_frac=0.1)
+                else:
+                    tp.assert_close(out[f'{rk}_{lv}'], g[gk], what=f'{tag} {rk}_{lv}')
+    names = {'MSEHip01': 'MSE01', 'VisibilityLossHip01': 'VisibilityLoss01', 'VisibilityPriorLossHip01': 'VisibilityPriorLoss01', 'TotalLoss': 'TotalLoss'}
+    lossc = LossComputerHip(cfg)
+    l40k = lossc.compute_losses(rb, out)
+    assert {names[k] for k in l40k} == {k[5:] for k in g if k.startswith('l40k_')}
+    for k, v in l40k.items():
+        tp.assert_close(v['loss_value'] if isinstance(v, dict) else v, g[f'l40k_{names[k]}'], rtol=2e-4, floor=1e-6, what=f'{tag} loss {k}')
+    l40k['TotalLoss'].backward()
+    for k, p in model.named_parameters():
+        if 'grad_' + k in g:
+            tp.grad_close(p.grad.cpu().numpy(), g['grad_' + k], f'{tag} grad of {k}')
+        np.testing.assert_allclose(float(p.grad.double().norm()), g['gdig_' + k][1], rtol=1e-3, atol=1e-9, err_msg=k)
+    if not heads['predict_vis']:                 # the visibility losses cannot be configured on such a model: the reference's KeyError
+        bad = dict(cfg, losses=[{'name': 'MSEHip01', 'weight': 1}, {'name': 'VisibilityLossHip01', 'weight': 0.1}])
+        with pytest.raises(KeyError):
+            LossComputerHip(bad).compute_losses(rb, {k: v.detach() for k, v in out.items()})
+    # eval mode against the oracle's render of the same weights
+    model.eval()
+    model.injected_rng = model.injected_z_fine = None
+    with torch.no_grad():
+        ev = model(tp.ref_batch(b, dev, 0), retraw=True, sec_views_vis=True)
+    cfg_o = {'ndc': b['ndc'], 'n_coarse': 64, 'n_fine': n_fine, 'depth': depth, **heads}
+    ro = vo.render_rays(vo.params_to_torch(params), b, cfg_o, None, train=False, sec_views=True)
+    for k in ('rgb_coarse', 'acc_coarse', 'raw_sigma_coarse', 'raw_rgb_coarse') + (('visibility2_coarse', 'raw_visibility_coarse') if heads['predict_vis'] else ()):
+        tp.assert_close(ev[k], ro[k], what=f'{tag} eval {k}')
+    assert ('visibility2_coarse' in ev) == heads['predict_vis']
+    if n_fine:
+        ef = (ev['rgb_fine'].cpu() - ro['rgb_fine']).abs().max()
+        print(f'{tag}: free-running eval rgb_fine max abs err {float(ef):.3e}')
+        assert float(ef) <= 3e-4
+
+
+def test_head_variant_of_the_default_trunk_and_refusals(dev):
+    """The 8 x 256 trunk with a head variant runs the generic kernels too (the MFMA kernels are specialised on the default heads): one
+    training step against the oracle; the 16-bit arithmetics and secondary views without visibility prediction are refused loudly."""
+    from loss_functions.LossComputerHip01 import LossComputerHip
+    from models.ModelFactory import get_model
+    from vipnerf_hip import _lib as L
+    from vipnerf_hip import ops
+    heads = dict(view_dep_rgb=False, predict_vis=True)
+    n = 24
+    b = vo.synthetic_batch(n, 811, scene='fern', nf=2)
+    params = vo.init_params(812, scale=1.6, **heads)
+    rng = vo.synthetic_rng(n, 64, 128, 813)
+    p = vo.params_to_torch(params, requires_grad=True)
+    cfg_o = {'ndc': True, 'n_coarse': 64, 'n_fine': 128, 'noise_std': 1.0, **heads}
+    ref = vo.render_rays(p, b, cfg_o, rng, train=True, sec_views=True)
+    lcfg = [{'name': 'MSE01', 'weight': 1}, {'name': 'VisibilityLoss01', 'weight': 0.1}, {'name': 'VisibilityPriorLoss01', 'iter_weights': {'0': 0, '30000': 0.001}}]
+    lref = vo.total_loss(b, ref, lcfg, 40000)
+    lref['TotalLoss'].backward()
+    _, cfg = tp.make_model(dev, True, None)
+    for k in ('coarse_mlp', 'fine_mlp'):
+        cfg['model'][k].update(view_dependent_rgb=False)
+    model = get_model(cfg, None)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()}, strict=True)
+    model = model.to(dev).train()
+    model.injected_rng = {k: v.to(dev) for k, v in rng.items()}
+    model.injected_z_fine = ref['z_vals_fine'].detach().to(dev)
+    rb = tp.ref_batch(b, dev, 40000)
+    out = model(rb)
+    for k in ('rgb_coarse', 'rgb_fine', 'visibility2_fine', 'raw_rgb_view_independent_fine', 'raw_visibility2_coarse', 'weights_fine'):
+        tp.assert_close(out[k], ref[k], what=f'8x256 rgb-trunk {k}')
+    lh = LossComputerHip(cfg).compute_losses(rb, out)
+    tp.assert_close(lh['TotalLoss'], lref['TotalLoss'], rtol=1e-4, floor=1e-6, what='TotalLoss')
+    lh['TotalLoss'].backward()
+    for k, t in model.named_parameters():
+        tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'8x256 rgb-trunk grad {k}')
+    cfg['model']['hip_precision'] = 'bf16'
+    with pytest.raises(L.VipNerfHipError, match='fp32 only'):
+        get_model(cfg, None)
+    with pytest.raises(L.VipNerfHipError, match='NO_VISIBILITY'):
+        ops.query_workspace(ops.make_config(True, 64, 128, 1, True, topology=(8, 256, 10, 4, ops.HEAD_NO_VISIBILITY)), 16)
+
+
 @pytest.mark.parametrize('depth,width,scene,nf', [(6, 128, 'fern', 2), (3, 32, 'dtu', 3), (8, 192, 'realestate', 3)])
 def test_other_topologies_vs_oracle(dev, depth, width, scene, nf):
     """Topologies other than 8 x 256 -- with and without the skip connection (depth > 5), coarse + fine, NDC and not, V = 1, 2,

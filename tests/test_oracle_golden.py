@@ -99,23 +99,30 @@ def test_f4_eval_render():
         close(plain[str(k)], g['plain_' + str(k)], rtol=2e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize('tag', ['llff', 'realestate', 'dtu', 'toy', 'dtu4wl'])
+@pytest.mark.parametrize('tag', ['llff', 'realestate', 'dtu', 'toy', 'dtu4wl', 'toy_rgbtrunk', 'dtu_novis', 'fern_plain'])
 def test_f5_train_step(tag):
+    """One training step of the reference, captured: outputs, losses, parameter gradients, one Adam step.  The last three are the head
+    variants no shipped config uses (mlp `view_dependent_rgb` / `predict_visibility` = False, VipNeRF01.py:467-491): rgb from the trunk
+    head, no visibility (MSE only), neither (no view branch)."""
     g = load(f'f5_train_{tag}')
+    heads = dict(view_dep_rgb=bool(g['view_dep_rgb']) if 'view_dep_rgb' in g else True, predict_vis=bool(g['predict_vis']) if 'predict_vis' in g else True)
     depth, width, n_fine = int(g['depth']), int(g['width']), int(g['n_fine'])
     levels = ('coarse', 'fine') if n_fine > 0 else ('coarse',)
     b = vo.synthetic_batch(int(g['n']), int(g['seed_batch']), scene=str(g['scene']), nf=int(g['nf']),
                            n_sparse=int(g['n_sparse']))
     params = vo.init_params(int(g['seed_params']), depth=depth, width=width, levels=levels,
-                            scale=float(g['scale_params']))
+                            scale=float(g['scale_params']), **heads)
     p = vo.params_to_torch(params, requires_grad=True)
     rng = {k[4:]: T(v) for k, v in g.items() if k.startswith('rng_')}
     cfg = _cfg(b['ndc'], n_fine, depth)
-    cfg.update(white_bkgd=bool(g.get('white_bkgd', False)), lindisp=bool(g.get('lindisp', False)))   # 'dtu4wl': V = 3, both on
+    cfg.update(white_bkgd=bool(g.get('white_bkgd', False)), lindisp=bool(g.get('lindisp', False)), **heads)   # 'dtu4wl': V = 3, both on
     out = vo.render_rays(p, b, cfg, rng, train=True, sec_views=True)
     _check_outputs(out, g, levels, rtol=2e-5, atol=2e-6)
+    if 'out_keys' in g:                          # the variant's key set is the reference's (raw_rgb_view_independent_*, no visibility2_* ...)
+        assert {str(k) for k in g['out_keys']} <= set(out.keys()), sorted({str(k) for k in g['out_keys']} - set(out.keys()))
+        assert not [k for k in out if ('visibility2' in k or 'raw_visibility' in k or 'view_' in k) and k not in {str(q) for q in g['out_keys']}]
     lcfg = [{'name': 'MSE01', 'weight': 1}, {'name': 'VisibilityLoss01', 'weight': 0.1},
-            {'name': 'VisibilityPriorLoss01', 'iter_weights': {'0': 0, '30000': 0.001}}]
+            {'name': 'VisibilityPriorLoss01', 'iter_weights': {'0': 0, '30000': 0.001}}][:3 if heads['predict_vis'] else 1]
     if int(g['n_sparse']) > 0:
         lcfg.append({'name': 'SparseDepthMSE01', 'weight': 0.1})
     for nm, it in (('l40k', 40000), ('l0', 0)):

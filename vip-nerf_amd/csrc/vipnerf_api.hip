@@ -81,14 +81,20 @@ static int check_cfg(const vipnerf_config *cfg) {
     if (dpt < 1 || dpt > D || wid < 8 || wid > W || wid % 8 || lp < 0 || lp > 16 || lv < 0 || lv > 8) {
         set_error("MLP topology netdepth=%d netwidth=%d degrees %d/%d unsupported (depth 1..8, width 8..256 multiple of 8, degrees <= 16 / 8)",
                   dpt, wid, lp, lv); return VIPNERF_E_UNSUPPORTED; }
-    if (!gen_is_fused_topology(gen_topo(dpt, wid, lp, lv)) && cfg->precision != VIPNERF_PREC_FP32) {
-        set_error("the generic-topology kernels (netdepth=%d netwidth=%d) are fp32 only; precision=%d", dpt, wid, cfg->precision);
+    if (cfg->head_variant < 0 || cfg->head_variant > (VIPNERF_HEAD_RGB_TRUNK | VIPNERF_HEAD_NO_VISIBILITY)) {
+        set_error("head_variant=%d unsupported (VIPNERF_HEAD_* bits)", cfg->head_variant); return VIPNERF_E_UNSUPPORTED; }
+    if ((cfg->head_variant & VIPNERF_HEAD_NO_VISIBILITY) && cfg->n_sec > 0) {
+        set_error("n_sec=%d with VIPNERF_HEAD_NO_VISIBILITY: an MLP that predicts no visibility has no secondary views (VipNeRF01.py:84)", cfg->n_sec);
+        return VIPNERF_E_UNSUPPORTED; }
+    if (!gen_is_fused_topology(gen_topo(dpt, wid, lp, lv, cfg->head_variant)) && cfg->precision != VIPNERF_PREC_FP32) {
+        set_error("the generic-topology kernels (netdepth=%d netwidth=%d head_variant=%d) are fp32 only; precision=%d", dpt, wid, cfg->head_variant,
+                  cfg->precision);
         return VIPNERF_E_UNSUPPORTED; }
     return VIPNERF_OK;
 }
 static GenTopo cfg_topo(const vipnerf_config *cfg) {
     return gen_topo(cfg->netdepth ? cfg->netdepth : D, cfg->netwidth ? cfg->netwidth : W, cfg->pe_degrees ? (cfg->pe_degrees & 0xff) : LP,
-                    cfg->pe_degrees ? ((cfg->pe_degrees >> 8) & 0xff) : LV);
+                    cfg->pe_degrees ? ((cfg->pe_degrees >> 8) & 0xff) : LV, cfg->head_variant);
 }
 static bool cfg_generic(const vipnerf_config *cfg) { return !gen_is_fused_topology(cfg_topo(cfg)); }
 
@@ -453,7 +459,7 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
             const PointSrc src = ray_points(cfg, rays, S, L.z_vals);
             const float *ga = (const float *)acts + (lv ? gen_acts((size_t)N * Sc, V, t).total : 0);
             ProfScope ps(lv ? "mlp_bwd_generic_fine" : "mlp_bwd_generic_coarse", st);
-            if ((rc = launch_gen_bwd(t, src, (const float *)(lv ? packed_fine : packed_coarse), L.raw_sigma, ga, bw, gb, G, st))) return rc;
+            if ((rc = launch_gen_bwd(t, src, (const float *)(lv ? packed_fine : packed_coarse), L.raw_sigma, L.raw_rgb, ga, bw, gb, G, st))) return rc;
             continue;
         }
         const BwdLayout bl = bwd_layout(P, V, stores_high16(cfg->precision), stores_t16(cfg->precision));

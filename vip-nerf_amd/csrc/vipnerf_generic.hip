@@ -168,35 +168,60 @@ __global__ __launch_bounds__(256) void k_gen_wgrad(GenWgrad g) {
 }
 
 // ------------------------------------------------------------------------------------------------ small per-point kernels
-// sigma = ReLU(w . h + b + noise * std)   (VipNeRF01.py:546-553)
-__global__ void k_gen_sigma(int64_t P, int W, const float *h, const float *w, const float *b, NoiseSrc ns, PointSrc s, float *sigma) {
+// trunk head (pts_output_linear, VipNeRF01.py:544-560): sigma = ReLU(w_0 . h + b_0 + noise * std); with NT = 4 (view_dependent_rgb = False)
+// also rgb = sigmoid(w_{1..3} . h + b_{1..3})
+template <int NT>
+__global__ void k_gen_trunk_head(int64_t P, int W, const float *h, const float *w, const float *b, NoiseSrc ns, PointSrc s, float *sigma, float *rgb) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
-    float v = 0.f;
-    for (int k = 0; k < W; ++k) v = fmaf(h[(size_t)p * W + k], w[k], v);
-    v += b[0];
+    float v[NT];
+    for (int c = 0; c < NT; ++c) v[c] = 0.f;
+    for (int k = 0; k < W; ++k) {
+        const float x = h[(size_t)p * W + k];
+        for (int c = 0; c < NT; ++c) v[c] = fmaf(x, w[c * W + k], v[c]);
+    }
     float nz = 0.f;
     if (ns.noise) nz = ns.noise[p];
     else if (ns.device_rng) nz = rng_normal(ns.seed, ns.offset, ns.stream, noise_index(ns, s, p));
-    sigma[p] = fmaxf(__fadd_rn(v, __fmul_rn(nz, ns.std)), 0.f);
+    sigma[p] = fmaxf(__fadd_rn(v[0] + b[0], __fmul_rn(nz, ns.std)), 0.f);
+    for (int c = 1; c < NT; ++c) rgb[3 * p + c - 1] = 1.f / (1.f + expf(-(v[c] + b[c])));
 }
-// scatter the (P,4) sigmoid outputs of direction a: a = 0 -> rgb, vis; a >= 1 -> vis2[:, a-1]
-__global__ void k_gen_scatter(int64_t P, int V, int a, const float *q, float *rgb, float *vis, float *vis2) {
+// scatter the sigmoid outputs q[P][4] of direction a (columns: rgb when the view branch predicts it, then visibility when it does):
+// a = 0 -> rgb, vis; a >= 1 -> vis2[:, a-1]
+__global__ void k_gen_scatter(int64_t P, int V, int a, int rgb_cols, int vis_col, const float *q, float *rgb, float *vis, float *vis2) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
-    if (a == 0) { rgb[3 * p] = q[4 * p]; rgb[3 * p + 1] = q[4 * p + 1]; rgb[3 * p + 2] = q[4 * p + 2]; vis[p] = q[4 * p + 3]; }
-    else vis2[p * V + a - 1] = q[4 * p + 3];
+    if (a == 0) {
+        for (int c = 0; c < rgb_cols; ++c) rgb[3 * p + c] = q[4 * p + c];
+        if (vis_col >= 0) vis[p] = q[4 * p + vis_col];
+    } else if (vis_col >= 0) vis2[p * V + a - 1] = q[4 * p + vis_col];
 }
-// d(pre-sigmoid outputs) of direction a, and d(sigma_raw) through the ReLU
-__global__ void k_gen_seeds(int64_t P, int V, int a, const float *q, const float *sigma, const float *drgb, const float *dvis,
-                            const float *dvis2, const float *dsig, float *dq, float *dsraw) {
+// d(pre-sigmoid outputs) of direction a's view head
+__global__ void k_gen_seeds(int64_t P, int V, int a, int rgb_cols, int vis_col, const float *q, const float *drgb, const float *dvis,
+                            const float *dvis2, float *dq) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     float d[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a == 0) { d[0] = drgb[3 * p]; d[1] = drgb[3 * p + 1]; d[2] = drgb[3 * p + 2]; d[3] = dvis[p]; }
-    else d[3] = dvis2[p * V + a - 1];
+    if (a == 0) {
+        for (int c = 0; c < rgb_cols; ++c) d[c] = drgb[3 * p + c];
+        if (vis_col >= 0) d[vis_col] = dvis[p];
+    } else if (vis_col >= 0) d[vis_col] = dvis2[p * V + a - 1];
     for (int c = 0; c < 4; ++c) { const float y = q[4 * p + c]; dq[4 * p + c] = d[c] * ((1.f - y) * y); }
-    if (a == 0) dsraw[p] = sigma[p] > 0.f ? dsig[p] : 0.f;
+}
+// d(trunk head pre-activations): column 0 = d(sigma_raw) through the ReLU (also written to dsraw), columns 1..3 = d(rgb) through the sigmoid
+// when the trunk predicts rgb
+__global__ void k_gen_trunk_seeds(int64_t P, int nt, const float *sigma, const float *rgb, const float *dsig, const float *drgb, float *dsraw,
+                                  float *dqt) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const float ds = sigma[p] > 0.f ? dsig[p] : 0.f;
+    dsraw[p] = ds;
+    dqt[4 * p] = ds;
+    for (int c = 1; c < 4; ++c) {
+        float v = 0.f;
+        if (c < nt) { const float y = rgb[3 * p + c - 1]; v = drgb[3 * p + c - 1] * ((1.f - y) * y); }
+        dqt[4 * p + c] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ launch helpers
@@ -255,8 +280,12 @@ int launch_gen_fwd(const GenTopo &t, const PointSrc &s, const NoiseSrc &ns, cons
         GCHK(gemm(g, false, st));
     }
     const float *hl = acts + al.h[t.D - 1];
-    hipLaunchKernelGGL(k_gen_sigma, dim3(nb), dim3(256), 0, st, P, t.W, hl, prm + gp.ws, prm + gp.bs, ns, s, sigma);
+    const int no = gen_view_outs(t), rgb_cols = gen_rgb_trunk(t) ? 0 : 3, vis_col = gen_pred_vis(t) ? rgb_cols : -1;
+    if (gen_rgb_trunk(t)) hipLaunchKernelGGL(k_gen_trunk_head<4>, dim3(nb), dim3(256), 0, st, P, t.W, hl, prm + gp.ws, prm + gp.bs, ns, s, sigma, rgb);
+    else hipLaunchKernelGGL(k_gen_trunk_head<1>, dim3(nb), dim3(256), 0, st, P, t.W, hl, prm + gp.ws, prm + gp.bs, ns, s, sigma, rgb);
     VN_HIP(hipGetLastError());
+    if (!gen_pred_vis(t)) VN_HIP(hipMemsetAsync(vis, 0, (size_t)P * sizeof(float), st));      // no visibility prediction: the output reads 0
+    if (no == 0) return VIPNERF_OK;                                                           // no view-dependent output: no feature / view layers
     {
         GenGemm g = gg(P, t.W, hl, t.W, t.W, prm + gp.wf, t.W, acts + al.feat, t.W);
         g.bias = prm + gp.bf;
@@ -266,16 +295,17 @@ int launch_gen_fwd(const GenTopo &t, const PointSrc &s, const NoiseSrc &ns, cons
         GenGemm g = gg(P, t.W / 2, acts + al.feat, t.W, t.W, prm + gp.wv, t.W + t.dv, acts + al.g[a], t.W / 2);
         g.A1 = acts + al.ped[a]; g.lda1 = t.dv; g.K1 = t.dv; g.bias = prm + gp.bv; g.act = 1;
         GCHK(gemm(g, false, st));
-        GenGemm o = gg(P, 4, acts + al.g[a], t.W / 2, t.W / 2, prm + gp.wo, t.W / 2, acts + al.q[a], 4);
+        if (no < 4) VN_HIP(hipMemsetAsync(acts + al.q[a], 0, (size_t)P * 4 * sizeof(float), st));   // unused columns stay 0 (their seeds too)
+        GenGemm o = gg(P, no, acts + al.g[a], t.W / 2, t.W / 2, prm + gp.wo, t.W / 2, acts + al.q[a], 4);
         o.bias = prm + gp.bo; o.act = 2;
         GCHK(gemm(o, false, st));
-        hipLaunchKernelGGL(k_gen_scatter, dim3(nb), dim3(256), 0, st, P, s.V, a, acts + al.q[a], rgb, vis, vis2);
+        hipLaunchKernelGGL(k_gen_scatter, dim3(nb), dim3(256), 0, st, P, s.V, a, rgb_cols, vis_col, acts + al.q[a], rgb, vis, vis2);
         VN_HIP(hipGetLastError());
     }
     return VIPNERF_OK;
 }
 
-int launch_gen_bwd(const GenTopo &t, const PointSrc &s, const float *prm, const float *sigma, const float *acts, float *bwd,
+int launch_gen_bwd(const GenTopo &t, const PointSrc &s, const float *prm, const float *sigma, const float *rgb, const float *acts, float *bwd,
                    const GenBwd &bl, const vipnerf_mlp_grads *G, hipStream_t st) {
     const int64_t P = s.P;
     const GenParams gp = gen_params(t);
@@ -288,15 +318,16 @@ int launch_gen_bwd(const GenTopo &t, const PointSrc &s, const float *prm, const 
     const GenActs al = gen_acts((size_t)P, s.V, t);
     const unsigned nb = (unsigned)((P + 255) / 256);
     const int W = t.W, H = t.W / 2;
-    float *dfeat = bwd + bl.dfeat, *dg = bwd + bl.dg, *dsraw = bwd + bl.dsraw;
+    const int no = gen_view_outs(t), nt = gen_trunk_outs(t), rgb_cols = gen_rgb_trunk(t) ? 0 : 3, vis_col = gen_pred_vis(t) ? rgb_cols : -1;
+    float *dfeat = bwd + bl.dfeat, *dg = bwd + bl.dg, *dsraw = bwd + bl.dsraw, *dqt = bwd + bl.dqt;
     // view branch, per direction
-    for (int a = 0; a <= s.V; ++a) {
+    for (int a = 0; no > 0 && a <= s.V; ++a) {
         float *dq = bwd + bl.dq[a];
-        hipLaunchKernelGGL(k_gen_seeds, dim3(nb), dim3(256), 0, st, P, s.V, a, acts + al.q[a], sigma, bwd + bl.drgb, bwd + bl.dvis,
-                           bwd + bl.dvis2, bwd + bl.dsig, dq, dsraw);
+        hipLaunchKernelGGL(k_gen_seeds, dim3(nb), dim3(256), 0, st, P, s.V, a, rgb_cols, vis_col, acts + al.q[a], bwd + bl.drgb, bwd + bl.dvis,
+                           bwd + bl.dvis2, dq);
         VN_HIP(hipGetLastError());
-        GCHK(wgrad(P, 4, dq, 4, acts + al.g[a], H, H, nullptr, 0, 0, G->g[P_OW], H, 0, G->g[P_OB], st));
-        GenGemm g = gg(P, H, dq, 4, 4, prm + gp.wo, H, dg, H);              // dg = (dq W_o) masked by g > 0
+        GCHK(wgrad(P, no, dq, 4, acts + al.g[a], H, H, nullptr, 0, 0, G->g[P_OW], H, 0, G->g[P_OB], st));
+        GenGemm g = gg(P, H, dq, 4, no, prm + gp.wo, H, dg, H);             // dg = (dq W_o) masked by g > 0
         g.mask = acts + al.g[a]; g.ldm = H;
         GCHK(gemm(g, true, st));
         GCHK(wgrad(P, H, dg, H, acts + al.feat, W, W, acts + al.ped[a], t.dv, t.dv, G->g[P_VW], W + t.dv, 0, G->g[P_VB], st));
@@ -304,14 +335,25 @@ int launch_gen_bwd(const GenTopo &t, const PointSrc &s, const float *prm, const 
         f.accumulate = a > 0;
         GCHK(gemm(f, true, st));
     }
-    // feature layer + sigma head -> d h_D (masked by its ReLU)
+    // trunk head seeds, feature layer + trunk head -> d h_D (masked by its ReLU)
+    hipLaunchKernelGGL(k_gen_trunk_seeds, dim3(nb), dim3(256), 0, st, P, nt, sigma, rgb, bwd + bl.dsig, bwd + bl.drgb, dsraw, dqt);
+    VN_HIP(hipGetLastError());
     const float *hl = acts + al.h[t.D - 1];
-    GCHK(wgrad(P, W, dfeat, W, hl, W, W, nullptr, 0, 0, G->g[P_FW], W, 0, G->g[P_FB], st));
-    GCHK(wgrad(P, 1, dsraw, 1, hl, W, W, nullptr, 0, 0, G->g[P_SW], W, 0, G->g[P_SB], st));
+    if (no > 0) GCHK(wgrad(P, W, dfeat, W, hl, W, W, nullptr, 0, 0, G->g[P_FW], W, 0, G->g[P_FB], st));
+    GCHK(wgrad(P, nt, dqt, 4, hl, W, W, nullptr, 0, 0, G->g[P_SW], W, 0, G->g[P_SB], st));
     float *dcur = bwd + bl.dh[0], *dnext = bwd + bl.dh[1];
-    {
+    if (no > 0 && nt == 1) {                                                // the default heads: one GEMM with sigma's rank-1 term in its epilogue
         GenGemm g = gg(P, W, dfeat, W, W, prm + gp.wf, W, dcur, W);
         g.rank1s = dsraw; g.rank1v = prm + gp.ws; g.mask = hl; g.ldm = W;
+        GCHK(gemm(g, true, st));
+    } else {                                                                // masked sums add: mask(a) + mask(b) = mask(a + b)
+        if (no > 0) {
+            GenGemm g = gg(P, W, dfeat, W, W, prm + gp.wf, W, dcur, W);
+            g.mask = hl; g.ldm = W;
+            GCHK(gemm(g, true, st));
+        }
+        GenGemm g = gg(P, W, dqt, 4, nt, prm + gp.ws, W, dcur, W);           // dqt W_s: K = the trunk head's rows
+        g.mask = hl; g.ldm = W; g.accumulate = no > 0;
         GCHK(gemm(g, true, st));
     }
     // trunk, last layer first: dcur = dLoss/d(pre-activation of layer i)

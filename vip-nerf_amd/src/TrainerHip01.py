@@ -26,6 +26,7 @@ except ImportError:
         if cand and cand not in sys.path:
             sys.path.insert(0, cand)
 from vipnerf_hip import dist as vdist
+from vipnerf_hip.optim import FlatAdam
 
 import CheckpointHip01 as ckpt
 from data_preprocessors.RayGeneratorHip01 import BatchIndexScheduler, RayGeneratorHip, predict_frame
@@ -47,8 +48,7 @@ class TrainerHip:
         self.loss_computer = LossComputerHip(configs)
         oc = configs.get('optimizer', {})
         self.lr_init, self.lr_decay_steps = float(oc.get('lr_initial', 5e-4)), float(oc.get('lr_decay', 250)) * 1000
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self.lr_init,
-                                          betas=(oc.get('beta1', 0.9), oc.get('beta2', 0.999)), fused=True)
+        self.optimizer = FlatAdam(self.model.parameters(), lr=self.lr_init, betas=(oc.get('beta1', 0.9), oc.get('beta2', 0.999)))
         self.bucket = vdist.FlatGradBucket(self.model.parameters())
 
     def learning_rate(self, iter_num: int) -> float:

@@ -9,6 +9,7 @@ import os
 import sys
 from pathlib import Path
 
+import torch
 
 try:
     import vipnerf_hip  # noqa: F401
@@ -49,8 +50,11 @@ def fused_loss_values(configs: dict, input_dict: dict, output_dict: dict):
         if f'rgb_{lv}' not in output_dict:
             return (None,) * 5
         # raw_visibility (N,S,1) -> (N,S) by squeeze: a view both ways ([..., 0] costs a zeros + a copy kernel in backward)
-        return (output_dict[f'rgb_{lv}'], output_dict[f'visibility_{lv}'], output_dict[f'raw_visibility_{lv}'].squeeze(-1),
-                output_dict.get(f'visibility2_{lv}'), output_dict[f'depth_{lv}'])
+        rv = output_dict.get(f'raw_visibility_{lv}')
+        # a model that predicts no visibility (mlp predict_visibility = False) has none: the kernel's visibility slots then hold a
+        # number no loss class may read (VisibilityLossHip raises the reference's KeyError instead)
+        rv = rv.squeeze(-1) if rv is not None else torch.zeros_like(output_dict[f'visibility_{lv}'])
+        return (output_dict[f'rgb_{lv}'], output_dict[f'visibility_{lv}'], rv, output_dict.get(f'visibility2_{lv}'), output_dict[f'depth_{lv}'])
     vals = FusedLossFunction.apply(cfg, n, input_dict['target_rgb'], input_dict['indices_mask_nerf'], prior, mask_sd, sd,
                                    *level('coarse'), *(level('fine') if fine else (None,) * 5))
     parts = vals.unbind(0)

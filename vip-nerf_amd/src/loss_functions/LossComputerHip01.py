@@ -56,6 +56,8 @@ class LossComputerHip:
         w8, present = [0.0] * 8, {}
         for name, obj in self.losses.items():
             a, b = obj.FUSED_SLOTS
+            if a == 2 and 'raw_visibility_coarse' not in output_dict:
+                return None                               # VisibilityLoss on a model without visibility prediction: the generic path raises
             if a == 4 and ('raw_visibility2_coarse' not in output_dict or (fine and 'raw_visibility2_fine' not in output_dict)):
                 continue                                  # VisibilityPriorLoss reports None on frames without secondary views
             if a == 6 and 'indices_mask_sparse_depth' not in input_dict:

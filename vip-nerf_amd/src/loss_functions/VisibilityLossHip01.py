@@ -12,6 +12,8 @@ class VisibilityLossHip:
         self.fine_mlp_needed = 'fine_mlp' in configs['model']
 
     def compute_loss(self, input_dict: dict, output_dict: dict, return_loss_maps: bool = False):
+        if 'raw_visibility_coarse' not in output_dict:            # mlp predict_visibility = False: what VisibilityLoss01.py raises there
+            raise KeyError('raw_visibility_coarse')
         v = fused_loss_values(self.configs, input_dict, output_dict)
         loss_dict = {'loss_value': v[2] + v[3] if self.fine_mlp_needed else v[2]}
         if return_loss_maps:

@@ -27,14 +27,15 @@ from vipnerf_hip import _lib as L
 from vipnerf_hip import ops
 from vipnerf_hip.autograd import RenderFunction, RenderState
 
-_REQUIRED = {'use_view_dirs': True, 'view_dependent_rgb': True, 'predict_visibility': True}
+_REQUIRED = {'use_view_dirs': True}
 
 
 class MLPParams(torch.nn.Module):
     """Parameter container with MLP's layout (reference VipNeRF01.py:451-492: netdepth trunk layers of netwidth, gamma(x)
     re-injected after layer 4 -- `self.skips = [4]` --, netwidth/2-wide view layer, rgb + visibility head).  No forward of
     its own: the network is evaluated inside the HIP kernels -- the fused MFMA ones for the topology every shipped reference
-    config uses (8 x 256, degrees 10 / 4), the generic per-layer ones for any other (e.g. BASELINE configs[0]'s 4 x 64)."""
+    config uses (8 x 256, degrees 10 / 4, view-dependent rgb + visibility), the generic per-layer ones for any other (e.g.
+    BASELINE configs[0]'s 4 x 64; `view_dependent_rgb` / `predict_visibility` = False, VipNeRF01.py:467-491)."""
 
     def __init__(self, configs, mlp_configs):
         super().__init__()
@@ -48,22 +49,27 @@ class MLPParams(torch.nn.Module):
         if not (1 <= D <= 8 and 8 <= W <= 256 and W % 8 == 0 and 0 <= lp <= 16 and 0 <= lv <= 8):
             raise L.VipNerfHipError(f'VipNeRFHip: netdepth={D} netwidth={W} degrees {lp}/{lv} unsupported (depth 1..8, width 8..256 and '
                                     f'a multiple of 8, degrees <= 16 / 8)')
-        self.topology = (D, W, lp, lv)
+        heads = ops.head_variant(mlp_configs)
+        self.topology = (D, W, lp, lv) + ((heads,) if heads else ())
+        self.view_dep_rgb = bool(mlp_configs['view_dependent_rgb'])
+        self.predict_visibility = bool(mlp_configs['predict_visibility'])
+        n_trunk, n_view = ops.head_outputs(self.topology)
         d_pts, d_view = 3 + 6 * lp, 3 + 6 * lv
         self.pts_linears = torch.nn.ModuleList(
             [torch.nn.Linear(d_pts, W)] +
             [torch.nn.Linear(W, W) if i != 4 else torch.nn.Linear(W + d_pts, W) for i in range(D - 1)])
-        self.views_linears = torch.nn.ModuleList([torch.nn.Linear(d_view + W, W // 2)])
-        self.pts_output_linear = torch.nn.Linear(W, 1)
-        self.feature_linear = torch.nn.Linear(W, W)
-        self.views_output_linear = torch.nn.Linear(W // 2, 4)
-        self.predict_visibility = True
+        if n_view:
+            self.views_linears = torch.nn.ModuleList([torch.nn.Linear(d_view + W, W // 2)])
+        self.pts_output_linear = torch.nn.Linear(W, n_trunk)
+        if n_view:
+            self.feature_linear = torch.nn.Linear(W, W)
+            self.views_output_linear = torch.nn.Linear(W // 2, n_view)
 
     def ordered_params(self):
         """The parameter tensors in the ABI's order, by attribute path: on a torch.nn.DataParallel REPLICA the weights are plain (non-leaf)
         tensor attributes -- the broadcast copies autograd reduces back onto the master -- and named_parameters() is empty there."""
         out = []
-        for name in ops.param_order(self.topology[0]):
+        for name in ops.param_order(self.topology):
             t = self
             for part in name.split('.'):
                 t = getattr(t, part)
@@ -81,13 +87,13 @@ class VipNeRFHip(torch.nn.Module):
             raise L.VipNerfHipError('VipNeRFHip needs a coarse_mlp')
         self.coarse_mlp_needed = True
         self.fine_mlp_needed = 'fine_mlp' in m
-        self.predict_visibility = True
         self.coarse_model = MLPParams(configs, m['coarse_mlp'])
         self.fine_model = MLPParams(configs, m['fine_mlp']) if self.fine_mlp_needed else None
         if self.fine_model is not None and self.fine_model.topology != self.coarse_model.topology:
             raise L.VipNerfHipError('VipNeRFHip: coarse and fine MLP must share one topology '
                                     f'({self.coarse_model.topology} vs {self.fine_model.topology})')
         self.topology = self.coarse_model.topology
+        self.predict_visibility = self.coarse_model.predict_visibility          # VipNeRF01.py:19 (one topology for both levels here)
         if self.topology != ops.DEFAULT_TOPOLOGY and m.get('hip_precision', 'fp32') != 'fp32':
             raise L.VipNerfHipError(f"hip_precision={m.get('hip_precision')!r}: the generic-topology kernels (netdepth/netwidth/degrees "
                                     f"{self.topology}) are fp32 only")
@@ -147,7 +153,7 @@ class VipNeRFHip(torch.nn.Module):
         else:
             batch['near'], batch['far'] = input_dict['near'], input_dict['far']
         V = 0
-        if sec_views_vis:
+        if sec_views_vis and self.predict_visibility:           # VipNeRF01.py:84,114,148: secondary views only where visibility is predicted
             if 'rays_o2' in input_dict:
                 o2 = input_dict['rays_o2']
             else:                                               # VipNeRF01.py:88-98: the other cameras' centres per row, one launch
@@ -195,8 +201,9 @@ class VipNeRFHip(torch.nn.Module):
                 ret[f'visibility2_{lv}'] = d[f'vis2_{lv}']
             if retraw:
                 ret[f'raw_sigma_{lv}'] = d[f'raw_sigma_{lv}'].unsqueeze(-1)
-                ret[f'raw_rgb_view_dependent_{lv}'] = d[f'raw_rgb_{lv}']
-                ret[f'raw_visibility_{lv}'] = d[f'raw_vis_{lv}'].unsqueeze(-1)
+                ret[f"raw_rgb_view_{'dependent' if self.coarse_model.view_dep_rgb else 'independent'}_{lv}"] = d[f'raw_rgb_{lv}']
+                if self.predict_visibility:
+                    ret[f'raw_visibility_{lv}'] = d[f'raw_vis_{lv}'].unsqueeze(-1)
                 if V > 0:
                     ret[f'raw_visibility2_{lv}'] = d[f'raw_vis2_{lv}'].unsqueeze(-1)
                 ret[f'raw_rgb_{lv}'] = d[f'raw_rgb_{lv}']

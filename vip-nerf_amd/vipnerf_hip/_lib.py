@@ -8,7 +8,7 @@ import os
 
 VIPNERF_MAX_SEC = 3
 VIPNERF_N_PARAMS = 24
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VIPNERF_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libvipnerf_hip.so')
@@ -24,7 +24,7 @@ class Config(C.Structure):
     _fields_ = [('ndc', C.c_int32), ('n_coarse', C.c_int32), ('n_fine', C.c_int32), ('n_sec', C.c_int32),
                 ('train', C.c_int32), ('lindisp', C.c_int32), ('white_bkgd', C.c_int32), ('save_acts', C.c_int32),
                 ('noise_std', C.c_float), ('given_z_fine', C.c_int32), ('perturb', C.c_int32), ('precision', C.c_int32), ('bf16_layout', C.c_int32),
-                ('netdepth', C.c_int32), ('netwidth', C.c_int32), ('pe_degrees', C.c_int32)]
+                ('netdepth', C.c_int32), ('netwidth', C.c_int32), ('pe_degrees', C.c_int32), ('head_variant', C.c_int32)]
 
 
 class Rays(C.Structure):

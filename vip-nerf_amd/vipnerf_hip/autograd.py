@@ -35,7 +35,7 @@ class RenderFunction(torch.autograd.Function):
     def forward(ctx, state: RenderState, *params):
         cfg = state.cfg
         two = cfg.n_fine > 0
-        n_mlp = len(ops.param_order(ops.topology_of(cfg)[0]))        # tensors per MLP (24 for the default topology)
+        n_mlp = len(ops.param_order(ops.topology_of(cfg)))        # tensors per MLP (24 for the default topology)
         pc = ops.pack_weights(list(params[:n_mlp]), cfg=cfg)
         pf = ops.pack_weights(list(params[n_mlp:]), cfg=cfg) if two else None
         need_bwd = state.grad_enabled and any(ctx.needs_input_grad)   # grad mode as seen by the caller of apply()

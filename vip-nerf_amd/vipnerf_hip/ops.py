@@ -9,27 +9,59 @@ from . import _lib as L
 
 TAIL_PARAMS = ['views_linears.0.weight', 'views_linears.0.bias', 'pts_output_linear.weight', 'pts_output_linear.bias',
                'feature_linear.weight', 'feature_linear.bias', 'views_output_linear.weight', 'views_output_linear.bias']
-DEFAULT_TOPOLOGY = (8, 256, 10, 4)            # netdepth, netwidth, points / views positional-encoding degree
+DEFAULT_TOPOLOGY = (8, 256, 10, 4)            # netdepth, netwidth, points / views positional-encoding degree [, head variant]
+HEAD_RGB_TRUNK, HEAD_NO_VISIBILITY = 1, 2     # VIPNERF_HEAD_*: mlp 'view_dependent_rgb' = False / 'predict_visibility' = False
 
 
-def param_order(depth: int = 8):
-    """Parameter names of one MLP in the reference's construction order (VipNeRF01.py:472-491)."""
-    return [f'pts_linears.{i}.{wb}' for i in range(depth) for wb in ('weight', 'bias')] + TAIL_PARAMS
+def head_variant(mlp_configs: dict) -> int:
+    """vipnerf_config.head_variant of one MLP's config dict (MLP.__init__, VipNeRF01.py:467-469)."""
+    return (0 if mlp_configs.get('view_dependent_rgb', True) else HEAD_RGB_TRUNK) | \
+        (0 if mlp_configs.get('predict_visibility', True) else HEAD_NO_VISIBILITY)
 
 
-def param_slots(depth: int = 8):
-    """vipnerf_mlp_params slot of each entry of param_order(depth): trunk layer i -> 2i, 2i+1; the rest -> 16..23."""
-    return list(range(2 * depth)) + list(range(16, 24))
+def _topo5(topology):
+    """int depth | (depth, width, l_pts, l_view) | (..., heads) -> the 5-tuple."""
+    if isinstance(topology, int):
+        return (topology,) + DEFAULT_TOPOLOGY[1:] + (0,)
+    t = tuple(int(v) for v in topology)
+    return t if len(t) == 5 else t + (0,)
+
+
+def head_outputs(topology):
+    """(rows of pts_output_linear, rows of views_output_linear); 0 view rows = no feature / view layers at all."""
+    heads = _topo5(topology)[4]
+    return (4 if heads & HEAD_RGB_TRUNK else 1), (0 if heads & HEAD_RGB_TRUNK else 3) + (0 if heads & HEAD_NO_VISIBILITY else 1)
+
+
+def _tail(topology):
+    """(name, ABI slot) of the non-trunk tensors this topology has, in the reference's construction order."""
+    n_view = head_outputs(topology)[1]
+    return [(n, 16 + i) for i, n in enumerate(TAIL_PARAMS) if n_view > 0 or n.startswith('pts_output_linear')]
+
+
+def param_order(topology=8):
+    """Parameter names of one MLP in the reference's construction order (VipNeRF01.py:472-491).  topology: netdepth or a topology tuple."""
+    return [f'pts_linears.{i}.{wb}' for i in range(_topo5(topology)[0]) for wb in ('weight', 'bias')] + [n for n, _ in _tail(topology)]
+
+
+def param_slots(topology=8):
+    """vipnerf_mlp_params slot of each entry of param_order(topology): trunk layer i -> 2i, 2i+1; the rest -> 16..23."""
+    return list(range(2 * _topo5(topology)[0])) + [s for _, s in _tail(topology)]
 
 
 def param_shapes(topology=DEFAULT_TOPOLOGY):
-    depth, width, l_pts, l_view = topology
+    depth, width, l_pts, l_view, _ = _topo5(topology)
     dp, dv = 3 + 6 * l_pts, 3 + 6 * l_view
+    n_trunk, n_view = head_outputs(topology)
     trunk = []
     for i in range(depth):
         k = dp if i == 0 else (width + dp if (i == 5 and depth > 5) else width)
         trunk += [(width, k), (width,)]
-    return trunk + [(width // 2, width + dv), (width // 2,), (1, width), (1,), (width, width), (width,), (4, width // 2), (4,)]
+    tail = {'views_linears.0.weight': (width // 2, width + dv), 'views_linears.0.bias': (width // 2,),
+            'pts_output_linear.weight': (n_trunk, width), 'pts_output_linear.bias': (n_trunk,),
+            'feature_linear.weight': (width, width), 'feature_linear.bias': (width,),
+            'views_output_linear.weight': (n_view, width // 2), 'views_output_linear.bias': (n_view,)}
+    return trunk + [tail[n] for n, _ in _tail(topology)]
 
 
 PARAM_ORDER = param_order(8)
@@ -84,6 +116,7 @@ def make_config(ndc, n_coarse, n_fine, n_sec, train, noise_std=0.0, lindisp=Fals
     c = L.Config()
     c.netdepth, c.netwidth = int(topology[0]), int(topology[1])
     c.pe_degrees = int(topology[2]) | (int(topology[3]) << 8)
+    c.head_variant = _topo5(topology)[4]
     c.precision = int(precision)
     c.bf16_layout = int(bf16_layout)
     c.perturb = int(bool(train if perturb is None else perturb))
@@ -102,8 +135,10 @@ def packed_bytes(precision: int = 0) -> int:
 
 
 def topology_of(cfg: L.Config):
-    return (cfg.netdepth or 8, cfg.netwidth or 256, (cfg.pe_degrees & 0xff) if cfg.pe_degrees else 10,
-            ((cfg.pe_degrees >> 8) & 0xff) if cfg.pe_degrees else 4)
+    """The 4-tuple for the default heads (what every caller passed so far), the 5-tuple otherwise."""
+    t = (cfg.netdepth or 8, cfg.netwidth or 256, (cfg.pe_degrees & 0xff) if cfg.pe_degrees else 10,
+         ((cfg.pe_degrees >> 8) & 0xff) if cfg.pe_degrees else 4)
+    return t + (cfg.head_variant,) if cfg.head_variant else t
 
 
 def pack_weights(params: List[torch.Tensor], out: Optional[torch.Tensor] = None, precision: int = 0,
@@ -114,7 +149,7 @@ def pack_weights(params: List[torch.Tensor], out: Optional[torch.Tensor] = None,
     if cfg is None:
         cfg = make_config(True, 64, 0, 0, False, precision=precision)
     topo = topology_of(cfg)
-    names, slots, shapes = param_order(topo[0]), param_slots(topo[0]), param_shapes(topo)
+    names, slots, shapes = param_order(topo), param_slots(topo), param_shapes(topo)
     if len(params) != len(names):
         raise L.VipNerfHipError(f'expected {len(names)} parameter tensors for netdepth {topo[0]}, got {len(params)}')
     mp = L.MlpParams()
@@ -267,7 +302,7 @@ def render_backward(cfg: L.Config, batch, packed_coarse, packed_fine, coarse, fi
     fill(og.coarse, grads_coarse)
     fill(og.fine, grads_fine)
     gc, gf = L.MlpGrads(), L.MlpGrads()
-    slots = param_slots(topology_of(cfg)[0])
+    slots = param_slots(topology_of(cfg))
     for s, t in zip(slots, gparams_coarse):
         gc.g[s] = _p(t, name=f'grad param slot {s}')
     if gparams_fine is not None:

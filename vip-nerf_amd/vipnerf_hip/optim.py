@@ -12,6 +12,10 @@ the flat buffer -- and one step is the six elementwise kernels of torch's own si
 -- the same expressions, in the same order, as torch.optim.Adam(foreach=False, fused=False) (torch/optim/adam.py::_single_tensor_adam):
 elementwise, so bit-identical to it per parameter (tests/test_abi_cpu.py::test_flat_adam_is_torch_adam).  The reference's optimizer
 (torch.optim.Adam, Trainer01.py:505-515, betas (0.9, 0.999), no weight decay, no amsgrad) is this update.
+
+state_dict() / load_state_dict() speak torch.optim.Adam's format (per-parameter 'step' / 'exp_avg' / 'exp_avg_sq', one param group), so
+the `optimizer_state_dict` of a checkpoint written with either optimizer -- the reference's (Trainer01.py:352-381) included -- resumes
+with the other.
 """
 import math
 from typing import Iterable
@@ -79,6 +83,46 @@ class FlatAdam:
         bc1, bc2 = 1 - b1 ** self.t, 1 - b2 ** self.t
         denom = (self.exp_avg_sq.sqrt() / math.sqrt(bc2)).add_(eps)
         self.flat.addcdiv_(self.exp_avg, denom, value=-(lr / bc1))
+
+    def state_dict(self) -> dict:
+        state, o = {}, 0
+        for i, p in enumerate(self.params):
+            n = p.numel()
+            if self.t > 0:                          # like torch: no per-parameter state before the first step
+                state[i] = {'step': torch.tensor(float(self.t)), 'exp_avg': self.exp_avg[o:o + n].view(p.shape).clone(),
+                            'exp_avg_sq': self.exp_avg_sq[o:o + n].view(p.shape).clone()}
+            o += n
+        g = self.param_groups[0]
+        group = {'lr': g['lr'], 'betas': g['betas'], 'eps': g['eps'], 'weight_decay': 0, 'amsgrad': False, 'maximize': False,
+                 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None, 'params': list(range(len(self.params)))}
+        return {'state': state, 'param_groups': [group]}
+
+    def load_state_dict(self, sd: dict):
+        groups = sd['param_groups']
+        ids = [i for g in groups for i in g['params']]
+        if len(groups) != 1 or len(ids) != len(self.params):
+            raise ValueError(f'FlatAdam.load_state_dict: expected one param group over {len(self.params)} parameters, got {len(groups)} group(s) over {len(ids)}')
+        g = groups[0]
+        if g.get('weight_decay', 0) != 0 or g.get('amsgrad', False) or g.get('maximize', False):
+            raise ValueError('FlatAdam.load_state_dict: weight decay / amsgrad / maximize are not part of this update')
+        self.param_groups[0].update(lr=float(g['lr']), betas=(float(g['betas'][0]), float(g['betas'][1])), eps=float(g['eps']))
+        state = sd['state']
+        if not state:
+            self.t = 0
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            return
+        steps = {int(float(state[i]['step'])) for i in ids}
+        if len(steps) != 1:
+            raise ValueError(f'FlatAdam.load_state_dict: parameters at different step counts {sorted(steps)}')
+        self.t, o = steps.pop(), 0
+        for i, p in zip(ids, self.params):
+            n = p.numel()
+            if tuple(state[i]['exp_avg'].shape) != tuple(p.shape):
+                raise ValueError(f'FlatAdam.load_state_dict: parameter {i} has shape {tuple(p.shape)}, its state {tuple(state[i]["exp_avg"].shape)}')
+            self.exp_avg[o:o + n].copy_(state[i]['exp_avg'].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(state[i]['exp_avg_sq'].reshape(-1))
+            o += n
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:

@@ -99,7 +99,10 @@ def test_product_path_has_no_cpu_fallback():
     with pytest.raises(_lib.VipNerfHipError):
         get_model({'data_loader': {'ndc': False}, 'model': {'name': 'VipNeRFHip01', 'hip_precision': 'fp16x3',
                                                              'coarse_mlp': dict(mlp, netwidth=64, netdepth=4)}}, None)
-    for bad in (dict(mlp, netwidth=100), dict(mlp, netdepth=9), dict(mlp, use_view_dirs=False)):
+    plain = get_model({'data_loader': {'ndc': False}, 'model': {'name': 'VipNeRFHip01', 'coarse_mlp': dict(mlp, use_view_dirs=False, view_dependent_rgb=False,
+                                                                                                         predict_visibility=False)}}, None)
+    assert len(list(plain.parameters())) == 18                  # 8 trunk layers + the 4-row trunk head: use_view_dirs = False needs no more
+    for bad in (dict(mlp, netwidth=100), dict(mlp, netdepth=9), dict(mlp, use_view_dirs=False), dict(mlp, use_view_dirs=False, predict_visibility=False)):
         with pytest.raises(_lib.VipNerfHipError):
             get_model({'data_loader': {'ndc': False}, 'model': {'name': 'VipNeRFHip01', 'coarse_mlp': bad}}, None)
     # the head variants (view_dependent_rgb / predict_visibility = False, VipNeRF01.py:467-491): the reference's parameter set (the oracle's

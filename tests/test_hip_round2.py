@@ -671,6 +671,17 @@ def test_head_variants_golden(dev, tag):
     for k in ('rgb_coarse', 'acc_coarse', 'raw_sigma_coarse', 'raw_rgb_coarse') + (('visibility2_coarse', 'raw_visibility_coarse') if heads['predict_vis'] else ()):
         tp.assert_close(ev[k], ro[k], what=f'{tag} eval {k}')
     assert ('visibility2_coarse' in ev) == heads['predict_vis']
+    if not (heads['view_dep_rgb'] or heads['predict_vis']):     # use_view_dirs = False (VipNeRF01.py:273-277): the same network, no directions read
+        for k in ('coarse_mlp', 'fine_mlp'):
+            cfg['model'][k]['use_view_dirs'] = False
+        m2 = get_model(cfg, None)
+        m2.load_state_dict(model.state_dict(), strict=True)
+        m2 = m2.to(dev).eval()
+        rb2 = tp.ref_batch(b, dev, 0)
+        del rb2['view_dirs']
+        with torch.no_grad():
+            ev2 = m2(rb2, retraw=True, sec_views_vis=True)
+        assert set(ev2.keys()) == set(ev.keys()) and all(torch.equal(ev2[k], ev[k]) for k in ev)
     if n_fine:
         ef = (ev['rgb_fine'].cpu() - ro['rgb_fine']).abs().max()
         print(f'{tag}: free-running eval rgb_fine max abs err {float(ef):.3e}')

@@ -27,8 +27,6 @@ from vipnerf_hip import _lib as L
 from vipnerf_hip import ops
 from vipnerf_hip.autograd import RenderFunction, RenderState
 
-_REQUIRED = {'use_view_dirs': True}
-
 
 class MLPParams(torch.nn.Module):
     """Parameter container with MLP's layout (reference VipNeRF01.py:451-492: netdepth trunk layers of netwidth, gamma(x)
@@ -39,10 +37,11 @@ class MLPParams(torch.nn.Module):
 
     def __init__(self, configs, mlp_configs):
         super().__init__()
-        for k, v in _REQUIRED.items():
-            if mlp_configs.get(k) != v:
-                raise L.VipNerfHipError(f"VipNeRFHip supports only {k}={v} (got {mlp_configs.get(k)!r}): no shipped reference "
-                                        f"config or BASELINE config uses another value")
+        if not mlp_configs.get('use_view_dirs') and (mlp_configs['view_dependent_rgb'] or mlp_configs['predict_visibility']):
+            # MLP.forward reads input_batch['view_dirs'] for any view-dependent output (VipNeRF01.py:519-520), which run_network only
+            # passes with use_view_dirs (:273-277): the reference raises KeyError on this combination
+            raise L.VipNerfHipError("VipNeRFHip: use_view_dirs=False needs view_dependent_rgb=False and predict_visibility=False "
+                                    "(the reference's MLP.forward fails on any other combination)")
         self.configs, self.mlp_configs = configs, mlp_configs
         D, W = int(mlp_configs['netdepth']), int(mlp_configs['netwidth'])
         lp, lv = int(mlp_configs['points_positional_encoding_degree']), int(mlp_configs['views_positional_encoding_degree'])
@@ -147,6 +146,8 @@ class VipNeRFHip(torch.nn.Module):
             raise L.VipNerfHipError('VipNeRFHip runs on the GPU only (rays_o is on %s); there is no CPU fallback' % rays_o.device)
         n = rays_o.shape[0]
         batch = {k: input_dict[k] for k in ('rays_o', 'rays_d', 'view_dirs') if k in input_dict}
+        if 'view_dirs' not in batch and not m['coarse_mlp'].get('use_view_dirs'):
+            batch['view_dirs'] = batch['rays_d']                # a network without view-dependent outputs reads no direction (ABI: non-NULL)
         if self.ndc:
             for k in ('rays_o_ndc', 'rays_d_ndc', 'near_ndc', 'far_ndc'):
                 batch[k] = input_dict[k]

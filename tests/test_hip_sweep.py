@@ -82,3 +82,44 @@ def test_config_sweep_vs_oracle(dev, c):
         tp.assert_close(hv, rv, rtol=2e-4, floor=1e-6, what=f'{what} loss {k}')
     for k, t in model.named_parameters():
         tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{what} grad {k}')
+
+
+# (output rtol, floor relative to the tensor's max, gradient rel. L2 per tensor, median over the 48 tensors): the 1024-ray classes of
+# tests/test_hip_round2.py::ARITH16 with twice the room for the gradients -- these batches are 1 .. 48 rows, not 1024, so a tensor's
+# gradient averages the 16-bit roundings of 25 x fewer points
+SWEEP16 = {'fp16': (5e-3, 5e-4, 1e-1, 1e-2), 'bf16': (4e-2, 5e-3, 3e-1, 4e-2)}
+
+
+@pytest.mark.parametrize('prec', list(SWEEP16))
+@pytest.mark.parametrize('c', CASES[:12], ids=lambda c: '%(i)d-%(scene)s-nf%(nf)d-n%(n)d-%(nco)d+%(nfi)d' % c)
+def test_config_sweep_16bit_vs_oracle(dev, c, prec):
+    """The same seeded cases through the single-MFMA 16-bit modes (two point tiles per wave, 16-bit tile storage, DMA-fed weight
+    gradients): sample counts from 64 to 256 per ray, V = 1..3, batches down to one row (a 256-point workgroup with 32 valid points),
+    sparse-depth rows, lindisp, white background -- at the accuracy class of one 16-bit rounding per operand."""
+    sparse = c['n_sparse'] > 0
+    b = vo.synthetic_batch(c['n'], 7000 + c['i'], scene=c['scene'], nf=c['nf'], n_sparse=c['n_sparse'])
+    n_rows = c['n'] + c['n_sparse']
+    params = vo.init_params(7100 + c['i'], scale=1.6)
+    rng = vo.synthetic_rng(n_rows, c['nco'], c['nfi'], 7200 + c['i'])
+    upd = {'white_bkgd': c['white'], 'lindisp': c['lindisp'], 'raw_noise_std': c['noise']}
+    cfg_o = {'ndc': b['ndc'], 'n_coarse': c['nco'], 'n_fine': c['nfi'], 'noise_std': c['noise'], 'white_bkgd': c['white'],
+             'lindisp': c['lindisp']}
+    rtol, floor, gtol, gmed = SWEEP16[prec]
+    (ref, lref, p), (out, lh, model) = _oracle_and_hip_step(dev, b, params, rng, upd, cfg_o, iter_num=c['iter_num'], sparse=sparse, prec=prec)
+    what = '%s case %d' % (prec, c['i'])
+    assert torch.equal(out['z_vals_coarse'].cpu(), ref['z_vals_coarse']), what + ': coarse depths must be bit-identical'
+    for k in ref:
+        if k in out and k not in ('z_vals_coarse', 'z_vals_fine'):
+            assert torch.isfinite(out[k]).all(), f'{what} {k}'
+            if k.startswith('depth'):
+                assert_close_few_outliers(out[k], ref[k], rtol, f'{what} {k}', floor=floor, max_frac=max(0.01, 1.5 / n_rows))
+            else:
+                tp.assert_close(out[k], ref[k], rtol=rtol, floor=max(floor, 2e-7 / max(float(ref[k].abs().max()), 1e-30)), what=f'{what} {k}')
+    tp.assert_close(lh['TotalLoss'], lref['TotalLoss'], rtol=4 * rtol, floor=1e-6, what=f'{what} TotalLoss')
+    errs = []
+    for k, t in model.named_parameters():
+        tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{what} grad {k}', l2_tol=gtol)
+        errs.append(float((t.grad.cpu() - p[k].grad).norm() / p[k].grad.norm().clamp_min(1e-30)))
+    errs.sort()
+    print(f'{what}: gradient rel. L2 median {errs[len(errs) // 2]:.2e}, worst {errs[-1]:.2e}')
+    assert errs[len(errs) // 2] <= gmed

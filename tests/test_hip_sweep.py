@@ -84,10 +84,12 @@ def test_config_sweep_vs_oracle(dev, c):
         tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{what} grad {k}')
 
 
-# (output rtol, floor relative to the tensor's max, gradient rel. L2 per tensor, median over the 48 tensors): the 1024-ray classes of
-# tests/test_hip_round2.py::ARITH16 with twice the room for the gradients -- these batches are 1 .. 48 rows, not 1024, so a tensor's
-# gradient averages the 16-bit roundings of 25 x fewer points
-SWEEP16 = {'fp16': (5e-3, 5e-4, 1e-1, 1e-2), 'bf16': (4e-2, 5e-3, 3e-1, 4e-2)}
+# (output rtol, floor relative to the tensor's max, absolute floor, gradient rel. L2 per tensor, median over the 48 tensors): the 1024-ray
+# classes of tests/test_hip_round2.py::ARITH16 with room for what these cases add -- batches of 2 .. 48 rows instead of 1024 (a tensor's
+# gradient averages the 16-bit roundings of 25 .. 500 x fewer points: measured medians up to 1.3e-2 fp16 / 4.5e-2 bf16 at 2 + 6 rows) and
+# noise-free cases, where the densities are small (max 0.2) and the 16-bit pre-activation's ABSOLUTE error (2e-4 fp16, 1.2e-3 bf16) is what
+# alpha / weights carry (1.4e-5 / 8e-5 on values <= 7e-3)
+SWEEP16 = {'fp16': (5e-3, 5e-4, 5e-5, 1e-1, 2e-2), 'bf16': (4e-2, 5e-3, 3e-4, 3e-1, 6e-2)}
 
 
 @pytest.mark.parametrize('prec', list(SWEEP16))
@@ -104,7 +106,7 @@ def test_config_sweep_16bit_vs_oracle(dev, c, prec):
     upd = {'white_bkgd': c['white'], 'lindisp': c['lindisp'], 'raw_noise_std': c['noise']}
     cfg_o = {'ndc': b['ndc'], 'n_coarse': c['nco'], 'n_fine': c['nfi'], 'noise_std': c['noise'], 'white_bkgd': c['white'],
              'lindisp': c['lindisp']}
-    rtol, floor, gtol, gmed = SWEEP16[prec]
+    rtol, floor, afloor, gtol, gmed = SWEEP16[prec]
     (ref, lref, p), (out, lh, model) = _oracle_and_hip_step(dev, b, params, rng, upd, cfg_o, iter_num=c['iter_num'], sparse=sparse, prec=prec)
     what = '%s case %d' % (prec, c['i'])
     assert torch.equal(out['z_vals_coarse'].cpu(), ref['z_vals_coarse']), what + ': coarse depths must be bit-identical'
@@ -114,7 +116,7 @@ def test_config_sweep_16bit_vs_oracle(dev, c, prec):
             if k.startswith('depth'):
                 assert_close_few_outliers(out[k], ref[k], rtol, f'{what} {k}', floor=floor, max_frac=max(0.01, 1.5 / n_rows))
             else:
-                tp.assert_close(out[k], ref[k], rtol=rtol, floor=max(floor, 2e-7 / max(float(ref[k].abs().max()), 1e-30)), what=f'{what} {k}')
+                tp.assert_close(out[k], ref[k], rtol=rtol, floor=max(floor, (10 * afloor if 'sigma' in k else afloor) / max(float(ref[k].abs().max()), 1e-30)), what=f'{what} {k}')
     tp.assert_close(lh['TotalLoss'], lref['TotalLoss'], rtol=4 * rtol, floor=1e-6, what=f'{what} TotalLoss')
     errs = []
     for k, t in model.named_parameters():

@@ -124,7 +124,10 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
                 split_pair<NS>(x[0], x[1], t1);
                 bin[s][0].v[pt] = t1[0];
             }
-            if (SAVE && layer < 8 && !EXP_NO_STORES) *(uint2 *)(a.acts + a.al.hm[layer] + ((size_t)p[pt] * 4 + q) * 2) = make_uint2(mk0, mk1);
+            // valid tiles only: a tile beyond P runs on point P - 1's position but reloads gamma(x) of group 0 at layer 5 (below) -- from there on
+            // its ReLU bits are not point P - 1's, and an unpredicated store would race the owner's (the 16-point kernels keep gamma(x) in
+            // registers: their out-of-range lanes write point P - 1's own bits again)
+            if (SAVE && layer < 8 && valid[pt] && !EXP_NO_STORES) *(uint2 *)(a.acts + a.al.hm[layer] + ((size_t)p[pt] * 4 + q) * 2) = make_uint2(mk0, mk1);
         }
     };
 

@@ -13,7 +13,7 @@ constexpr int PT2_PTS_PER_WG = 256;       // 8 waves x 2 point tiles x 16 points
 
 #if defined(__HIPCC__)
 // The deferred T16 stores of one weight stage, both point tiles: the part-0 B fragments of NSTEP k-steps of the layer input (= the
-// previous layer's output, or the gradient the running GEMM consumes), behind the stage's last MFMA group.  4 NSTEP store
+// previous layer's output, or the gradient the running GEMM consumes), behind the stage's last MFMA group.  2 T16_SPK NSTEP store
 // instructions per wave when both tiles are in range (what the counted waits of the stream assume; WStreamT::counted otherwise).
 template <typename FR, int NSTEP, int TILES = 16>       // TILES: width of the stored array in 16-feature tiles
 struct DeferredT16 {
@@ -23,7 +23,7 @@ struct DeferredT16 {
     int j, q, s0;
     const BOp<FR, 2> (*bin)[1];
     // VN_PT2_SPREAD = 1: all of a stage's stores behind its last MFMA group; = NSTEP (4, the default): one k-step's stores (4 instructions)
-    // behind every NG / NSTEP-th group, so that the stage's 16 store instructions per wave do not queue at the vector-memory port at once --
+    // behind every NG / NSTEP-th group, so that the stage's store instructions do not queue at the vector-memory port at once --
     // measured on one box (bf16, 4096 rays): forward 1.66 -> 1.60 ms, data gradients 1.73 -> 1.61; 8 parts (one point tile's k-step each):
     // forward 1.63, data gradients 2.15 (the extra scheduling barriers cost registers: spills)
 #ifndef VN_PT2_SPREAD

@@ -39,7 +39,10 @@ def _step(model, cfg, batch, base, it=40000):
     return keep, float(losses['TotalLoss']), grads
 
 
-@pytest.mark.parametrize('scene,n,prec,add_tol', [('fern', 8192, 'fp32', 2e-5), ('dtu', 16384, 'bf16', 2e-4), ('dtu', 16384, 'fp16', 2e-4)])
+# (the last three: ray counts whose point counts are no multiple of the 256-point workgroups / of the weight-gradient chunk plans, halves with
+# an odd number of 32-point blocks)
+@pytest.mark.parametrize('scene,n,prec,add_tol', [('fern', 8192, 'fp32', 2e-5), ('dtu', 16384, 'bf16', 2e-4), ('dtu', 16384, 'fp16', 2e-4),
+                                                  ('fern', 3002, 'bf16', 2e-4), ('dtu', 1006, 'fp16', 2e-4), ('fern', 1502, 'fp16x3h', 2e-5)])
 def test_shard_size_properties(scene, n, prec, add_tol):
     import bench
     import test_hip_parity as tp

@@ -328,6 +328,9 @@ __device__ __forceinline__ void store_pair_f32(float *, int64_t, int, int, int, 
 #ifndef VN_T16_X4
 #define VN_T16_X4 1
 #endif
+#ifndef VN_T16_NT
+#define VN_T16_NT 1       // nontemporal tile stores (the data is next read by another kernel, GBs later); 0: plain stores
+#endif
 constexpr int T16_SPK = VN_T16_X4 ? 1 : 2;       // store instructions store_t16 issues per k-step (what the counted stream waits assume)
 // stored feature index i (tile i >> 4, column i & 15) of a T16 array written from C/D fragments -> the feature it holds
 __host__ __device__ inline int t16_feature(int i) {
@@ -342,7 +345,9 @@ __device__ __forceinline__ void store_t16(float *base, int64_t grp, int tiles, i
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
     const u4 w = __builtin_bit_cast(u4, v);
     if (VN_T16_X4) {
-        __builtin_nontemporal_store(w, (u4 *)((char *)base + ((size_t)grp * tiles + 2 * s + (q >> 1)) * 512 + j * 32 + (q & 1) * 16));
+        u4 *dst = (u4 *)((char *)base + ((size_t)grp * tiles + 2 * s + (q >> 1)) * 512 + j * 32 + (q & 1) * 16);
+        if (VN_T16_NT) __builtin_nontemporal_store(w, dst);
+        else *dst = w;
         return;
     }
     char *t0 = (char *)base + ((size_t)grp * tiles + 2 * s) * 512 + j * 32 + q * 8;

@@ -54,6 +54,43 @@ __global__ __launch_bounds__(512) void k_dma(const char *src, size_t bytes_per_w
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// registers -> LDS: what a register-staged operand stream does (global_load_dwordx4 + ds_write_b128 of the same lane-linear image); MIX: every
+// second 4 KiB burst goes by DMA instead
+template <int DEPTH, bool MIX>   // 4 KiB bursts in flight per wave
+__global__ __launch_bounds__(512) void k_regs_lds(const char *src, size_t bytes_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t per_wave = bytes_per_wg / 8;
+    const char *g = src + (size_t)blockIdx.x * bytes_per_wg + (size_t)wave * per_wave + lane * 16;
+    char *l = lds + wave * DEPTH * 4096;
+    const int n = (int)(per_wave / 4096);
+    u4 v[DEPTH][4];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[d][u] = (MIX && (d & 1)) ? (u4){0u, 0u, 0u, 0u} : __builtin_nontemporal_load((const u4 *)(g + (size_t)d * 4096 + u * 1024));
+    for (int i = 0; i + DEPTH <= n; i += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (MIX && (d & 1)) {            // DMA burst for this slot (of the NEXT round), its predecessor drained by the vmcnt of the register loads behind it
+                const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(l + d * 4096));
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                             "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
+                             "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(g + (size_t)(i + d) * 4096), "s"(dst) : "memory");
+                continue;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *(u4 *)(l + d * 4096 + u * 1024 + lane * 16) = v[d][u];        // waits for this burst's loads (compiler's vmcnt)
+            if (i + DEPTH + d < n)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[d][u] = __builtin_nontemporal_load((const u4 *)(g + (size_t)(i + DEPTH + d) * 4096 + u * 1024));
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 int main() {
     const size_t bytes = (size_t)4 << 30, n = bytes / 16;
     u4 *a, *b; unsigned *sink;
@@ -94,5 +131,24 @@ int main() {
             }
             printf("dma   ring %d x 4 KiB per wave (%3zu KiB LDS per workgroup), grid %5d: %.3f ms  %.2f TB/s\n", ring, lds >> 10, g, best, (double)bytes / best * 1e-9);
         }
+    for (int mix = 0; mix < 2; ++mix)
+        for (int depth = 2; depth <= 4; depth *= 2)
+            for (int g : {256, 1024}) {
+                const size_t per = bytes / g;
+                float best = 1e30f;
+                const size_t lds = (size_t)8 * depth * 4096;
+                for (int rep = 0; rep < 6; ++rep) {
+                    CK(hipEventRecord(e0));
+                    if (!mix && depth == 2) hipLaunchKernelGGL((k_regs_lds<2, false>), dim3(g), dim3(512), lds, 0, (const char *)a, per);
+                    if (!mix && depth == 4) hipLaunchKernelGGL((k_regs_lds<4, false>), dim3(g), dim3(512), lds, 0, (const char *)a, per);
+                    if (mix && depth == 2) hipLaunchKernelGGL((k_regs_lds<2, true>), dim3(g), dim3(512), lds, 0, (const char *)a, per);
+                    if (mix && depth == 4) hipLaunchKernelGGL((k_regs_lds<4, true>), dim3(g), dim3(512), lds, 0, (const char *)a, per);
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (rep > 0 && ms < best) best = ms;
+                }
+                printf("%s depth %d x 4 KiB per wave (%3zu KiB LDS per workgroup), grid %5d: %.3f ms  %.2f TB/s\n", mix ? "regs+dma -> LDS" : "regs -> LDS    ", depth,
+                       lds >> 10, g, best, (double)bytes / best * 1e-9);
+            }
     return 0;
 }

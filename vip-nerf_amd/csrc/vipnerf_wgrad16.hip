@@ -16,6 +16,7 @@
 // reduction of vipnerf_wgrad.hip (k_wgrad_reduce) sums the chunks into the nn.Linear-layout gradients (deterministic, no atomics).
 // These GEMMs have 0.5 ... 64 MFMAs per KiB of operand: all of them are bound by how many bytes a CU keeps in flight, which is what
 // the DMA ring is for (3-4 blocks per workgroup, several workgroups per CU for the thin ones).
+#include <type_traits>
 #include "vipnerf_wgrad.h"
 #include "vipnerf_prof.h"
 
@@ -56,6 +57,9 @@ __device__ __forceinline__ float dot_ones(const bf16x8 &v, float s) {
 #define VN_WG16_BIG_WN 4
 #define VN_WG16_BIG_NB 4
 #endif
+#ifndef VN_WG16_HYBRID
+#define VN_WG16_HYBRID 1           // the 256 x 256 kernel streams half of each block by DMA, half through registers (k_wg16's HY)
+#endif
 #ifndef VN_WG16_SIGMA_FUSED
 #define VN_WG16_SIGMA_FUSED 1      // the sigma head rides in the feature layer's GEMM (XA below); 0: its own 16 x 256 launch
 #endif
@@ -65,7 +69,10 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // XA: a GEMM descriptor may carry ONE extra 16-row A tile (WgDesc::wcol = a 16-wide T16 array) against the same B -- the sigma head
 // (row 4 of direction 0's head-seed tile against h_8) rides in the feature layer's GEMM instead of reading h_8 a second time: one more
 // 1 KiB piece per block, one more MFMA per column tile for the waves of the first row block, its partial [16][N] + 16 sums behind the rest.
-template <bool BF, int MT, int NT, int WM, int WN, int NB, bool XA = false>
+// HY (hybrid stream, NB = 4): the DMA path alone tops out at 6.0-6.2 TB/s on this part, register loads at 7.0-7.3, half and half at 7.0
+// (tools/hbm_stream_probe.hip) -- so half of every block's pieces arrive by DMA as before and half through registers (global_load_dwordx4
+// one trip = two blocks ahead, ds_write_b128 of the same lane-linear image); see the trip loop in the kernel.
+template <bool BF, int MT, int NT, int WM, int WN, int NB, bool XA = false, bool HY = false>
 __global__ __launch_bounds__(64 * WM * WN) void k_wg16(WgArgs a) {
     typedef typename FragOf<!BF>::type FR;
     constexpr int NW = WM * WN, TM = MT / WM, TN = NT / WN;
@@ -74,6 +81,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wg16(WgArgs a) {
     constexpr int PW = (PIECES + NW - 1) / NW;       // pieces per wave and block: PW, or PW - 1 for the last waves
     constexpr int MINP = PIECES / NW;                // what the waits count (conservative for the waves that issue PW)
     static_assert(MT % WM == 0 && NT % WN == 0 && NB >= 2 && NB <= 4 && (NB - 1) * PW <= 63 && MINP >= 1, "shape");
+    static_assert(!HY || NB == 4, "hybrid stream: four slots");
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     char *lds = (char *)lds_f;
 
@@ -102,38 +110,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wg16(WgArgs a) {
 #pragma unroll
     for (int j = 0; j < (XA ? TN : 1); ++j) accx[j] = (floatx4)(0.f);
 
-    auto issue = [&](int b, int slot) {
-#pragma unroll
-        for (int i = 0; i < PW; ++i) {
-            const int pc = wave + i * NW;
-            if (pc < PIECES) {
-                const char *src = pc < MT ? gA + ((size_t)b * MT + pc) * 1024 : gB + ((size_t)b * NT + (pc - MT)) * 1024;
-                glds_chunks<1>((const float *)src, __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds + slot * BLK + pc * 1024)));
-            }
-        }
-        if (XA && has_x && wave == NW - 1)           // the extra tile's block (2 groups x 512 B); one more load than MINP counts: still a lower bound
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    auto piece_src = [&](int b, int pc) { return pc < MT ? gA + ((size_t)b * MT + pc) * 1024 : gB + ((size_t)b * NT + (pc - MT)) * 1024; };
+    auto dma_piece = [&](int b, int slot, int pc) {
+        glds_chunks<1>((const float *)piece_src(b, pc), __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds + slot * BLK + pc * 1024)));
+    };
+    auto dma_extra = [&](int b, int slot) {          // the extra tile's block (2 groups x 512 B); one more load than the waits count: still a lower bound
+        if (XA && has_x && wave == NW - 1)
             glds_chunks<1>((const float *)(gX + (size_t)b * 1024), __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds + slot * BLK + PIECES * 1024)));
     };
-    int fill = 0;
-#pragma unroll
-    for (int b = 0; b < NB - 1; ++b)
-        if (b < nblk) { issue(b, fill); fill = fill + 1 == NB ? 0 : fill + 1; }
-
-    int cur = 0;
-    for (int b = 0; b < nblk; ++b) {
-        // this wave's pieces of block b have landed: at most the pieces of the y younger blocks it has issued stay outstanding
-        const int y = nblk - 1 - b < NB - 2 ? nblk - 1 - b : NB - 2;
-        __builtin_amdgcn_sched_barrier(0);
-        if (y <= 0) wait_vm<0>();
-        else if (y == 1) wait_vm<MINP>();
-        else wait_vm<2 * MINP>();
-        __builtin_amdgcn_s_barrier();                // every wave's pieces are in; every wave is done with the slot about to be refilled
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if (b + NB - 1 < nblk) { issue(b + NB - 1, fill); fill = fill + 1 == NB ? 0 : fill + 1; }
-
-        const char *A = lds + cur * BLK, *B = A + MT * 1024;
-        cur = cur + 1 == NB ? 0 : cur + 1;
+    // the product of the block in LDS slot `slot` into the accumulators
+    auto multiply = [&](int slot) {
+        const char *A = lds + slot * BLK, *B = A + MT * 1024;
         FR af[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -156,6 +144,99 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wg16(WgArgs a) {
             for (int i = 0; i < TM; ++i) bsum[i] = dot_ones(af[i], bsum[i]);
             if (XA) { if (do_x) bsumx = dot_ones(ax, bsumx); }
         }
+    };
+    auto publish = [&]() {                            // every wave's pieces are in; every wave is done with the slot about to be refilled
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    if constexpr (!HY) {
+        auto issue = [&](int b, int slot) {
+#pragma unroll
+            for (int i = 0; i < PW; ++i) {
+                const int pc = wave + i * NW;
+                if (pc < PIECES) dma_piece(b, slot, pc);
+            }
+            dma_extra(b, slot);
+        };
+        int fill = 0;
+#pragma unroll
+        for (int b = 0; b < NB - 1; ++b)
+            if (b < nblk) { issue(b, fill); fill = fill + 1 == NB ? 0 : fill + 1; }
+        int cur = 0;
+        for (int b = 0; b < nblk; ++b) {
+            // this wave's pieces of block b have landed: at most the pieces of the y younger blocks it has issued stay outstanding
+            const int y = nblk - 1 - b < NB - 2 ? nblk - 1 - b : NB - 2;
+            __builtin_amdgcn_sched_barrier(0);
+            if (y <= 0) wait_vm<0>();
+            else if (y == 1) wait_vm<MINP>();
+            else wait_vm<2 * MINP>();
+            publish();
+            if (b + NB - 1 < nblk) { issue(b + NB - 1, fill); fill = fill + 1 == NB ? 0 : fill + 1; }
+            multiply(cur);
+            cur = cur + 1 == NB ? 0 : cur + 1;
+        }
+    } else {
+        // Hybrid stream, four slots (block k in slot k % 4), two blocks per trip.  Per block a wave moves PWH pieces by DMA (pieces
+        // [0, PIECES / 2): the A operand's) and PWH through registers ([PIECES / 2, PIECES)).  Everything trip b + 2 needs -- DMA(b + 2),
+        // DMA(b + 3), the register pieces of both -- is issued together at the start of trip b, right behind its barrier (the two slots are
+        // the ones trip b - 2 used), so at the start of a trip the wave has outstanding exactly that trip's operations, issued one trip
+        // (two block times) earlier: ONE s_waitcnt vmcnt(0) per trip is exact, the register pieces go to LDS in front of the trip's only
+        // barrier, and the compiler's own bookkeeping for the register loads (which cannot see the inline-asm DMA) costs nothing.
+        constexpr int PWH = PW / 2;
+        static_assert(NB == 4 && PIECES % (2 * NW) == 0, "hybrid stream: four slots, every wave PW / 2 pieces by either path");
+        u4 r0[PWH], r1[PWH];
+        auto dma_half = [&](int b, int slot) {
+#pragma unroll
+            for (int i = 0; i < PWH; ++i) dma_piece(b, slot, wave + i * NW);
+            dma_extra(b, slot);
+        };
+        auto load_regs = [&](int b, u4 (&r)[PWH]) {
+#pragma unroll
+            for (int i = 0; i < PWH; ++i) r[i] = __builtin_nontemporal_load((const u4 *)piece_src(b, PIECES / 2 + wave + i * NW));
+        };
+        auto write_regs = [&](int slot, const u4 (&r)[PWH]) {
+#pragma unroll
+            for (int i = 0; i < PWH; ++i) *(u4 *)(lds + slot * BLK + (PIECES / 2 + wave + i * NW) * 1024 + lane * 16) = r[i];
+        };
+        int b = 0, sb = 0;                           // sb: slot of block b (even blocks: 0 or 2)
+        bool in_flight = false;                      // blocks b, b + 1: DMA issued, register pieces in r0 / r1
+        if (nblk >= 4) {
+            dma_half(0, 0); dma_half(1, 1);
+            load_regs(0, r0); load_regs(1, r1);
+            in_flight = true;
+            for (; b + 3 < nblk; b += 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                wait_vm<0>();
+                write_regs(sb, r0);
+                write_regs(sb + 1, r1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                publish();                           // blocks b, b + 1 are in; every wave is done with blocks b - 2, b - 1
+                dma_half(b + 2, sb ^ 2); dma_half(b + 3, (sb ^ 2) + 1);
+                load_regs(b + 2, r0); load_regs(b + 3, r1);
+                multiply(sb);
+                multiply(sb + 1);
+                sb ^= 2;
+            }
+        }
+        // the last 2 or 3 blocks of a long chunk (b, b + 1 in flight), or all 1 .. 3 blocks of a short one: everything in, one barrier
+        const int left = nblk - b;
+        __builtin_amdgcn_sched_barrier(0);
+        if (in_flight) {
+            write_regs(sb, r0);
+            write_regs(sb + 1, r1);
+        }
+        for (int k = in_flight ? 2 : 0; k < left; ++k) {
+            const int sk = (sb + k) & 3;
+            dma_half(b + k, sk);
+            load_regs(b + k, r0);
+            write_regs(sk, r0);
+        }
+        wait_vm<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        publish();
+        for (int k = 0; k < left; ++k) multiply((sb + k) & 3);
     }
 
     // partial product of this chunk: [16 MT][16 NT] row-major, then the column sums of A [16 MT]
@@ -197,12 +278,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wg16(WgArgs a) {
     }
 }
 
-template <bool BF, int MT, int NT, int WM, int WN, int NB, bool XA = false>
+template <bool BF, int MT, int NT, int WM, int WN, int NB, bool XA = false, bool HY = false>
 static int launch_wg16(const WgArgs &args, int n_desc, int n_chunks, hipStream_t st) {
     if (n_desc == 0) return VIPNERF_OK;
     const size_t ldsb = (size_t)NB * (MT + NT + (XA ? 1 : 0)) * 1024;
-    VN_HIP(hipFuncSetAttribute((const void *)k_wg16<BF, MT, NT, WM, WN, NB, XA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-    hipLaunchKernelGGL((k_wg16<BF, MT, NT, WM, WN, NB, XA>), dim3(n_chunks, n_desc), dim3(64 * WM * WN), ldsb, st, args);
+    VN_HIP(hipFuncSetAttribute((const void *)k_wg16<BF, MT, NT, WM, WN, NB, XA, HY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    hipLaunchKernelGGL((k_wg16<BF, MT, NT, WM, WN, NB, XA, HY>), dim3(n_chunks, n_desc), dim3(64 * WM * WN), ldsb, st, args);
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;
 }
@@ -213,7 +294,7 @@ static int launch_all(const WgArgs &big, int nbig, int n_chunks, const WgArgs &p
     int rc;
     {
         ProfScope ps("wgrad_256x256", st);
-        if ((rc = launch_wg16<BF, 16, 16, VN_WG16_BIG_WM, VN_WG16_BIG_WN, VN_WG16_BIG_NB, VN_WG16_SIGMA_FUSED != 0>(big, nbig, n_chunks, st))) return rc;
+        if ((rc = launch_wg16<BF, 16, 16, VN_WG16_BIG_WM, VN_WG16_BIG_WN, VN_WG16_HYBRID ? 4 : VN_WG16_BIG_NB, VN_WG16_SIGMA_FUSED != 0, VN_WG16_HYBRID != 0>(big, nbig, n_chunks, st))) return rc;
     }
     ProfScope ps("wgrad_small", st);
     if ((rc = launch_wg16<BF, 16, 4, 4, 1, 3>(pe, npe, n_pe, st))) return rc;

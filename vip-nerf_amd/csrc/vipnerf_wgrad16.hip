@@ -184,21 +184,24 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wg16(WgArgs a) {
         // the ones trip b - 2 used), so at the start of a trip the wave has outstanding exactly that trip's operations, issued one trip
         // (two block times) earlier: ONE s_waitcnt vmcnt(0) per trip is exact, the register pieces go to LDS in front of the trip's only
         // barrier, and the compiler's own bookkeeping for the register loads (which cannot see the inline-asm DMA) costs nothing.
-        constexpr int PWH = PW / 2;
-        static_assert(NB == 4 && PIECES % (2 * NW) == 0, "hybrid stream: four slots, every wave PW / 2 pieces by either path");
-        u4 r0[PWH], r1[PWH];
+#ifndef VN_WG16_DMA_PIECES
+#define VN_WG16_DMA_PIECES 2     // of a wave's 4 pieces per block (256 x 256 launch): measured 1.36 ms per 4096-ray step; see DESIGN.md 4.3a for 0 / 1 / 3
+#endif
+        constexpr int PWD = VN_WG16_DMA_PIECES < PW ? VN_WG16_DMA_PIECES : PW / 2, PWR = PW - PWD;     // pieces per wave and block by DMA / through registers
+        static_assert(NB == 4 && PIECES % NW == 0 && PWR >= 1, "hybrid stream: four slots, every wave the same number of pieces");
+        u4 r0[PWR], r1[PWR];
         auto dma_half = [&](int b, int slot) {
 #pragma unroll
-            for (int i = 0; i < PWH; ++i) dma_piece(b, slot, wave + i * NW);
+            for (int i = 0; i < PWD; ++i) dma_piece(b, slot, wave + i * NW);
             dma_extra(b, slot);
         };
-        auto load_regs = [&](int b, u4 (&r)[PWH]) {
+        auto load_regs = [&](int b, u4 (&r)[PWR]) {
 #pragma unroll
-            for (int i = 0; i < PWH; ++i) r[i] = __builtin_nontemporal_load((const u4 *)piece_src(b, PIECES / 2 + wave + i * NW));
+            for (int i = 0; i < PWR; ++i) r[i] = __builtin_nontemporal_load((const u4 *)piece_src(b, PWD * NW + wave + i * NW));
         };
-        auto write_regs = [&](int slot, const u4 (&r)[PWH]) {
+        auto write_regs = [&](int slot, const u4 (&r)[PWR]) {
 #pragma unroll
-            for (int i = 0; i < PWH; ++i) *(u4 *)(lds + slot * BLK + (PIECES / 2 + wave + i * NW) * 1024 + lane * 16) = r[i];
+            for (int i = 0; i < PWR; ++i) *(u4 *)(lds + slot * BLK + (PWD * NW + wave + i * NW) * 1024 + lane * 16) = r[i];
         };
         int b = 0, sb = 0;                           // sb: slot of block b (even blocks: 0 or 2)
         bool in_flight = false;                      // blocks b, b + 1: DMA issued, register pieces in r0 / r1

@@ -4,9 +4,11 @@
 //
 // Every operand is a 16-bit array in the tile-blocked layout the forward / data-gradient kernels wrote:
 //     [P / 16 groups][width / 16 tiles][16 points][16 features],   one (group, tile) = a row-major 16 x 16 matrix = 512 B,
-// so the bytes of a 32-point block of an operand are contiguous in HBM.  Nothing is staged through registers:
+// so the bytes of a 32-point block of an operand are contiguous in HBM.  No conversion, no register transposition anywhere:
 //   * HBM -> LDS by DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, lane-linear: the LDS image IS the HBM image), a ring of
-//     NB blocks, counted vmcnt + one raw workgroup barrier per block;
+//     NB blocks, counted vmcnt + one raw workgroup barrier per block; the 256 x 256 launch (HY) moves half of every block through
+//     registers instead (global_load_dwordx4 + ds_write_b128 of the same image), two blocks per barrier -- the DMA path alone tops out
+//     below what HBM delivers;
 //   * LDS -> MFMA fragments by the hardware transpose read: ds_read_b64_tr_b16 of lane l at (tile base + 8 l) returns, for feature
 //     l & 15, the points 4 (l >> 4) .. + 3 of the tile -- one read per 16-point group, two per 32-deep v_mfma_f32_16x16x32 fragment.
 //     The same read serves A and B (contraction index = point: element e < 4 of lane group q is point 4 q + e of the block's first

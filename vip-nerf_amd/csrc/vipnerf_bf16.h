@@ -185,6 +185,9 @@ __device__ __forceinline__ ACC mfma_split(const FR (&a)[NS], const FR (&b)[NS], 
 template <int NS, typename FR, int NPT>
 __device__ __forceinline__ AccN<NPT> mfma_split(const FR (&a)[NS], const BOp<FR, NPT> (&b)[NS], AccN<NPT> c) {
     static_assert(NS == 1, "point-tile pairs: single-MFMA modes");
+#if defined(VN_EXP) && VN_EXP == 43
+    return c;                                     // timing experiment only: no MFMAs (what the stores and the weight stream cost alone)
+#endif
 #pragma unroll
     for (int pt = 0; pt < NPT; ++pt) c.v[pt] = mfma_bf(a[0], b[0].v[pt], c.v[pt]);
     return c;

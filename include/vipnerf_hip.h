@@ -284,6 +284,19 @@ int32_t vipnerf_losses_forward(const vipnerf_config *cfg, int64_t n_rays, const 
                                const vipnerf_outputs *out, const vipnerf_loss_out *lout,
                                vipnerf_stream_t stream);
 
+/* The backward of the fused losses: out_k[i] = g[slot_k] * in_k[i] for up to VIPNERF_MAX_SCALE_SEGS arrays in ONE launch -- the loss
+ * kernel's unweighted gradient seeds times the upstream gradient of their loss value (autograd of TotalLoss = sum_k weight_k * loss_k,
+ * reference src/loss_functions/LossComputer01.py:33-44, which PyTorch evaluates as one multiplication per seed tensor).  g: the 8 upstream
+ * gradients of loss_values, on the device (no host synchronisation); in and out may be the same array. */
+#define VIPNERF_MAX_SCALE_SEGS 16
+typedef struct vipnerf_scale_seg {
+    const float *in; float *out;      /* device */
+    int64_t numel;
+    int32_t slot;                     /* index into g, 0..7 */
+    int32_t reserved;
+} vipnerf_scale_seg;
+int32_t vipnerf_scale_segments(int32_t n_segs, const vipnerf_scale_seg *segs, const float *g, vipnerf_stream_t stream);
+
 /* ---- stage-wise entry points (used by the parity tests; each is also a valid standalone op) ------------- */
 /* VipNeRF.get_z_vals_coarse (VipNeRF01.py:173-203).  t_rand NULL = no jitter. */
 int32_t vipnerf_coarse_depths(int64_t n_rays, int32_t n_samples, int32_t lindisp, const float *near,

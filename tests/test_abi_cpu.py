@@ -44,6 +44,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_lib.Rng) == 4 * 8 + 3 * 8 + 8
     assert C.sizeof(_lib.RayGen) == 4 * 4 + 4 * 4 + 2 * 8 + 8 + 2 * 8 + 4 * 8
     assert C.sizeof(_lib.RayBatch) == 16 * 8
+    assert C.sizeof(_lib.ScaleSeg) == 2 * 8 + 8 + 2 * 4
 
 
 def test_argument_validation_without_gpu():

@@ -837,3 +837,25 @@ def test_build_then_smoke_in_one_interpreter():
     r = subprocess.run([sys.executable, '-c', 'import __graft_entry__ as g; g.build(); g.smoke(); print("BUILD+SMOKE OK")'],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0 and 'BUILD+SMOKE OK' in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+def test_scale_segments_is_the_loss_backward_multiplication(dev):
+    """vipnerf_scale_segments (the fused losses' backward: every gradient seed times the upstream gradient of its loss value, ONE launch)
+    equals the per-tensor multiplications it replaces bit for bit -- ragged sizes, an empty tensor, repeated slots; more than 16 tensors
+    and a short g are refused."""
+    from vipnerf_hip import _lib as L
+    from vipnerf_hip import ops
+    torch.manual_seed(3)
+    shapes = [(4096, 3), (4096, 64), (4096, 64), (4096, 1), (4096,), (37, 3), (1, 192), (0, 5), (5,), (1000003,)]
+    ts = [torch.randn(*s, device=dev) for s in shapes]
+    slots = [0, 2, 2, 4, 6, 1, 3, 5, 7, 6]
+    g = torch.randn(8, device=dev)
+    outs = ops.scale_segments(ts, slots, g)
+    assert len(outs) == len(ts)
+    for t, sl, o in zip(ts, slots, outs):
+        assert o.shape == t.shape and torch.equal(o, g[sl] * t)
+    assert ops.scale_segments([], [], g) == []
+    with pytest.raises(L.VipNerfHipError):
+        ops.scale_segments(ts * 2, slots * 2, g)
+    with pytest.raises(L.VipNerfHipError):
+        ops.scale_segments(ts[:1], [0], g[:4])

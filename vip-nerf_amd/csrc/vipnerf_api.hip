@@ -521,6 +521,23 @@ int32_t vipnerf_losses_forward(const vipnerf_config *cfg, int64_t n_rays, const 
     return launch_losses(a, (hipStream_t)stream);
 }
 
+int32_t vipnerf_scale_segments(int32_t n_segs, const vipnerf_scale_seg *segs, const float *g, vipnerf_stream_t stream) {
+    clear_stale_hip_error();
+    if (n_segs < 0 || n_segs > VIPNERF_MAX_SCALE_SEGS) { set_error("scale_segments: n_segs=%d (0..%d)", n_segs, VIPNERF_MAX_SCALE_SEGS); return VIPNERF_E_ARG; }
+    if (n_segs == 0) return VIPNERF_OK;
+    if (!segs || !g) { set_error("scale_segments: NULL argument"); return VIPNERF_E_ARG; }
+    ScaleArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n = n_segs; a.g = g;
+    for (int k = 0; k < n_segs; ++k) {
+        if (segs[k].numel < 0 || segs[k].slot < 0 || segs[k].slot > 7 || (segs[k].numel > 0 && (!segs[k].in || !segs[k].out))) {
+            set_error("scale_segments: segment %d: numel %lld, slot %d, NULL pointers?", k, (long long)segs[k].numel, segs[k].slot); return VIPNERF_E_ARG; }
+        a.s[k] = segs[k];
+    }
+    ProfScope ps("losses_bwd", (hipStream_t)stream);
+    return launch_scale_segments(a, (hipStream_t)stream);
+}
+
 int32_t vipnerf_generate_rays(const vipnerf_raygen *gen, int64_t n_rays, const vipnerf_ray_batch *out,
                               vipnerf_stream_t stream) {
     clear_stale_hip_error();

@@ -50,5 +50,11 @@ int launch_composite(const CompositeArgs &a, hipStream_t st);
 int launch_composite_bwd(const CompositeBwdArgs &a, hipStream_t st);
 int launch_sample_fine(const SampleArgs &a, hipStream_t st);
 int launch_losses(const LossArgs &a, hipStream_t st);
+struct ScaleArgs {
+    vipnerf_scale_seg s[VIPNERF_MAX_SCALE_SEGS];
+    int n;
+    const float *g;
+};
+int launch_scale_segments(const ScaleArgs &a, hipStream_t st);
 
 }  // namespace vn

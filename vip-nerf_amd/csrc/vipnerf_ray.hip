@@ -472,6 +472,23 @@ __global__ void k_loss_final(LossArgs a) {
     if (threadIdx.x == 0) a.loss_values[7] = 0.f;
 }
 
+// out_k = g[slot_k] * in_k for all segments in one launch (blockIdx.y = segment): the fused losses' backward
+__global__ void k_scale_segments(ScaleArgs a) {
+    const vipnerf_scale_seg sg = a.s[blockIdx.y];
+    const float w = a.g[sg.slot];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < sg.numel; i += (int64_t)gridDim.x * blockDim.x) sg.out[i] = w * sg.in[i];
+}
+int launch_scale_segments(const ScaleArgs &a, hipStream_t st) {
+    int64_t most = 0;
+    for (int k = 0; k < a.n; ++k) most = a.s[k].numel > most ? a.s[k].numel : most;
+    if (a.n <= 0 || most <= 0) return VIPNERF_OK;
+    int64_t bx = (most + 1023) / 1024;              // 256 threads x 4 elements each where the segment is that long
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(k_scale_segments, dim3((unsigned)bx, (unsigned)a.n), dim3(256), 0, st, a);
+    VN_HIP(hipGetLastError());
+    return VIPNERF_OK;
+}
+
 int launch_losses(const LossArgs &a, hipStream_t st) {
     if (a.N <= 0) return VIPNERF_OK;
     hipLaunchKernelGGL(k_loss_counts, dim3(1), dim3(1024), 0, st, a.N, a.in.mask_nerf, a.in.mask_sparse, a.counts);

@@ -81,6 +81,10 @@ class LossOut(C.Structure):
     _fields_ = [('loss_values', c_f), ('coarse', LossLevelSeeds), ('fine', LossLevelSeeds), ('scratch', c_f)]
 
 
+class ScaleSeg(C.Structure):
+    _fields_ = [('in_', c_f), ('out', c_f), ('numel', C.c_int64), ('slot', C.c_int32), ('reserved', C.c_int32)]
+
+
 class Camera(C.Structure):
     _fields_ = [('kinv', C.c_float * 9), ('pose', C.c_float * 12), ('ndc_cx', C.c_float), ('ndc_cy', C.c_float),
                 ('pad', C.c_float * 2)]
@@ -130,6 +134,7 @@ SYMBOLS = {
     'vipnerf_render_backward': (C.c_int32, [P(Config), P(Rays), c_f, c_f, P(Outputs), P(OutGrads), c_f, c_f,
                                             P(MlpGrads), P(MlpGrads), c_f]),
     'vipnerf_losses_forward': (C.c_int32, [P(Config), C.c_int64, P(LossIn), P(Outputs), P(LossOut), c_f]),
+    'vipnerf_scale_segments': (C.c_int32, [C.c_int32, P(ScaleSeg), c_f, c_f]),
     'vipnerf_coarse_depths': (C.c_int32, [C.c_int64, C.c_int32, C.c_int32, c_f, c_f, c_f, c_f, c_f]),
     'vipnerf_sample_fine': (C.c_int32, [C.c_int64, C.c_int32, C.c_int32, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     'vipnerf_mlp_forward': (C.c_int32, [C.c_int64, C.c_int32, c_f, c_f, c_f, c_f, C.c_float, c_f, c_f, c_f, c_f,

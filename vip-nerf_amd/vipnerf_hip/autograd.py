@@ -245,15 +245,15 @@ class FusedLossFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         sc, sf = ctx.seeds
-        out = []
+        out = [None] * 10
+        todo = []                                    # (position in out, seed tensor, slot of loss_values whose upstream gradient scales it)
         for li, sd in enumerate((sc, sf)):
             if sd is None:
-                out += [None] * 5
                 continue
-            out.append(g[0 + li] * sd['rgb'])
-            out.append(g[2 + li] * sd['visibility'])
-            out.append(g[2 + li] * sd['raw_vis'])
-            out.append(g[4 + li] * sd['vis2'] if 'vis2' in sd else None)
-            out.append(g[6] * sd['depth'] if 'depth' in sd else None)
-        out = [o if p else None for o, p in zip(out, ctx.present)]
+            for j, (key, slot) in enumerate((('rgb', 0 + li), ('visibility', 2 + li), ('raw_vis', 2 + li), ('vis2', 4 + li), ('depth', 6))):
+                if key in sd and ctx.present[5 * li + j]:
+                    todo.append((5 * li + j, sd[key], slot))
+        scaled = ops.scale_segments([t for _, t, _ in todo], [s for _, _, s in todo], g)      # one launch for all of them
+        for (pos, _, _), t in zip(todo, scaled):
+            out[pos] = t
         return (None, None, None, None, None, None, None, *out)

@@ -473,6 +473,31 @@ def losses_forward(cfg: L.Config, n_rays, target_rgb, mask_nerf, prior, mask_spa
     return vals, seeds[0], seeds[1]
 
 
+def scale_segments(tensors: List[torch.Tensor], slots: List[int], g: torch.Tensor) -> List[torch.Tensor]:
+    """-> [g[slot_k] * tensors[k]] in ONE launch (the fused losses' backward: seeds times the upstream gradients of their loss values).
+    The results are views of one buffer."""
+    if not tensors:
+        return []
+    if len(tensors) > 16:
+        raise L.VipNerfHipError(f'scale_segments: {len(tensors)} tensors (at most 16)')
+    ins = [f32c(t) for t in tensors]
+    gc = f32c(g).reshape(-1)
+    if gc.numel() < 8:
+        raise L.VipNerfHipError('scale_segments: g must hold 8 values')
+    offs, total = [], 0
+    for t in ins:
+        offs.append(total)
+        total += (t.numel() + 3) & ~3
+    flat = torch.empty(total, dtype=torch.float32, device=ins[0].device)
+    outs = [flat[o:o + t.numel()].view(t.shape) for o, t in zip(offs, ins)]
+    segs = (L.ScaleSeg * len(ins))()
+    for k, (t, o, sl) in enumerate(zip(ins, outs, slots)):
+        segs[k].in_, segs[k].out, segs[k].numel, segs[k].slot = _p(t) if t.numel() else None, _p(o) if t.numel() else None, t.numel(), int(sl)
+    with on_device(*ins, gc, flat) as dev:
+        L.check(L.load().vipnerf_scale_segments(len(ins), segs, _p(gc), _stream(dev)), 'vipnerf_scale_segments')
+    return outs
+
+
 # ------------------------------------------------------------------------------------------------ measurement
 def profile_enable(on: bool):
     L.check(L.load().vipnerf_profile_enable(int(on)), 'vipnerf_profile_enable')

@@ -297,6 +297,16 @@ typedef struct vipnerf_scale_seg {
 } vipnerf_scale_seg;
 int32_t vipnerf_scale_segments(int32_t n_segs, const vipnerf_scale_seg *segs, const float *g, vipnerf_stream_t stream);
 
+/* One Adam step on flat fp32 buffers (parameters, both moments, gradients: n elements each) in ONE launch -- the update of
+ * torch.optim.Adam (the reference's optimizer, src/Trainer01.py:505-515: betas (0.9, 0.999), no weight decay, no amsgrad), evaluated with
+ * the roundings of torch's single-tensor path (torch/optim/adam.py::_single_tensor_adam), whose five elementwise kernels it replaces:
+ *     m <- lerp(m, g, lerp_w);  v <- v * beta2;  v <- v + sq_w * (g * g);  d <- sqrt(v) * inv_sqrt_bc2 + eps;  p <- p + neg_step * (m / d)
+ * The caller passes the scalars torch derives on the host (in double, then rounded to float): lerp_w = 1 - beta1, sq_w = 1 - beta2,
+ * inv_sqrt_bc2 = (float)(1.0 / sqrt(1 - beta2^t)) (the reciprocal in double: ATen's division by a host scalar), neg_step = -lr / (1 - beta1^t).  fma_mask: which of the three fused multiply-adds torch's
+ * kernels contract (bit 0 the lerp, bit 1 v's update, bit 2 the parameter's); -1 = the combination tests/ found bit-identical on gfx950. */
+int32_t vipnerf_adam_step(int64_t n, float *param, float *exp_avg, float *exp_avg_sq, const float *grad, float lerp_w, float beta2, float sq_w,
+                          float inv_sqrt_bc2, float eps, float neg_step, int32_t fma_mask, vipnerf_stream_t stream);
+
 /* ---- stage-wise entry points (used by the parity tests; each is also a valid standalone op) ------------- */
 /* VipNeRF.get_z_vals_coarse (VipNeRF01.py:173-203).  t_rand NULL = no jitter. */
 int32_t vipnerf_coarse_depths(int64_t n_rays, int32_t n_samples, int32_t lindisp, const float *near,

@@ -114,3 +114,41 @@ def test_flat_adam_trains_like_torch_adam():
         if kind == 'flat':
             assert opt._flat_grad().data_ptr() == next(iter(model.parameters())).grad.data_ptr(), 'the adopted gradient buffer is used as it is'
     assert torch.equal(finals[0], finals[1])
+
+
+def test_fused_adam_step_is_torch_adam():
+    """vipnerf_adam_step (one launch for the whole flat update; FlatAdam's default on the GPU) takes, bit for bit, the steps of torch.optim.Adam's
+    single-tensor path on the device: 1,191,946 values, gradients spanning 12 orders of magnitude incl. exact zeros, five steps with a changing
+    learning rate.  Which of torch's three update expressions are contracted into an fma is a property of its compiled kernels: the library's
+    default combination is the one that matches here (all eight are tried and the matching ones printed)."""
+    from vipnerf_hip import ops
+    dev = torch.device('cuda:0')
+    torch.manual_seed(21)
+    n = 1191946
+    p0 = torch.randn(n, device=dev) * 0.1
+    grads = []
+    for it in range(5):
+        g = torch.randn(n, device=dev) * 10.0 ** torch.randint(-9, 3, (n,), device=dev).float()
+        g[torch.rand(n, device=dev) < 0.05] = 0.0
+        grads.append(g)
+    lrs = [5e-4 * 0.97 ** it for it in range(5)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=5e-4, betas=(0.9, 0.999), eps=1e-8, foreach=False, fused=False)
+    states = []
+    for it in range(5):
+        ref.grad = grads[it].clone()
+        opt.param_groups[0]['lr'] = lrs[it]
+        opt.step()
+        st = opt.state[ref]
+        states.append((ref.detach().clone(), st['exp_avg'].clone(), st['exp_avg_sq'].clone()))
+    matching = []
+    for mask in list(range(8)) + [-1]:
+        p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        ok = True
+        for it in range(5):
+            ops.adam_step(p, m, v, grads[it], lrs[it], 0.9, 0.999, 1e-8, it + 1, fma_mask=mask)
+            ok = ok and torch.equal(p, states[it][0]) and torch.equal(m, states[it][1]) and torch.equal(v, states[it][2])
+        if ok:
+            matching.append(mask)
+    print('fma masks whose five steps equal torch.optim.Adam bit for bit:', matching)
+    assert -1 in matching, f'the library default does not reproduce torch.optim.Adam; matching masks: {matching}'

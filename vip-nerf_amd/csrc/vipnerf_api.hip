@@ -538,6 +538,21 @@ int32_t vipnerf_scale_segments(int32_t n_segs, const vipnerf_scale_seg *segs, co
     return launch_scale_segments(a, (hipStream_t)stream);
 }
 
+#ifndef VN_ADAM_FMA_MASK
+#define VN_ADAM_FMA_MASK 7        // which of torch's three update expressions its kernels contract into an fma on gfx950 (tests/test_hip_fullsize.py)
+#endif
+int32_t vipnerf_adam_step(int64_t n, float *param, float *exp_avg, float *exp_avg_sq, const float *grad, float lerp_w, float beta2, float sq_w,
+                          float inv_sqrt_bc2, float eps, float neg_step, int32_t fma_mask, vipnerf_stream_t stream) {
+    clear_stale_hip_error();
+    if (n < 0) { set_error("adam_step: n < 0"); return VIPNERF_E_ARG; }
+    if (n == 0) return VIPNERF_OK;
+    if (!param || !exp_avg || !exp_avg_sq || !grad) { set_error("adam_step: NULL argument"); return VIPNERF_E_ARG; }
+    if (fma_mask < -1 || fma_mask > 7) { set_error("adam_step: fma_mask=%d (-1 or 0..7)", fma_mask); return VIPNERF_E_ARG; }
+    ProfScope ps("adam", (hipStream_t)stream);
+    return launch_adam_step(n, param, exp_avg, exp_avg_sq, grad, lerp_w, beta2, sq_w, inv_sqrt_bc2, eps, neg_step,
+                            fma_mask < 0 ? VN_ADAM_FMA_MASK : fma_mask, (hipStream_t)stream);
+}
+
 int32_t vipnerf_generate_rays(const vipnerf_raygen *gen, int64_t n_rays, const vipnerf_ray_batch *out,
                               vipnerf_stream_t stream) {
     clear_stale_hip_error();

@@ -56,5 +56,7 @@ struct ScaleArgs {
     const float *g;
 };
 int launch_scale_segments(const ScaleArgs &a, hipStream_t st);
+int launch_adam_step(int64_t n, float *p, float *m, float *v, const float *g, float lerp_w, float beta2, float sq_w, float inv_s, float eps,
+                     float neg_step, int mask, hipStream_t st);
 
 }  // namespace vn

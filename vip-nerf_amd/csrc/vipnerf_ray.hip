@@ -489,6 +489,40 @@ int launch_scale_segments(const ScaleArgs &a, hipStream_t st) {
     return VIPNERF_OK;
 }
 
+// One Adam step on flat buffers; every operation rounded where torch's separate elementwise kernels round (see include/vipnerf_hip.h)
+template <int MASK>
+__global__ void k_adam_step(int64_t n, float *p, float *m, float *v, const float *g, float lerp_w, float beta2, float sq_w, float inv_s, float eps,
+                            float neg_step) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i], m0 = m[i];
+        const float diff = __fsub_rn(gi, m0);
+        const float m1 = (MASK & 1) ? fmaf(lerp_w, diff, m0) : __fadd_rn(m0, __fmul_rn(lerp_w, diff));
+        const float v0 = __fmul_rn(v[i], beta2), gg = __fmul_rn(gi, gi);              // addcmul is a + alpha * (b * c)
+        const float v1 = (MASK & 2) ? fmaf(sq_w, gg, v0) : __fadd_rn(v0, __fmul_rn(sq_w, gg));
+        // sqrtf and / are the correctly rounded ones (hipcc's default; HIP's __fsqrt_rn / __fdiv_rn map to the NATIVE instructions unless
+        // OCML_BASIC_ROUNDED_OPERATIONS is defined); the library is built with -ffp-contract=off, so nothing below fuses by itself
+        const float d = __fadd_rn(__fmul_rn(sqrtf(v1), inv_s), eps);
+        const float q = m1 / d;
+        p[i] = (MASK & 4) ? fmaf(neg_step, q, p[i]) : __fadd_rn(p[i], __fmul_rn(neg_step, q));
+        m[i] = m1;
+        v[i] = v1;
+    }
+}
+int launch_adam_step(int64_t n, float *p, float *m, float *v, const float *g, float lerp_w, float beta2, float sq_w, float inv_s, float eps,
+                     float neg_step, int mask, hipStream_t st) {
+    if (n <= 0) return VIPNERF_OK;
+    int64_t nb = (n + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    const dim3 grid((unsigned)nb), blk(256);
+    switch (mask & 7) {
+#define ADAM_CASE(M) case M: hipLaunchKernelGGL(k_adam_step<M>, grid, blk, 0, st, n, p, m, v, g, lerp_w, beta2, sq_w, inv_s, eps, neg_step); break;
+        ADAM_CASE(0) ADAM_CASE(1) ADAM_CASE(2) ADAM_CASE(3) ADAM_CASE(4) ADAM_CASE(5) ADAM_CASE(6) ADAM_CASE(7)
+#undef ADAM_CASE
+    }
+    VN_HIP(hipGetLastError());
+    return VIPNERF_OK;
+}
+
 int launch_losses(const LossArgs &a, hipStream_t st) {
     if (a.N <= 0) return VIPNERF_OK;
     hipLaunchKernelGGL(k_loss_counts, dim3(1), dim3(1024), 0, st, a.N, a.in.mask_nerf, a.in.mask_sparse, a.counts);

@@ -498,6 +498,22 @@ def scale_segments(tensors: List[torch.Tensor], slots: List[int], g: torch.Tenso
     return outs
 
 
+def adam_step(param: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, grad: torch.Tensor, lr: float, beta1: float, beta2: float,
+              eps: float, step: int, fma_mask: int = -1):
+    """One Adam step on flat fp32 device buffers in ONE launch (in place), with torch.optim.Adam's single-tensor roundings; the host-side
+    scalars are derived exactly as torch/optim/adam.py::_single_tensor_adam derives them (Python doubles, rounded to float by the kernels'
+    scalar arguments)."""
+    import numpy as np
+    for t in (param, exp_avg, exp_avg_sq, grad):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 1 or t.numel() != param.numel():
+            raise L.VipNerfHipError('adam_step: flat contiguous fp32 buffers of one size')
+    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    inv_s = float(np.float32(1.0 / bc2 ** 0.5))     # torch divides by a host scalar as a multiplication by its reciprocal, taken in double, rounded to float
+    with on_device(param, exp_avg, exp_avg_sq, grad) as dev:
+        L.check(L.load().vipnerf_adam_step(param.numel(), _p(param), _p(exp_avg), _p(exp_avg_sq), _p(grad), 1 - beta1, beta2, 1 - beta2, inv_s, eps,
+                                           -(lr / bc1), int(fma_mask), _stream(dev)), 'vipnerf_adam_step')
+
+
 # ------------------------------------------------------------------------------------------------ measurement
 def profile_enable(on: bool):
     L.check(L.load().vipnerf_profile_enable(int(on)), 'vipnerf_profile_enable')

@@ -9,6 +9,9 @@ the flat buffer -- and one step is the six elementwise kernels of torch's own si
     exp_avg.lerp_(g, 1 - beta1);  exp_avg_sq.mul_(beta2).addcmul_(g, g, value=1 - beta2)
     denom = (exp_avg_sq.sqrt() / sqrt(1 - beta2^t)).add_(eps);  param.addcdiv_(exp_avg, denom, value=-lr / (1 - beta1^t))
 
+(on the GPU by default ONE launch: the library's vipnerf_adam_step evaluates the same chain with the roundings of those kernels -- which
+of them contract into an fma, the division by a host scalar as a multiplication by its double-precision reciprocal rounded to float --
+found and pinned against torch on the device, tests/test_hip_fullsize.py::test_fused_adam_step_is_torch_adam; fused=False keeps the six)
 -- the same expressions, in the same order, as torch.optim.Adam(foreach=False, fused=False) (torch/optim/adam.py::_single_tensor_adam):
 elementwise, so bit-identical to it per parameter (tests/test_abi_cpu.py::test_flat_adam_is_torch_adam).  The reference's optimizer
 (torch.optim.Adam, Trainer01.py:505-515, betas (0.9, 0.999), no weight decay, no amsgrad) is this update.
@@ -24,7 +27,7 @@ import torch
 
 
 class FlatAdam:
-    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 5e-4, betas=(0.9, 0.999), eps: float = 1e-8):
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 5e-4, betas=(0.9, 0.999), eps: float = 1e-8, fused: bool = None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError('FlatAdam: no parameters')
@@ -42,6 +45,10 @@ class FlatAdam:
         self._grad = torch.zeros_like(self.flat)    # gather target when the gradients are not already one buffer
         self.param_groups = [{'lr': float(lr), 'betas': (float(betas[0]), float(betas[1])), 'eps': float(eps)}]
         self.t = 0
+        # fused: the whole step as ONE launch of the library's vipnerf_adam_step (same roundings; device buffers only).  None = where possible
+        self.fused = self.flat.is_cuda if fused is None else bool(fused)
+        if self.fused and not self.flat.is_cuda:
+            raise ValueError('FlatAdam(fused=True) needs the parameters on the GPU')
 
     def _flat_grad(self) -> torch.Tensor:
         """The gradients as one tensor in parameter order: the buffer they already are consecutive views of (the HIP backward's
@@ -78,6 +85,10 @@ class FlatAdam:
         lr, (b1, b2), eps = grp['lr'], grp['betas'], grp['eps']
         g = self._flat_grad()
         self.t += 1
+        if self.fused:
+            from . import ops
+            ops.adam_step(self.flat, self.exp_avg, self.exp_avg_sq, g.contiguous(), lr, b1, b2, eps, self.t)
+            return
         self.exp_avg.lerp_(g, 1 - b1)
         self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
         bc1, bc2 = 1 - b1 ** self.t, 1 - b2 ** self.t

@@ -305,7 +305,7 @@ def main():
     ap.add_argument('--no-configs4', action='store_true', help='skip the configs[4] block (DTU shard in bf16 / fp16)')
     ap.add_argument('--configs4-rays', type=int, default=16384, help='rays per GPU of the configs[4] block (131,072 / 8)')
     ap.add_argument('--optimizer', default='flat', choices=['flat', 'torch-fused'], help='flat: vipnerf_hip.optim.FlatAdam (torch.optim.Adam\'s own '
-                    'update on the flat buffers, bit-identical, 6 launches); torch-fused: torch.optim.Adam(fused=True) (2 x ~100 us multi_tensor_apply)')
+                    'update on the flat buffers, bit-identical, one launch); torch-fused: torch.optim.Adam(fused=True) (2 x ~100 us multi_tensor_apply)')
     ap.add_argument('--force-dist', action='store_true', help='take the multi-rank code path (process group, broadcast, all-reduce, '
                     'barriers) even with one rank')
     args = ap.parse_args()
@@ -361,7 +361,7 @@ def main():
             self.model.train()
             self.lossc = LossComputerHip(self.cfg)
             if args.optimizer == 'flat':         # torch's single-tensor Adam expressions on ONE flat parameter / moment / gradient buffer
-                from vipnerf_hip.optim import FlatAdam                       # (bit-identical to torch.optim.Adam; 6 launches per step)
+                from vipnerf_hip.optim import FlatAdam                       # (bit-identical to torch.optim.Adam; one library launch per step)
                 self.opt = FlatAdam(self.model.parameters(), lr=5e-4, betas=(0.9, 0.999))
             else:
                 self.opt = torch.optim.Adam(self.model.parameters(), lr=5e-4, betas=(0.9, 0.999), fused=True)
@@ -504,7 +504,7 @@ def main():
                    'rays_per_gpu': rays, 'global_rays': rays * world, 'parallelism': f'ray-sharded dp{world}',
                    'gemm_arithmetic': args.precision, 'arithmetic_note': ARITH[args.precision][3],
                    'optimizer': 'Adam(lr 5e-4, betas 0.9 / 0.999): ' + ('vipnerf_hip.optim.FlatAdam -- torch.optim.Adam\'s single-tensor update on one flat '
-                                 'parameter / moment / gradient buffer (bit-identical per parameter)' if args.optimizer == 'flat' else 'torch.optim.Adam(fused=True)')},
+                                 'parameter / moment / gradient buffer, one launch (vipnerf_adam_step; bit-identical per parameter)' if args.optimizer == 'flat' else 'torch.optim.Adam(fused=True)')},
         'roofline': roofline_block(args.precision, prof, args.steps, rays, ms, sclk, n_sec=n_sec, workload=args.workload),
     }
     if collectives and world == 1:

@@ -302,8 +302,11 @@ static int launch_all(const WgArgs &big, int nbig, int n_chunks, const WgArgs &p
         if ((rc = launch_wg16<BF, 16, 16, VN_WG16_BIG_WM, VN_WG16_BIG_WN, VN_WG16_HYBRID ? 4 : VN_WG16_BIG_NB, VN_WG16_SIGMA_FUSED != 0, VN_WG16_HYBRID != 0>(big, nbig, n_chunks, st))) return rc;
     }
     ProfScope ps("wgrad_small", st);
-    if ((rc = launch_wg16<BF, 16, 4, 4, 1, 3>(pe, npe, n_pe, st))) return rc;
-    if ((rc = launch_wg16<BF, 8, 16, 2, 2, 3>(vf, nvf, n_single, st))) return rc;
+#ifndef VN_WG16_THIN_HYBRID
+#define VN_WG16_THIN_HYBRID 0      // the 256 x 64 and 128 x 256 launches on the hybrid trip stream too (measured: DESIGN.md 4.3a)
+#endif
+    if ((rc = launch_wg16<BF, 16, 4, 4, 1, VN_WG16_THIN_HYBRID ? 4 : 3, false, VN_WG16_THIN_HYBRID != 0>(pe, npe, n_pe, st))) return rc;
+    if ((rc = launch_wg16<BF, 8, 16, 2, 2, VN_WG16_THIN_HYBRID ? 4 : 3, false, VN_WG16_THIN_HYBRID != 0>(vf, nvf, n_single, st))) return rc;
     if ((rc = launch_wg16<BF, 1, 16, 1, 4, 4>(sg, nsg, n_single, st))) return rc;
     if ((rc = launch_wg16<BF, 8, 2, 4, 1, 4>(vd, nvd, n_vd, st))) return rc;
     return launch_wg16<BF, 1, 8, 1, 4, 4>(oh, noh, n_oh, st);

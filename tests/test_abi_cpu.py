@@ -291,3 +291,29 @@ def test_flat_adam_state_dict_is_torch_adams():
     assert ob.t == 0 and float(ob.exp_avg.abs().max()) == 0
     with pytest.raises(ValueError):
         ob.load_state_dict(torch.optim.Adam(a[:2]).state_dict())
+
+
+def test_argument_checks_need_no_gpu():
+    """Every entry point validates its arguments before it touches the device: the error paths return VIPNERF_E_* (and a message through
+    vipnerf_last_error) on a machine without a GPU."""
+    from vipnerf_hip import _lib
+    lib = _lib.load()
+
+    def last():
+        buf = C.create_string_buffer(512)
+        lib.vipnerf_last_error(buf, 512)
+        return buf.value.decode()
+
+    segs = (_lib.ScaleSeg * 17)()
+    assert lib.vipnerf_scale_segments(17, segs, None, None) < 0 and 'n_segs' in last()
+    assert lib.vipnerf_scale_segments(0, None, None, None) == 0
+    assert lib.vipnerf_scale_segments(1, segs, None, None) < 0 and 'NULL' in last()
+    assert lib.vipnerf_adam_step(-1, None, None, None, None, 0.1, 0.999, 0.001, 1.0, 1e-8, -1e-3, -1, None) < 0
+    assert lib.vipnerf_adam_step(0, None, None, None, None, 0.1, 0.999, 0.001, 1.0, 1e-8, -1e-3, -1, None) == 0
+    assert lib.vipnerf_adam_step(8, None, None, None, None, 0.1, 0.999, 0.001, 1.0, 1e-8, -1e-3, -1, None) < 0 and 'NULL' in last()
+    from vipnerf_hip import ops
+    bad = ops.make_config(True, 64, 128, 1, True, topology=(8, 256, 10, 4, 7))
+    a, b = C.c_size_t(0), C.c_size_t(0)
+    assert lib.vipnerf_query_workspace(C.byref(bad), 16, C.byref(a), C.byref(b)) < 0 and 'head_variant' in last()
+    bad = ops.make_config(True, 48, 128, 1, True)
+    assert lib.vipnerf_query_workspace(C.byref(bad), 16, C.byref(a), C.byref(b)) < 0 and 'n_coarse' in last()

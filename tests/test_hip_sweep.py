@@ -91,7 +91,9 @@ def test_config_sweep_vs_oracle(dev, c):
 # alpha / weights carry (1.4e-5 / 8e-5 on values <= 7e-3)
 SWEEP16 = {'fp16': (5e-3, 5e-4, 5e-5, 1e-1, 2e-2), 'bf16': (4e-2, 5e-3, 3e-4, 3e-1, 6e-2),
            # fp16x3h: fp32-grade forward / data gradients (3 fp16 MFMAs per product), 16-bit tile storage + single-MFMA weight gradients
-           'fp16x3h': (2e-4, 1e-5, 2e-7, 1e-2, 1e-3)}      # measured: medians 1.7e-5 .. 1.7e-4, worst tensor 2.1e-3
+           'fp16x3h': (2e-4, 1e-5, 2e-7, 1e-2, 1e-3),      # measured: medians 1.7e-5 .. 1.7e-4, worst tensor 2.1e-3
+           # fp16x3: fp32-grade everywhere (3 fp16 MFMAs per product in every GEMM, presplit operand storage, split weight-gradient kernels)
+           'fp16x3': (2e-4, 1e-5, 2e-7, 5e-3, 1e-5)}        # measured: medians 3e-7 .. 2.3e-6; a tensor or two per case at 1e-4 .. 2e-3 (ReLU flips of single points in 1 .. 48-row batches)
 
 
 @pytest.mark.parametrize('prec', list(SWEEP16))

@@ -129,3 +129,13 @@ def test_config_sweep_16bit_vs_oracle(dev, c, prec):
     errs.sort()
     print(f'{what}: gradient rel. L2 median {errs[len(errs) // 2]:.2e}, worst {errs[-1]:.2e}')
     assert errs[len(errs) // 2] <= gmed
+    # the same weights in eval mode with secondary views (a validation frame: the kernels without activation stores, ragged point counts):
+    # the coarse level against the oracle's eval render (the fine level samples from the coarse weights: finite, and close where it is compared)
+    model.eval()
+    model.injected_rng = model.injected_z_fine = None
+    with torch.no_grad():
+        ev = model(tp.ref_batch(b, dev, 0), retraw=True, sec_views_vis=True)
+    ro = vo.render_rays(vo.params_to_torch(params), b, cfg_o, None, train=False, sec_views=True)
+    for k in ('rgb_coarse', 'acc_coarse', 'visibility2_coarse', 'raw_sigma_coarse', 'raw_visibility2_coarse', 'weights_coarse'):
+        tp.assert_close(ev[k], ro[k], rtol=rtol, floor=max(floor, (10 * afloor if 'sigma' in k else afloor) / max(float(ro[k].abs().max()), 1e-30)), what=f'{what} eval {k}')
+    assert all(torch.isfinite(v).all() for v in ev.values())

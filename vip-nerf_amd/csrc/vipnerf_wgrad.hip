@@ -1262,10 +1262,32 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
                  const vipnerf_mlp_grads *G, int precision, hipStream_t st, const unsigned *gmax) {
     if (P == 0) return VIPNERF_OK;
     if (stores_t16(precision)) return launch_wgrad16(P, V, acts, al, bwd, bl, G, precision, st, gmax);
-    const int n_chunks = wgrad_chunks(P), n_pe = wgrad_chunks_split(P, WGRAD_SPLIT_PE), n_thin = wgrad_chunks_split(P, WGRAD_SPLIT_THIN),
-              n_single = wgrad_chunks_split(P, WGRAD_SINGLE_SPLIT);
-    const int chunk_pts = wgrad_chunk_pts(P), chunk_pe = chunk_pts / WGRAD_SPLIT_PE, chunk_thin = chunk_pts / WGRAD_SPLIT_THIN,
-              chunk_single = chunk_pts / WGRAD_SINGLE_SPLIT;
+#ifndef VN_WGRAD_ONE_ROUND
+#define VN_WGRAD_ONE_ROUND 1       // point chunks: one round of workgroups per launch where the level is large enough (like vipnerf_wgrad16.hip)
+#endif
+    int n_chunks = wgrad_chunks(P), n_pe = wgrad_chunks_split(P, WGRAD_SPLIT_PE), n_thin = wgrad_chunks_split(P, WGRAD_SPLIT_THIN),
+        n_single = wgrad_chunks_split(P, WGRAD_SINGLE_SPLIT);
+    int chunk_pts = wgrad_chunk_pts(P), chunk_pe = chunk_pts / WGRAD_SPLIT_PE, chunk_thin = chunk_pts / WGRAD_SPLIT_THIN,
+        chunk_single = chunk_pts / WGRAD_SINGLE_SPLIT;
+    if (VN_WGRAD_ONE_ROUND) {
+        // (workgroups a CU holds of the class) x 256 CUs over the launch's GEMMs, never more chunks than the plan the partial buffer was sized
+        // for: every chunk costs a partial product written and read back by the reduction (4096 rays, fine level: 768 -> 256 chunks of the
+        // 256 x 64 pair and of the 128 x 256 GEMM, 1536 -> 512 of the per-direction ones)
+        auto plan = [&](int &n, int &pts, int slots, int n_desc) {
+            const int target = slots / n_desc;
+            if (target >= n) return;
+            pts = (int)(((P + target - 1) / target + 31) / 32 * 32);
+            n = (int)((P + pts - 1) / pts);
+        };
+        // (the 256 x 256 class keeps its chunks of <= 8192 points, three rounds at the fine level: in one round the exact-fp32 kernel measured
+        // the same 8.22 ms per step and the HBM-bound split kernel of fp16x3 3.31 -> 3.61 -- one synchronised wave of workgroups streams worse)
+#ifndef VN_WGRAD_ROUNDS
+#define VN_WGRAD_ROUNDS 1
+#endif
+        plan(n_pe, chunk_pe, 512 * VN_WGRAD_ROUNDS, 2);
+        plan(n_single, chunk_single, 256 * VN_WGRAD_ROUNDS, 1);
+        plan(n_thin, chunk_thin, 1024 * VN_WGRAD_ROUNDS, 1 + V);
+    }
     float *partial = bwd + bl.partial;
     // storage of the 256x256 class's operands: 0 = fp32, 1 = fp16 high parts (FP16X3H), 2 = fp16 hi + lo planes (FP16X3)
     const int halves = stores_high16(precision) ? 1 : (precision == VIPNERF_PREC_FP16X3 && VN_F16_PRESPLIT ? 2 : 0);

@@ -327,7 +327,10 @@ int launch_wgrad16(size_t P, int V, const float *acts, const ActLayout &al, floa
         return Plan{(int)((P + pts - 1) / pts), pts};
     };
     const int cp0 = wgrad_chunk_pts(P);
-    const Plan pb = plan(wgrad_chunks(P), cp0, 256, 8);
+#ifndef VN_WG16_BIG_SLOTS
+#define VN_WG16_BIG_SLOTS 256      // workgroups of the 256 x 256 launch at a large level: one round of the chip (two / three rounds measured: DESIGN.md 4.3a)
+#endif
+    const Plan pb = plan(wgrad_chunks(P), cp0, VN_WG16_BIG_SLOTS, 8);
     const Plan pp = plan(wgrad_chunks_split(P, WGRAD_SPLIT_PE), cp0 / WGRAD_SPLIT_PE, 512, 2);
     const Plan psg = plan(wgrad_chunks_split(P, WGRAD_SINGLE_SPLIT), cp0 / WGRAD_SINGLE_SPLIT, 512, 1);
     const Plan pd = plan(wgrad_chunks_split(P, WGRAD_SPLIT_THIN), cp0 / WGRAD_SPLIT_THIN, 768, 1 + V);

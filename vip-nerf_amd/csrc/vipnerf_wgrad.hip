@@ -1269,6 +1269,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
         n_single = wgrad_chunks_split(P, WGRAD_SINGLE_SPLIT);
     int chunk_pts = wgrad_chunk_pts(P), chunk_pe = chunk_pts / WGRAD_SPLIT_PE, chunk_thin = chunk_pts / WGRAD_SPLIT_THIN,
         chunk_single = chunk_pts / WGRAD_SINGLE_SPLIT;
+    int n_sigma = n_single, chunk_sigma = chunk_single;
     if (VN_WGRAD_ONE_ROUND) {
         // (workgroups a CU holds of the class) x 256 CUs over the launch's GEMMs, never more chunks than the plan the partial buffer was sized
         // for: every chunk costs a partial product written and read back by the reduction (4096 rays, fine level: 768 -> 256 chunks of the
@@ -1285,6 +1286,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
 #define VN_WGRAD_ROUNDS 1
 #endif
         plan(n_pe, chunk_pe, 512 * VN_WGRAD_ROUNDS, 2);
+        plan(n_sigma, chunk_sigma, 512 * VN_WGRAD_ROUNDS, 1);        // the sigma head's launch: 72 KiB of LDS, two workgroups per CU
         plan(n_single, chunk_single, 256 * VN_WGRAD_ROUNDS, 1);
         plan(n_thin, chunk_thin, 1024 * VN_WGRAD_ROUNDS, 1 + V);
     }
@@ -1297,7 +1299,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
     int n88 = 0, n82 = 0, n48 = 0, n41 = 0, n18 = 0, n14 = 0, ng = 0;
     size_t off = 0;
     auto init = [&](WgArgs &w, int cp) { w.P = (int64_t)P; w.chunk_pts = cp; w.partial = partial; };
-    init(c88, chunk_pts); init(c82, chunk_pe); init(c48, chunk_single); init(c41, chunk_thin); init(c18, chunk_single); init(c14, chunk_thin);
+    init(c88, chunk_pts); init(c82, chunk_pe); init(c48, chunk_single); init(c41, chunk_thin); init(c18, chunk_sigma); init(c14, chunk_thin);
     red.partial = partial;
     red.gmax = gmax;
 
@@ -1307,7 +1309,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
         d.A = A; d.lda = lda; d.m_load = m_load; d.B = B; d.ldb = ldb; d.k_load = k_load;
         d.wcol = nullptr; d.wcol_stride = 0; d.a_split16 = 0;
         d.part_off = off; d.part_stride = (size_t)Mp * Kp + Mp;
-        d.n_chunks = (&w == &c88) ? n_chunks : ((&w == &c48 || &w == &c18) ? n_single : (&w == &c82 ? n_pe : n_thin));
+        d.n_chunks = (&w == &c88) ? n_chunks : (&w == &c48 ? n_single : (&w == &c18 ? n_sigma : (&w == &c82 ? n_pe : n_thin)));
         const size_t o = off;
         off += (size_t)d.n_chunks * d.part_stride;
         return o;
@@ -1360,7 +1362,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
     }
     if (!fuse_sigma) {   // sigma head: A = column 4 of DQ[0]
         const size_t o = add(c18, n18, 32, 256, bwd + bl.dq[0] + 4, 8, 4, acts + al.h[D - 1], W, W);
-        group(n_single, o, 1, 32, 256, 1, W, G->g[P_SW], W, 0, G->g[P_SB]);
+        group(n_sigma, o, 1, 32, 256, 1, W, G->g[P_SW], W, 0, G->g[P_SB]);
     }
     {   // view layer, feature columns: A = sum over directions
         const size_t o = add(c48, n48, 128, 256, bwd + bl.dyvsum, WV, WV, acts + al.feat, W, W);
@@ -1427,7 +1429,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
         if ((rc = launch_bf16x3<8, 2, 1>(c82, n82, n_pe, st))) return rc;
     }
     if ((rc = launch_class<1, 1, 4>(c41, n41, n_thin, st))) return rc;
-    if ((rc = launch_class<1, 2, 1>(c18, n18, n_single, st))) return rc;
+    if ((rc = launch_class<1, 2, 1>(c18, n18, n_sigma, st))) return rc;
     if ((rc = launch_class<1, 1, 1>(c14, n14, n_thin, st))) return rc;
     return launch_wgrad_reduce(red, ng, st);
 }

@@ -67,12 +67,19 @@ class MLPParams(torch.nn.Module):
     def ordered_params(self):
         """The parameter tensors in the ABI's order, by attribute path: on a torch.nn.DataParallel REPLICA the weights are plain (non-leaf)
         tensor attributes -- the broadcast copies autograd reduces back onto the master -- and named_parameters() is empty there."""
-        out = []
+        replica = getattr(self, '_is_replica', False)
+        cached = None if replica else self.__dict__.get('_ordered_cache')
+        if cached is not None and all(owner._parameters.get(attr) is t for owner, attr, t in cached[0]):
+            return cached[1]                         # the same nn.Parameter objects as last time (optimizers change their .data, not them)
+        out, where = [], []
         for name in ops.param_order(self.topology):
-            t = self
+            owner, t = None, self
             for part in name.split('.'):
-                t = getattr(t, part)
+                owner, t = t, getattr(t, part)
             out.append(t)
+            where.append((owner, name.rsplit('.', 1)[1], t))
+        if not replica:
+            self.__dict__['_ordered_cache'] = (where, out)
         return out
 
 

@@ -1,6 +1,7 @@
 """Tensor-level wrappers over the C ABI.  PyTorch is used here for device memory and the current stream only;
 all arithmetic happens in libvipnerf_hip.so."""
 import ctypes as C
+import functools
 from typing import Dict, List, Optional
 
 import torch
@@ -39,17 +40,32 @@ def _tail(topology):
     return [(n, 16 + i) for i, n in enumerate(TAIL_PARAMS) if n_view > 0 or n.startswith('pts_output_linear')]
 
 
+@functools.lru_cache(maxsize=None)
+def _param_order_cached(topo5):
+    return tuple([f'pts_linears.{i}.{wb}' for i in range(topo5[0]) for wb in ('weight', 'bias')] + [n for n, _ in _tail(topo5)])
+
+
 def param_order(topology=8):
     """Parameter names of one MLP in the reference's construction order (VipNeRF01.py:472-491).  topology: netdepth or a topology tuple."""
-    return [f'pts_linears.{i}.{wb}' for i in range(_topo5(topology)[0]) for wb in ('weight', 'bias')] + [n for n, _ in _tail(topology)]
+    return list(_param_order_cached(_topo5(topology)))
 
 
 def param_slots(topology=8):
     """vipnerf_mlp_params slot of each entry of param_order(topology): trunk layer i -> 2i, 2i+1; the rest -> 16..23."""
-    return list(range(2 * _topo5(topology)[0])) + [s for _, s in _tail(topology)]
+    return list(_param_slots_cached(_topo5(topology)))
+
+
+@functools.lru_cache(maxsize=None)
+def _param_slots_cached(topo5):
+    return tuple(list(range(2 * topo5[0])) + [s for _, s in _tail(topo5)])
 
 
 def param_shapes(topology=DEFAULT_TOPOLOGY):
+    return list(_param_shapes_cached(_topo5(topology)))
+
+
+@functools.lru_cache(maxsize=None)
+def _param_shapes_cached(topology):
     depth, width, l_pts, l_view, _ = _topo5(topology)
     dp, dv = 3 + 6 * l_pts, 3 + 6 * l_view
     n_trunk, n_view = head_outputs(topology)
@@ -61,7 +77,7 @@ def param_shapes(topology=DEFAULT_TOPOLOGY):
             'pts_output_linear.weight': (n_trunk, width), 'pts_output_linear.bias': (n_trunk,),
             'feature_linear.weight': (width, width), 'feature_linear.bias': (width,),
             'views_output_linear.weight': (n_view, width // 2), 'views_output_linear.bias': (n_view,)}
-    return trunk + [tail[n] for n, _ in _tail(topology)]
+    return tuple(trunk + [tail[n] for n, _ in _tail(topology)])
 
 
 PARAM_ORDER = param_order(8)
@@ -108,6 +124,10 @@ def _p(t: Optional[torch.Tensor], dtype=torch.float32, name='tensor'):
 
 
 def f32c(t: torch.Tensor) -> torch.Tensor:
+    # (the common case costs one attribute test instead of three tensor calls: ~70 calls per training step, and at the reference's 1024
+    # rays per iteration the 16-bit step is bound by the host's enqueue time, tools/cpu_enqueue_time.py)
+    if t.dtype is torch.float32 and t.is_contiguous():
+        return t.detach() if t.requires_grad else t
     return t.detach().to(torch.float32).contiguous()
 
 

@@ -92,21 +92,24 @@ def stage_macs(n_sec):
     return {'mlp_fwd': per_point, 'mlp_dgrad': per_point, 'wgrad_256x256': 8 * 65536, 'wgrad_small': per_point - 8 * 65536}
 
 
-def model_configs(ndc=True):
+def model_configs(ndc=True, sparse_depth=False):
     mlp = lambda ns: {'num_samples': ns, 'netdepth': 8, 'netwidth': 256, 'points_positional_encoding_degree': 10,
                       'views_positional_encoding_degree': 4, 'use_view_dirs': True, 'view_dependent_rgb': True,
                       'predict_visibility': True}
+    losses = [{'name': 'MSEHip01', 'weight': 1}, {'name': 'VisibilityLossHip01', 'weight': 0.1},
+              {'name': 'VisibilityPriorLossHip01', 'iter_weights': {'0': 0, '30000': 0.001}}]
+    if sparse_depth:            # BASELINE configs[2]: the sparse-depth prior at the reference's weight (RealEstateTrainerTester01.py:249-259)
+        losses.append({'name': 'SparseDepthMSEHip01', 'weight': 0.1})
     return {'data_loader': {'ndc': ndc},
             'model': {'name': 'VipNeRFHip01', 'coarse_mlp': mlp(64), 'fine_mlp': mlp(128), 'chunk': 4096,
                       'netchunk': 16384, 'lindisp': False, 'perturb': True, 'raw_noise_std': 1.0, 'white_bkgd': False},
-            'losses': [{'name': 'MSEHip01', 'weight': 1}, {'name': 'VisibilityLossHip01', 'weight': 0.1},
-                       {'name': 'VisibilityPriorLossHip01', 'iter_weights': {'0': 0, '30000': 0.001}}],
-            'device': [0]}
+            'losses': losses, 'device': [0]}
 
 
-def make_scene(name, dev, seed=0):
+def make_scene(name, dev, seed=0, sparse_depth=False):
     """The product's on-device batch builder over a synthetic scene: `views` cameras on a 0.2-wide baseline looking down -z, random
-    images and random visibility-prior masks (there is no dataset in the container).  -> RayGeneratorHip"""
+    images and random visibility-prior masks (there is no dataset in the container).  sparse_depth: ~2 % of the pixels carry a
+    COLMAP-style sparse depth (uniform in [near, far]) and a reprojection error, -1 elsewhere.  -> RayGeneratorHip"""
     import numpy as np
     from data_preprocessors.RayGeneratorHip01 import RayGeneratorHip
     h, w, f, near, far, ndc, nf = SCENES[name]
@@ -116,14 +119,29 @@ def make_scene(name, dev, seed=0):
     g = torch.Generator(device=dev).manual_seed(seed)
     images = torch.rand(nf, h, w, 3, generator=g, device=dev)
     prior = (torch.rand(nf, nf - 1, h, w, generator=g, device=dev) < 0.5).float()
-    return RayGeneratorHip((h, w), K[None], poses, near, far, ndc, dev, images=images, visibility_prior=prior)
+    sd = se = None
+    if sparse_depth:
+        rs = np.random.RandomState(seed + 17)
+        has = rs.rand(nf, h, w) < 0.02
+        sd = np.where(has, rs.uniform(near, min(far, 20.0), (nf, h, w)), -1.0).astype(np.float32)
+        se = np.where(has, rs.uniform(0.1, 2.0, (nf, h, w)), -1.0).astype(np.float32)
+    return RayGeneratorHip((h, w), K[None], poses, near, far, ndc, dev, images=images, visibility_prior=prior, sparse_depths=sd, sparse_errors=se)
 
 
-def make_batch(gen, n_rays, seed, iter_num=40000):
-    """One resident training batch of n_rays random pixels of the scene (rays generated on the GPU by vipnerf_generate_rays)."""
+def make_batch(gen, n_rays, seed, iter_num=40000, n_sparse=0):
+    """One resident training batch of n_rays random pixels of the scene (rays generated on the GPU by vipnerf_generate_rays); n_sparse > 0
+    appends that many sparse-depth rows -- random pixels that carry a sparse depth -- behind them (the reference's 2048 + 2048 layout,
+    select_batch_indices, DataPreprocessor01.py:544-563)."""
+    import numpy as np
     g = torch.Generator().manual_seed(seed)
-    ids = torch.randint(0, gen.n * gen.h * gen.w, (n_rays,), generator=g)
-    return gen.get_next_batch(iter_num, indices=ids.numpy())
+    ids = torch.randint(0, gen.n * gen.h * gen.w, (n_rays,), generator=g).numpy()
+    if not n_sparse:
+        return gen.get_next_batch(iter_num, indices=ids)
+    pool = np.nonzero(gen.sparse_depths.cpu().numpy() > 0)[0] if not hasattr(gen, '_sd_pool') else gen._sd_pool
+    gen._sd_pool = pool
+    pick = pool[torch.randint(0, pool.shape[0], (n_sparse,), generator=g).numpy()]
+    return gen.get_next_batch(iter_num, indices=np.concatenate([ids, pick]),
+                              row_is_sparse=np.concatenate([np.zeros(n_rays, dtype=bool), np.ones(n_sparse, dtype=bool)]))
 
 
 def make_batch_oracle(vo, n_rays, seed, dev, iter_num=40000, scene='fern', nf=2):
@@ -285,6 +303,24 @@ def roofline_block(prec, prof, steps, rays, ms_per_step, sclk_mhz, n_sec=1, work
     return r
 
 
+def respawn_cmd(gpus, environ, argv):
+    """The launcher command `python bench.py --gpus N` turns itself into when N > 1 and no launcher set WORLD_SIZE, else None.
+    Raises SystemExit when a launcher's WORLD_SIZE contradicts --gpus."""
+    ws = environ.get('WORLD_SIZE')
+    if ws is not None:
+        if int(ws) != gpus:
+            raise SystemExit(f'--gpus {gpus} but WORLD_SIZE={ws}: bench.py reports n_gpus = the ranks that ran, launch it with matching numbers')
+        return None
+    if gpus <= 1:
+        return None
+    import socket
+    with socket.socket() as sk:                  # a free rendezvous port on the loopback interface
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={gpus}', '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -308,7 +344,21 @@ def main():
                     'update on the flat buffers, bit-identical, one launch); torch-fused: torch.optim.Adam(fused=True) (2 x ~100 us multi_tensor_apply)')
     ap.add_argument('--force-dist', action='store_true', help='take the multi-rank code path (process group, broadcast, all-reduce, '
                     'barriers) even with one rank')
+    ap.add_argument('--no-configs2', action='store_true', help='skip the configs[2] block (RealEstate geometry, 3 views, 2048 + 2048 sparse-depth rows)')
+    ap.add_argument('--no-sizes', action='store_true', help='skip the `sizes` block (the reference\'s shipped batch sizes through vipnerf_train_step)')
+    ap.add_argument('--step-api', default='module', choices=['module', 'onecall'], help='how `value` itself steps: module = the reference\'s module '
+                    'contract (model() -> compute_losses -> backward -> optimizer.step, Trainer01.py:61-107); onecall = vipnerf_train_step')
+    ap.add_argument('--check-ranks', action='store_true', help='spawn / join the ranks, count them with one all-reduce, print {"n_gpus", "ranks_reduced"} '
+                    'and exit without touching a GPU (the CPU test of the --gpus N launcher)')
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` with N > 1 and no launcher around it: become the launcher (one rank per GPU under torch.distributed.run).  A
+    # WORLD_SIZE that contradicts --gpus is an error: the line never reports an n_gpus other than the number of ranks that reduced.
+    cmd = respawn_cmd(args.gpus, os.environ, sys.argv[1:])
+    if cmd is not None:
+        import subprocess
+        sys.stdout.flush()
+        raise SystemExit(subprocess.call(cmd))
 
     # stdout carries ONE JSON line, from rank 0, and nothing else: fd 1 is pointed at stderr for the whole run (what a native library prints
     # there -- RCCL's version banner under the platform's NCCL_DEBUG=VERSION, once per rank, buffered until exit -- lands on stderr), and the
@@ -319,8 +369,24 @@ def main():
     from vipnerf_hip import dist as vdist
     from vipnerf_hip import ops
     rank, world, local = vdist.init_from_env(force=True if args.force_dist else None)
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    ranks_reduced = world
+    if vdist._active():                          # how many ranks really take part: one all-reduce of ones
+        t = torch.ones(1, device='cuda' if torch.distributed.get_backend() == 'nccl' else 'cpu')
+        torch.distributed.all_reduce(t)
+        ranks_reduced = int(t.item())
+        if ranks_reduced != world:
+            raise SystemExit(f'{ranks_reduced} ranks reduced but WORLD_SIZE={world}')
+    if args.check_ranks:
+        if rank == 0:
+            os.write(json_fd, (json.dumps({'n_gpus': world, 'ranks_reduced': ranks_reduced, 'check_ranks': True}) + '\n').encode())
+        if torch.distributed.is_initialized():
+            vdist.barrier()
+            torch.distributed.destroy_process_group()
+        return
+    from vipnerf_hip import _lib as vlib
+    vlib.require_product_build('bench.py')       # a timing-only experiment build (-DVN_EXP=n) would time "faster" unnoticed
     dev = torch.device(f'cuda:{local % torch.cuda.device_count()}')   # (one GPU per rank; the modulo only serves the
     torch.cuda.set_device(dev)                                        # 2-ranks-on-1-GPU gloo run of the N>1 code path)
     collectives = vdist._active()
@@ -350,27 +416,32 @@ def main():
     class Workload:
         """One scene + ray count: model, optimizer, resident batches, and the contract's timing procedure per arithmetic."""
 
-        def __init__(self, scene, n_rays, precision):
-            self.scene, self.rays = scene, n_rays
+        def __init__(self, scene, n_rays, precision, n_sparse=0, step_api='module'):
+            self.scene, self.rays, self.n_sparse, self.step_api = scene, n_rays, n_sparse, step_api
+            self.rows = n_rays + n_sparse             # rows of a batch: nerf rows + sparse-depth rows (configs[2]: 2048 + 2048)
             self.n_sec = SCENES[scene][6] - 1
-            self.cfg = model_configs(SCENES[scene][5])
+            self.cfg = model_configs(SCENES[scene][5], sparse_depth=n_sparse > 0)
             self.cfg['model']['hip_precision'] = precision
             torch.manual_seed(0)
             self.model = get_model(self.cfg, None).to(dev)
             vdist.broadcast_parameters(self.model)
             self.model.train()
             self.lossc = LossComputerHip(self.cfg)
-            if args.optimizer == 'flat':         # torch's single-tensor Adam expressions on ONE flat parameter / moment / gradient buffer
+            if args.optimizer == 'flat' or step_api == 'onecall':     # torch's single-tensor Adam expressions on ONE flat parameter / moment / gradient buffer
                 from vipnerf_hip.optim import FlatAdam                       # (bit-identical to torch.optim.Adam; one library launch per step)
                 self.opt = FlatAdam(self.model.parameters(), lr=5e-4, betas=(0.9, 0.999))
             else:
                 self.opt = torch.optim.Adam(self.model.parameters(), lr=5e-4, betas=(0.9, 0.999), fused=True)
             self.bucket = vdist.FlatGradBucket(self.model.parameters())
-            self.gen = make_scene(scene, dev)
-            self.n_batches = min(args.steps + args.warmup, 8 if n_rays > 8192 else 32)      # distinct resident batches, cycled
-            self.batches = [make_batch(self.gen, n_rays, 1000 + rank * 100003 + i) for i in range(self.n_batches)]
+            self.stepper = None
+            if step_api == 'onecall':                # ONE library call per iteration (vipnerf_train_step); ranks reduce the flat gradient between backward and Adam
+                from vipnerf_hip.step import FusedTrainStep
+                self.stepper = FusedTrainStep(self.model, self.cfg, self.opt, bucket_reduce=vdist.all_reduce_mean_flat if collectives else None)
+            self.gen = make_scene(scene, dev, sparse_depth=n_sparse > 0)
+            self.n_batches = min(args.steps + args.warmup, 8 if self.rows > 8192 else 32)      # distinct resident batches, cycled
+            self.batches = [make_batch(self.gen, n_rays, 1000 + rank * 100003 + i, n_sparse=n_sparse) for i in range(self.n_batches)]
             for b in self.batches:         # ray-sharded ranks draw the random numbers of their own rows of the global batch (Philox
-                b['rng_ray_base'] = rank * n_rays      # keyed by global ray index)
+                b['rng_ray_base'] = rank * self.rows   # keyed by global ray index)
             torch.cuda.synchronize()
             self.it = 40000
 
@@ -380,6 +451,9 @@ def main():
             b['common_data'] = {'poses': src['common_data']['poses']}
             b['iter_num'] = self.it                   # a new iteration number per step: new Philox offset (loss weights: > 30000)
             self.it += 1
+            if self.stepper is not None:
+                self.stepper(b)
+                return
             self.bucket.release()
             out = self.model(b)
             losses = self.lossc.compute_losses(b, out)
@@ -392,6 +466,8 @@ def main():
             allocator's multi-GB workspace blocks, Adam's state] W warm-up steps, then EXACTLY K steps between barrier +
             synchronize pairs; max over ranks."""
             self.model.configs['model']['hip_precision'] = prec
+            if self.stepper is not None:
+                self.stepper.release()               # the one-call path's persistent buffers of the previous arithmetic
             torch.cuda.empty_cache()                 # the workspace sizes differ between the arithmetics
             for i in range(INIT_STEPS):
                 self.step(i)
@@ -421,10 +497,12 @@ def main():
             return elapsed, prof, (cs.median() if cs is not None else None)
 
         def release(self):
-            self.model = self.opt = self.bucket = self.batches = self.gen = None
+            if self.stepper is not None:
+                self.stepper.release()
+            self.model = self.opt = self.bucket = self.batches = self.gen = self.stepper = None
             torch.cuda.empty_cache()
 
-    main_wl = Workload(args.workload, rays, args.precision)
+    main_wl = Workload(args.workload, rays, args.precision, step_api=args.step_api)
     model = main_wl.model
     elapsed, prof, sclk = main_wl.timed_run(args.precision)
     # N > 1 (the driver's scaling runs): `value` plus the configs[4] arithmetic only, unless --also is given explicitly
@@ -485,6 +563,43 @@ def main():
                      'roofline': roofline_block(p, pr, args.steps, args.configs4_rays, pms, sc, n_sec=wl4.n_sec, workload='dtu')}
         wl4.release()
 
+    # BASELINE configs[2]: RealEstate geometry, 3 input views (V = 2), visibility + sparse-depth priors: the reference's batch of 2048 nerf rows
+    # + 2048 sparse-depth rows (RealEstateTrainerTester01.py:249-259; SparseDepthMSE at weight 0.1, SparseDepthMSE01.py:58-63), every rank its own batch
+    c2 = None
+    if not args.no_configs2 and not (args.workload == 'realestate'):
+        if c4 is None:
+            main_wl.release()
+        wl2 = Workload('realestate', 2048, 'fp32', n_sparse=2048)
+        c2 = {'workload': 'BASELINE configs[2]: RealEstate geometry (NDC), 3 views (V = 2 secondary views), 2048 nerf rows + 2048 sparse-depth rows per '
+                          'iteration x (64+128) samples, coarse+fine 8x256 MLP, losses MSE 1 + Visibility 0.1 + VisibilityPrior 0.001 + SparseDepthMSE 0.1, Adam',
+              'rows_per_gpu': 4096, 'nerf_rows': 2048, 'sparse_depth_rows': 2048, 'n_gpus': world, 'mac_per_point': stage_macs(wl2.n_sec)['mlp_fwd']}
+        for p in (('fp32', 'bf16') if world == 1 else ('bf16',)):
+            el, pr, sc = wl2.timed_run(p)
+            pms = el / args.steps * 1e3
+            c2[p] = {'value': round(4096 * world * args.steps / el, 1), 'unit': 'rays/s', 'ms_per_step': round(pms, 3), 'dtype': ARITH[p][0],
+                     'roofline': roofline_block(p, pr, args.steps, 4096, pms, sc, n_sec=wl2.n_sec, workload='realestate')}
+        wl2.release()
+
+    # The batch sizes the reference's shipped configs train at (`num_rays` 1024, or 2048 + 2048 with sparse depth --
+    # NerfLlffTrainerTester01.py:251,261,617), through the module contract AND through the one-call step (vipnerf_train_step): at these
+    # sizes the 16-bit step is as long as the host needs to enqueue it through five Python -> ctypes calls
+    sizes = None
+    if not args.no_sizes and world == 1:
+        if c4 is None and c2 is None:
+            main_wl.release()
+        sizes = {'note': 'ms per training step (K timed steps, same procedure as `value`); module = VipNeRFHip.forward -> compute_losses -> backward -> '
+                         'FlatAdam.step (the reference trainer\'s sequence); onecall = vipnerf_train_step (the same kernels queued by ONE library call)'}
+        for label, scene, n, nsd in (('fern_1024', 'fern', 1024, 0), ('realestate_2048+2048sd', 'realestate', 2048, 2048)):
+            sizes[label] = {'rows': n + nsd, 'sparse_depth_rows': nsd, 'scene': scene}
+            for api in ('module', 'onecall'):
+                wls = Workload(scene, n, 'fp32', n_sparse=nsd, step_api=api)
+                for p in ('fp32', 'bf16'):
+                    el, pr, sc = wls.timed_run(p)
+                    kern = sum(v[1] for v in pr.values()) / args.steps
+                    sizes[label].setdefault(p, {})[api] = {'ms_per_step': round(el / args.steps * 1e3, 3), 'rays_per_sec': round((n + nsd) * args.steps / el, 1),
+                                                           'kernel_ms_per_step': round(kern, 3)}
+                wls.release()
+
     if rank != 0:
         vdist.barrier()                          # rank 0 finishes its report, then everybody leaves together
         torch.distributed.destroy_process_group()
@@ -521,6 +636,13 @@ def main():
         result['render'] = render
     if c4 is not None:
         result['configs4_dtu'] = c4
+    if c2 is not None:
+        result['configs2_realestate'] = c2
+    if sizes is not None:
+        result['sizes'] = sizes
+    result['ranks_reduced'] = ranks_reduced
+    result['step_api'] = args.step_api
+    result['build_info'] = vlib.build_info()
 
     if world == 1 and not args.no_cpu_baseline:
         from oracle import vipnerf_oracle as vo       # the checker, as the reported CPU baseline only

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VIPNERF_ABI_VERSION 3
+#define VIPNERF_ABI_VERSION 4
 
 #define VIPNERF_OK             0
 #define VIPNERF_E_ARG         (-1)   /* null / inconsistent argument */
@@ -233,6 +233,11 @@ typedef struct vipnerf_loss_out {
 
 /* ---- library / error ------------------------------------------------------------------------------------ */
 int32_t vipnerf_abi_version(void);
+/* How the loaded library was built: "libvipnerf_hip abi=4 arch=gfx950 VN_EXP=unset VN_...=..." -- every build-time switch of
+ * vip-nerf_amd/csrc/vipnerf_knobs.h with its value (static string).  vipnerf_build_is_experiment() != 0 for a TIMING-ONLY experiment build
+ * (-DVN_EXP=n: stores, encodings or MFMAs left out, results are garbage): bindings warn, benchmarks and smoke tests must refuse it. */
+const char *vipnerf_build_info(void);
+int32_t vipnerf_build_is_experiment(void);
 /* copies the calling thread's last error text (NUL terminated, truncated to n) */
 int32_t vipnerf_last_error(char *buf, size_t n);
 
@@ -306,6 +311,43 @@ int32_t vipnerf_scale_segments(int32_t n_segs, const vipnerf_scale_seg *segs, co
  * kernels contract (bit 0 the lerp, bit 1 v's update, bit 2 the parameter's); -1 = the combination tests/ found bit-identical on gfx950. */
 int32_t vipnerf_adam_step(int64_t n, float *param, float *exp_avg, float *exp_avg_sq, const float *grad, float lerp_w, float beta2, float sq_w,
                           float inv_sqrt_bc2, float eps, float neg_step, int32_t fma_mask, vipnerf_stream_t stream);
+
+/* ---- one training iteration in ONE call -------------------------------------------------------------------- */
+/* The reference trainer's per-iteration sequence (src/Trainer01.py:61-107: model(input_batch) -> LossComputer.compute_losses ->
+ * TotalLoss.backward() -> optimizer.step()) queued by a single library call: [secondary camera centres] -> pack both MLPs' weights ->
+ * vipnerf_render_forward -> vipnerf_losses_forward -> gradient seeds x loss weights (+ TotalLoss) -> vipnerf_render_backward -> [Adam].
+ * Exactly the kernels, launch shapes and order of the separate calls above (results are bit-identical to them; only TotalLoss, which the
+ * separate path sums with a library dot product, may differ in the last bit) -- what it removes is the host: ~45 launches enqueued from
+ * C++ in ~0.2 ms instead of five Python -> ctypes round trips plus autograd glue (1.6 ms), which bounds the step at the batch sizes the
+ * reference's shipped configs train at (1024, 2048 + 2048 rays: NerfLlffTrainerTester01.py:251,261,617).  Stream ordered, no
+ * synchronisation, no allocation: every buffer is the caller's and may be reused from call to call.
+ *
+ * cfg: train and save_acts must be set.  rays->rays_o2 may be produced by the call itself: give poses / pixel_id / n_frames and a
+ * rays_o2_out buffer (N, n_frames-1, 3) that rays->rays_o2 points to (vipnerf_secondary_origins), or leave poses NULL.
+ * loss_weights[k]: weight of lout->loss_values[k] in TotalLoss (LossComputer01.py:33-44; 0 for a loss that is not configured).
+ * The seed arrays of `lout` hold the WEIGHTED seeds afterwards.  grads_*: dLoss/dparam, overwritten (24 + 24 views of one flat buffer
+ * when an optimizer step or an all-reduce follows).  adam_n > 0: the update of vipnerf_adam_step on the flat buffers after the backward
+ * pass (a multi-GPU caller passes 0, all-reduces the flat gradient and calls vipnerf_adam_step itself). */
+typedef struct vipnerf_train_step_args {
+    const vipnerf_config *cfg;
+    const vipnerf_rays *rays;
+    const vipnerf_rng *rng;
+    const vipnerf_loss_in *loss_in;
+    float loss_weights[8];
+    const vipnerf_mlp_params *params_coarse, *params_fine;   /* fp32 master weights (fine: NULL if cfg->n_fine == 0) */
+    void *packed_coarse, *packed_fine;                       /* vipnerf_packed_weights_bytes_c(cfg) bytes each: rewritten every call */
+    const vipnerf_outputs *out;                              /* every output of vipnerf_render_forward */
+    const vipnerf_loss_out *lout;                            /* loss_values (8), seeds, scratch */
+    float *total_loss;                                       /* (1) device: sum_k loss_weights[k] * loss_values[k]; may be NULL */
+    void *acts, *bwd_ws;                                     /* vipnerf_query_workspace(cfg with save_acts) */
+    const vipnerf_mlp_grads *grads_coarse, *grads_fine;
+    /* optional: secondary camera centres (VipNeRF01.py:84-98) */
+    const float *poses; const void *pixel_id; int32_t pixel_id_is_int64; int32_t n_frames; float *rays_o2_out;
+    /* optional: Adam on flat buffers (see vipnerf_adam_step) */
+    int64_t adam_n; float *adam_param, *adam_exp_avg, *adam_exp_avg_sq; const float *adam_grad;
+    float lerp_w, beta2, sq_w, inv_sqrt_bc2, eps, neg_step; int32_t fma_mask; int32_t reserved;
+} vipnerf_train_step_args;
+int32_t vipnerf_train_step(const vipnerf_train_step_args *args, vipnerf_stream_t stream);
 
 /* ---- stage-wise entry points (used by the parity tests; each is also a valid standalone op) ------------- */
 /* VipNeRF.get_z_vals_coarse (VipNeRF01.py:173-203).  t_rand NULL = no jitter. */

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f'{n} declared in include/vipnerf_hip.h but not exported'
     assert set(names) == set(_lib.SYMBOLS), 'ctypes binding and header disagree'
-    assert lib.vipnerf_abi_version() == 3
+    assert lib.vipnerf_abi_version() == 4
     wide = 4 * (72 * 8192 + 68 * 8192 + 7424)      # the unsuffixed pair = precision FP32: [wide image][narrow image]
     assert lib.vipnerf_packed_weights_bytes() == lib.vipnerf_packed_weights_bytes_p(0) > wide
 
@@ -208,7 +208,8 @@ def test_philox_restatement_reproduces_random123_vectors():
 def test_flat_adam_is_torch_adam():
     """vipnerf_hip.optim.FlatAdam (one flat parameter / moment / gradient buffer, six elementwise kernels per step) takes, bit for bit, the
     steps of torch.optim.Adam's single-tensor path -- the reference's optimizer (Trainer01.py:505-515) -- with gradients that are views of
-    one buffer (the HIP backward's layout) as well as with separate gradient tensors and a missing one."""
+    one buffer (the HIP backward's layout) as well as with separate gradient tensors.  A parameter WITHOUT a gradient is where the two differ by
+    design (torch skips it, one flat update cannot): FlatAdam raises instead of diverging silently."""
     import torch
     from vipnerf_hip.optim import FlatAdam
     torch.manual_seed(0)
@@ -224,13 +225,13 @@ def test_flat_adam_is_torch_adam():
         for k, (a, b) in enumerate(zip(ref, mine)):
             g = flat[off:off + a.numel()].view(a.shape)
             off += a.numel()
-            if it == 3 and k == 1:
-                a.grad, b.grad = None, None                  # torch skips a parameter without a gradient; FlatAdam sees a zero gradient --
-                continue                                     # different by design (moments decay), so give both an explicit zero instead
             a.grad = g.clone()
             b.grad = g if it % 2 == 0 else g.clone()         # even steps: views of ONE buffer (adopted, no copy); odd steps: separate tensors
-        if it == 3:
-            ref[1].grad = torch.zeros_like(ref[1])
+        if it == 3:                                          # a missing gradient: refused, by name
+            keep, mine[1].grad = mine[1].grad, None
+            with pytest.raises(RuntimeError, match=r'parameter\(s\) \[1\] have no gradient'):
+                o_mine.step()
+            mine[1].grad = keep
         for grp in o_ref.param_groups:
             grp['lr'] = 5e-4 * 0.9 ** it
         o_mine.param_groups[0]['lr'] = 5e-4 * 0.9 ** it
@@ -239,6 +240,36 @@ def test_flat_adam_is_torch_adam():
         for a, b in zip(ref, mine):
             assert torch.equal(a.detach(), b.detach()), f'step {it}'
     assert all(p.data_ptr() == o_mine.flat[sum(q.numel() for q in mine[:i]):].data_ptr() for i, p in enumerate(mine))
+
+
+def test_flat_adam_refuses_checkpoints_it_cannot_represent():
+    """a torch.optim.Adam state in which the parameters sit at different step counts, or some have no state at all, cannot be
+    one flat update with one step count: load_state_dict says which parameters are the problem instead of raising KeyError."""
+    import torch
+    from vipnerf_hip.optim import FlatAdam
+    ps = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(2))]
+    ot = torch.optim.Adam(ps, lr=1e-3, foreach=False, fused=False)
+    for it in range(3):
+        ps[0].grad, ps[1].grad = torch.randn(4, 3), torch.randn(5)
+        ps[2].grad = torch.randn(2) if it < 2 else None     # the last step skips parameter 2
+        ot.step()
+    sd = ot.state_dict()
+    mine = FlatAdam([torch.nn.Parameter(p.detach().clone()) for p in ps], lr=1e-3)
+    with pytest.raises(ValueError, match=r'different step counts \(most at 3; parameter\(s\) \[2\] at \[2\]\)'):
+        mine.load_state_dict(sd)
+    sd2 = {'state': {k: v for k, v in sd['state'].items() if k != 1}, 'param_groups': sd['param_groups']}
+    with pytest.raises(ValueError, match=r'parameter\(s\) \[1\] have no \(or partial\) optimizer state'):
+        mine.load_state_dict(sd2)
+
+
+def test_secondary_origins_rejects_malformed_poses():
+    """the kernel strides by 16 floats per camera; anything but (nf, 4, 4) / (nf, 3, 4) poses is refused before any launch."""
+    import torch
+    from vipnerf_hip import _lib, ops
+    pid = torch.zeros(5, 3, dtype=torch.int32)
+    for bad in (torch.zeros(3, 16), torch.zeros(3, 4, 3), torch.zeros(4, 4)):
+        with pytest.raises(_lib.VipNerfHipError, match='poses must be'):
+            ops.secondary_origins(bad, pid, 3)
 
 
 def test_flat_adam_state_dict_is_torch_adams():

@@ -41,7 +41,7 @@ def step_grads(model, batch, rng, sl):
 
 def worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)
     from oracle import vipnerf_oracle as vo
     from vipnerf_hip import dist as vdist
     r, w, _ = vdist.init_from_env(backend='gloo')
@@ -100,6 +100,74 @@ def test_two_rank_sharded_step_matches_single_process():
     assert ref.size == 1191946
     err = np.linalg.norm(ret[0] - ref) / np.linalg.norm(ref)
     assert err < 1e-5, err
+
+
+def worker8(rank, world, port, ret):
+    """One of 8 ranks: the shard arithmetic of the two 8-GPU statements (65,536 / 131,072 rows, 2048 + 2048 rows, uneven classes with trim)
+    checked ON the rank with its own (rank, world) from the environment, then a real 8-way all-reduce of the oracle's gradients of this
+    rank's two rows of a 16-row config-2 style batch (nerf + sparse-depth rows) drawn with the global rows' random numbers."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from oracle import vipnerf_oracle as vo
+    from vipnerf_hip import dist as vdist
+    r, w, _ = vdist.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world)
+    # BASELINE configs[3] / configs[4]: contiguous equal shards, rank r owns rows [r N / 8, (r + 1) N / 8)
+    for n_rows in (65536, 131072):
+        sl = vdist.shard_rows(n_rows, r, w)
+        assert (sl.start, sl.stop) == (r * n_rows // w, (r + 1) * n_rows // w)
+        ids = vdist.shard_row_ids({'rays_o': torch.zeros(n_rows, 3), 'row_class_counts': (n_rows, 0)}, r, w)
+        assert ids.numel() == n_rows // w and int(ids[0]) == sl.start and int(ids[-1]) == sl.stop - 1
+    # configs[2]'s batch: 2048 nerf rows then 2048 sparse-depth rows -> 256 + 256 per rank
+    ids = vdist.shard_row_ids({'rays_o': torch.zeros(4096, 3), 'row_class_counts': (2048, 2048)}, r, w)
+    assert ids.tolist() == list(range(256 * r, 256 * (r + 1))) + list(range(2048 + 256 * r, 2048 + 256 * (r + 1)))
+    # uneven classes (the short last batch of an epoch, an odd number of sparse-depth pixels): trimmed per class, never an empty collective
+    ids = vdist.shard_row_ids({'rays_o': torch.zeros(1000 + 77, 3), 'row_class_counts': (1000, 77)}, r, w, uneven='trim')
+    assert ids.tolist() == list(range(125 * r, 125 * (r + 1))) + list(range(1000 + 9 * r, 1000 + 9 * (r + 1)))
+    everyone = [None] * w
+    dist.all_gather_object(everyone, ids.tolist())
+    flat = sorted(i for part in everyone for i in part)
+    assert flat == list(range(1000)) + list(range(1000, 1072)), 'trimmed shards must cover each class\'s first count - count % world rows once'
+    # the gradient of the global batch = the mean of the 8 rank gradients (one all-reduce of the flat bucket)
+    model = OracleModule(vo.init_params(5 + rank, scale=1.6))
+    vdist.broadcast_parameters(model, src=0)
+    bucket = vdist.FlatGradBucket(model.parameters())
+    batch = vo.synthetic_batch(8, 3, scene='realestate', nf=3, n_sparse=8)
+    rng = vo.synthetic_rng(16, 64, 128, 4)
+    shard = vdist.shard_batch(batch, r, w)
+    rows = shard['rng_ray_ids']
+    assert rows.tolist() == [r, 8 + r]
+    bucket.zero()
+    out = vo.render_rays(model.pdict(), shard, CFG, {k: v[rows] for k, v in rng.items()}, train=True, sec_views=True)
+    vo.total_loss(shard, out, LOSSES8, 40000)['TotalLoss'].backward()
+    bucket.all_reduce_mean()
+    ret[rank] = bucket.flat.clone().numpy()
+    dist.destroy_process_group()
+
+
+LOSSES8 = LOSSES + [{'name': 'SparseDepthMSE01', 'weight': 0.1}]
+
+
+def test_eight_rank_shards_and_reduction_match_single_process():
+    """SURVEY 8e at the world size the 8-GPU statements use: 8 gloo ranks, each with its row-class-aware shard (one nerf row + one
+    sparse-depth row) and the global rows' random numbers; the reduced gradient is the same on every rank and equals the single-process
+    gradient of the 16-row batch."""
+    from oracle import vipnerf_oracle as vo
+    from vipnerf_hip import dist as vdist
+    world, port = 8, 27500 + (os.getpid() % 2000)
+    ret = mp.Manager().dict()
+    mp.spawn(worker8, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(1, world):
+        assert np.array_equal(ret[0], ret[r]), f'rank {r} disagrees with rank 0 after the all-reduce'
+    model = OracleModule(vo.init_params(5, scale=1.6))
+    bucket = vdist.FlatGradBucket(model.parameters())
+    bucket.zero()
+    batch = vo.synthetic_batch(8, 3, scene='realestate', nf=3, n_sparse=8)
+    out = vo.render_rays(model.pdict(), batch, CFG, vo.synthetic_rng(16, 64, 128, 4), train=True, sec_views=True)
+    vo.total_loss(batch, out, LOSSES8, 40000)['TotalLoss'].backward()
+    ref = bucket.flat.numpy()
+    err = np.linalg.norm(ret[0] - ref) / np.linalg.norm(ref)
+    assert err < 2e-5, err
 
 
 def test_shard_rows_partition():

@@ -161,7 +161,7 @@ def test_frame_strips_equal_the_whole_frame(dev):
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
     model = model.to(dev).eval()
     whole = predict_frame(model, gen, frame=2, secondary=True)
-    for world in (2, 3, 5, res[0] + 8):                  # the last one: more ranks than rows, some strips are empty
+    for world in (2, 3, 5, 8, res[0] + 8):                  # the last one: more ranks than rows, some strips are empty
         strips = [frame_strip(res[0], r, world) for r in range(world)]
         assert strips[0][0] == 0 and strips[-1][1] == res[0] and all(a[1] == b[0] for a, b in zip(strips, strips[1:]))
         parts = [predict_frame(model, gen, frame=2, secondary=True, rows=rw) for rw in strips]

@@ -86,6 +86,55 @@ def test_two_hip_ranks_on_one_gpu_equal_one_process():
     assert err < 1e-5, f'averaged rank gradients vs single-process gradients: {err:.2e}'
 
 
+def test_eight_hip_ranks_on_one_gpu_equal_one_process():
+    """The same at the world size of BASELINE configs[3] / configs[4]: EIGHT ranks of the HIP module share the GPU (gloo carries the
+    all-reduce), 48 + 16 rows each; every rank's fine depths are the global rows' (Philox keyed by global row index), the reduced gradient
+    is identical on all ranks and equals the single-process one."""
+    assert torch.cuda.is_available()
+    world, port = 8, 30000 + (os.getpid() % 900)
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    from oracle import vipnerf_oracle as vo
+    import test_hip_parity as tp
+    dev = torch.device('cuda:0')
+    _, rb = _global_batch(dev)
+    model, cfg = tp.make_model(dev, True, vo.init_params(20, scale=1.6), sparse=True)
+    model.train()
+    out = _step(model, cfg, rb)
+    ref = torch.cat([p.grad.flatten() for p in model.parameters()]).cpu().numpy()
+    zf = out['z_vals_fine'].detach().cpu().numpy()
+    seen = []
+    for r in range(world):
+        assert np.array_equal(ret[0], ret[r]), f'rank {r} disagrees after the all-reduce'
+        assert ret[f'ids{r}'].shape[0] == (N_NERF + N_SD) // world
+        assert np.array_equal(ret[f'z{r}'], zf[ret[f'ids{r}']]), f'rank {r}: fine depths differ from the single-process run'
+        seen += ret[f'ids{r}'].tolist()
+    assert sorted(seen) == list(range(N_NERF + N_SD))
+    err = np.linalg.norm(ret[0] - ref) / np.linalg.norm(ref)
+    assert err < 1e-5, f'averaged rank gradients vs single-process gradients: {err:.2e}'
+
+
+def test_bench_self_spawns_eight_ranks_strong_scaling():
+    """`python bench.py --gpus 8` WITHOUT a launcher: bench.py becomes the launcher (torch.distributed.run, 8 ranks -- here all on this GPU
+    over gloo), runs the ray-sharded strong-scaling statement (8192 rays per iteration / 8) with the render leg as 8 strips of the 756-row
+    frame (756 / 8 is not an integer), and reports n_gpus = the ranks that took part in its collectives."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['VIPNERF_DIST_BACKEND'] = 'gloo'
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--scaling', 'strong', '--global-rays', '8192',
+           '--no-configs4', '--no-configs2', '--also', 'bf16']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 8 and res['ranks_reduced'] == 8 and res['scaling'] == 'strong'
+    assert res['config']['rays_per_gpu'] == 1024 and res['config']['global_rays'] == 8192 and res['value'] > 0 and res['value_bf16'] > 0
+    assert res['render']['fp32']['row_strips'] == 8 and res['render_ms_per_frame'] > 0
+    assert 'VN_EXP=unset' in res['build_info']
+
+
 def test_bench_two_ranks_on_one_gpu():
     """The driver's N > 1 launch line (torch.distributed.run, one rank per GPU) with two ranks sharing this GPU over gloo:
     bench.py must come back with ONE JSON line from rank 0 -- every rank has to take part in every collective of the

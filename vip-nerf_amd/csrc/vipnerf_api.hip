@@ -107,12 +107,8 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st);
 // "narrow" (16-point waves, two per SIMD; vipnerf_bf16n.h).  The packed buffer carries both images
 // ([fp32][wide][narrow]); VIPNERF_BF16_LAYOUT=wide|narrow picks the kernels (forward and data-gradient kernels
 // must agree: the ReLU masks are stored in fragment order).
-#ifndef VN_BF16_NARROW_DEFAULT
-#define VN_BF16_NARROW_DEFAULT 1
-#endif
-#ifndef VN_FP32_NARROW_DEFAULT
-#define VN_FP32_NARROW_DEFAULT 1
-#endif
+// build switch VN_BF16_NARROW_DEFAULT (default 1, vipnerf_knobs.h)
+// build switch VN_FP32_NARROW_DEFAULT (default 1, vipnerf_knobs.h)
 static bool bf16_narrow(int layout = VIPNERF_LAYOUT_DEFAULT, int precision = 0) {
     if (precision >= VIPNERF_PREC_FP16X3) return true;      // fp16 fragments exist in the narrow layout only
     if (precision == VIPNERF_PREC_FP32) {                   // exact fp32: wide = v_mfma_f32_32x32x2_f32, one wave per SIMD;
@@ -142,7 +138,10 @@ static int launch_mlp_fwd_any(MlpFwdArgs &a, int precision, hipStream_t st, int 
     if (precision == VIPNERF_PREC_FP32 && !bf16_narrow(layout, precision)) return launch_mlp_fwd(a, st);
     if (bf16_narrow(layout, precision)) {
         a.packed += packed_total_floats(precision);   // [fp32][wide] precede the narrow image
-        if (VN_PT2 && single_mfma_t16(precision)) return launch_mlp_fwd_pt2(a, precision, st);     // single-MFMA modes: two point tiles per wave
+        if (precision == VIPNERF_PREC_FP16 || precision == VIPNERF_PREC_BF16) {                       // single-MFMA modes: two point tiles per wave
+            if (!single_mfma_t16(precision)) { set_error("this library was built without T16 storage (VN_T16 / VN_BF16_H16 = 0): no single-MFMA 16-bit kernels"); return VIPNERF_E_UNSUPPORTED; }
+            return launch_mlp_fwd_pt2(a, precision, st);
+        }
         return launch_mlp_fwd_bf16n(a, precision, st);
     }
     a.packed += PK_TOTAL_F;                       // the wide split-bf16 image follows the fp32 image
@@ -190,6 +189,12 @@ using namespace vn;
 extern "C" {
 
 int32_t vipnerf_abi_version(void) { return VIPNERF_ABI_VERSION; }
+
+// How this library was built: every build-time switch with its value (vipnerf_knobs.h).  "VN_EXP=unset" for a product build.
+const char *vipnerf_build_info(void) {
+    return "libvipnerf_hip abi=" VN_KNOB_STR(VIPNERF_ABI_VERSION) " arch=gfx950 " VN_BUILD_INFO_KNOBS;
+}
+int32_t vipnerf_build_is_experiment(void) { return VN_EXP_VALUE >= 0 ? 1 : 0; }
 
 int32_t vipnerf_last_error(char *buf, size_t n) {
     if (!buf || n == 0) return VIPNERF_E_ARG;
@@ -491,6 +496,12 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
             if (rc) return rc;
         }
         // 3. weight gradients: dW = dY^T H as MFMA GEMMs over the point axis
+#if defined(VN_EXP)
+        {   // experiment builds only (tools/ablation_pt2.py): the data-gradient kernels alone, e.g. under rocm-smi
+            static const bool skip = [] { const char *e = getenv("VIPNERF_EXP_SKIP_WGRAD"); return e && *e == '1'; }();
+            if (skip) continue;
+        }
+#endif
         if ((rc = launch_wgrad(P, V, mb.acts, mb.al, bw, bl, G, cfg->precision, st,
                                (cfg->precision >= VIPNERF_PREC_FP16X3 && cfg->precision <= VIPNERF_PREC_FP16) ? (const unsigned *)(bw + bl.gmax) : nullptr))) return rc;
     }
@@ -538,9 +549,7 @@ int32_t vipnerf_scale_segments(int32_t n_segs, const vipnerf_scale_seg *segs, co
     return launch_scale_segments(a, (hipStream_t)stream);
 }
 
-#ifndef VN_ADAM_FMA_MASK
-#define VN_ADAM_FMA_MASK 7        // which of torch's three update expressions its kernels contract into an fma on gfx950 (tests/test_hip_fullsize.py)
-#endif
+// build switch VN_ADAM_FMA_MASK (default 7, vipnerf_knobs.h): which of torch's three update expressions its kernels contract into an fma on gfx950 (tests/test_hip_fullsize.py)
 int32_t vipnerf_adam_step(int64_t n, float *param, float *exp_avg, float *exp_avg_sq, const float *grad, float lerp_w, float beta2, float sq_w,
                           float inv_sqrt_bc2, float eps, float neg_step, int32_t fma_mask, vipnerf_stream_t stream) {
     clear_stale_hip_error();
@@ -551,6 +560,68 @@ int32_t vipnerf_adam_step(int64_t n, float *param, float *exp_avg, float *exp_av
     ProfScope ps("adam", (hipStream_t)stream);
     return launch_adam_step(n, param, exp_avg, exp_avg_sq, grad, lerp_w, beta2, sq_w, inv_sqrt_bc2, eps, neg_step,
                             fma_mask < 0 ? VN_ADAM_FMA_MASK : fma_mask, (hipStream_t)stream);
+}
+
+int32_t vipnerf_train_step(const vipnerf_train_step_args *t, vipnerf_stream_t stream) {
+    clear_stale_hip_error();
+    if (!t || !t->cfg || !t->rays || !t->loss_in || !t->params_coarse || !t->packed_coarse || !t->out || !t->lout || !t->acts || !t->bwd_ws ||
+        !t->grads_coarse) { set_error("train_step: NULL argument"); return VIPNERF_E_ARG; }
+    const vipnerf_config *cfg = t->cfg;
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (!cfg->train || !cfg->save_acts) { set_error("train_step: cfg.train and cfg.save_acts must be set"); return VIPNERF_E_ARG; }
+    const bool two = cfg->n_fine > 0;
+    if (two && (!t->params_fine || !t->packed_fine || !t->grads_fine)) { set_error("train_step: n_fine > 0 but a fine-level argument is NULL"); return VIPNERF_E_ARG; }
+    if (t->adam_n < 0 || (t->adam_n > 0 && (!t->adam_param || !t->adam_exp_avg || !t->adam_exp_avg_sq || !t->adam_grad))) {
+        set_error("train_step: bad Adam arguments"); return VIPNERF_E_ARG; }
+    const int64_t N = t->rays->n_rays;
+    // 0. the other cameras' centres of every row (VipNeRF01.py:84-98)
+    if (t->poses) {
+        if (!t->pixel_id || !t->rays_o2_out || t->rays_o2_out != t->rays->rays_o2) {
+            set_error("train_step: poses given, so pixel_id and rays_o2_out (== rays->rays_o2) are needed"); return VIPNERF_E_ARG; }
+        if ((rc = vipnerf_secondary_origins(N, t->n_frames, t->poses, t->pixel_id, t->pixel_id_is_int64, t->rays_o2_out, stream))) return rc;
+    }
+    // 1. this iteration's weights in fragment order
+    if ((rc = vipnerf_pack_weights_c(cfg, t->params_coarse, t->packed_coarse, stream))) return rc;
+    if (two && (rc = vipnerf_pack_weights_c(cfg, t->params_fine, t->packed_fine, stream))) return rc;
+    // 2. forward, 3. losses
+    if ((rc = vipnerf_render_forward(cfg, t->rays, t->rng, t->packed_coarse, t->packed_fine, t->out, t->acts, stream))) return rc;
+    if ((rc = vipnerf_losses_forward(cfg, N, t->loss_in, t->out, t->lout, stream))) return rc;
+    // 4. d TotalLoss / d outputs = weight of the loss x its unweighted seeds, in place (what autograd does with the five-call path's seeds:
+    //    the same segments in the same order through the same kernel), and TotalLoss itself
+    const int V = cfg->n_sec, Sc = cfg->n_coarse, Sf = cfg->n_coarse + cfg->n_fine;
+    ScaleArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    for (int k = 0; k < 8; ++k) sa.w[k] = t->loss_weights[k];
+    sa.loss_values = t->lout->loss_values; sa.total = t->total_loss;
+    vipnerf_out_grads og;
+    memset(&og, 0, sizeof(og));
+    for (int lv = 0; lv < (two ? 2 : 1); ++lv) {
+        const vipnerf_loss_level_seeds &sd = lv ? t->lout->fine : t->lout->coarse;
+        vipnerf_level_grads &g = lv ? og.fine : og.coarse;
+        const int S = lv ? Sf : Sc;
+        auto seg = [&](float *p, int64_t numel, int slot) {
+            vipnerf_scale_seg &e = sa.s[sa.n++];
+            e.in = p; e.out = p; e.numel = numel; e.slot = slot; e.reserved = 0;
+        };
+        seg(sd.rgb, N * 3, 0 + lv); g.rgb = sd.rgb;
+        seg(sd.visibility, N * S, 2 + lv); g.visibility = sd.visibility;
+        seg(sd.raw_vis, N * S, 2 + lv); g.raw_vis = sd.raw_vis;
+        if (V > 0) { seg(sd.vis2, N * V, 4 + lv); g.vis2 = sd.vis2; }
+        if (lv == (two ? 1 : 0) && sd.depth) { seg(sd.depth, N, 6); g.depth = sd.depth; }
+    }
+    if (N > 0) {
+        ProfScope ps("losses_bwd", (hipStream_t)stream);
+        if ((rc = launch_scale_segments(sa, (hipStream_t)stream))) return rc;
+    }
+    // 5. backward
+    if ((rc = vipnerf_render_backward(cfg, t->rays, t->packed_coarse, t->packed_fine, t->out, &og, t->acts, t->bwd_ws, t->grads_coarse,
+                                      t->grads_fine, stream))) return rc;
+    // 6. optimizer
+    if (t->adam_n > 0)
+        return vipnerf_adam_step(t->adam_n, t->adam_param, t->adam_exp_avg, t->adam_exp_avg_sq, t->adam_grad, t->lerp_w, t->beta2, t->sq_w,
+                                 t->inv_sqrt_bc2, t->eps, t->neg_step, t->fma_mask, stream);
+    return VIPNERF_OK;
 }
 
 int32_t vipnerf_generate_rays(const vipnerf_raygen *gen, int64_t n_rays, const vipnerf_ray_batch *out,

@@ -90,9 +90,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&out)[NS]) {
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 // fp16 fragments ("fp16x3", narrow layout only): same fragment shapes, 11-bit parts instead of 8-bit ones
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-#ifndef VN_SPLIT_FMA_MIX
-#define VN_SPLIT_FMA_MIX 1
-#endif
+// build switch VN_SPLIT_FMA_MIX (default 1, vipnerf_knobs.h)
 template <int NS>
 __device__ __forceinline__ void split8(const float (&x)[8], half8 (&out)[NS]) {
     if constexpr (NS == 2 && VN_SPLIT_FMA_MIX) {
@@ -185,7 +183,7 @@ __device__ __forceinline__ ACC mfma_split(const FR (&a)[NS], const FR (&b)[NS], 
 template <int NS, typename FR, int NPT>
 __device__ __forceinline__ AccN<NPT> mfma_split(const FR (&a)[NS], const BOp<FR, NPT> (&b)[NS], AccN<NPT> c) {
     static_assert(NS == 1, "point-tile pairs: single-MFMA modes");
-#if defined(VN_EXP) && VN_EXP == 43
+#if defined(VN_EXP) && (VN_EXP == 43 || VN_EXP == 44)
     return c;                                     // timing experiment only: no MFMAs (what the stores and the weight stream cost alone)
 #endif
 #pragma unroll
@@ -204,7 +202,13 @@ __device__ __forceinline__ AccN<NPT> mfma_split(const FR (&a)[NS], const BOp<FR,
 // leaves the other seven (including its SIMD partner) computing.
 // STAGGER (narrow layout, -DVN_DMA_MODE=2): every wave issues its 1/WAVES share, wave w behind MFMA group w * NG / WAVES of the
 // stage instead of all of them behind group 0 -- no single wave is ~60 cycles x CH behind the others at the stage barrier.
-template <int CH, int NBUF, int WAVES = 4, bool ROTATE = false, bool STAGGER = false>
+// ISSUERS (ROTATE only; build switch VN_DMA_ISSUERS for the narrow kernels): how many waves share a stage's DMA, CH / ISSUERS pieces each, all
+// behind the first MFMA group; the issuer set advances by ISSUERS waves per stage.  Waves w and w + 4 share a SIMD, so with ISSUERS <= 4 no
+// two issuers of a stage sit on one SIMD: each issuer's partner keeps that SIMD's MFMA pipe fed while it issues.  Why it matters: a
+// global_load_lds piece costs its wave ~60 cycles of issue time among MFMAs (MI355X_MICROARCH.md), so ONE wave issuing a 64-piece stage
+// is ~3800 cycles behind the other seven at the stage barrier -- as long as the stage's own MFMA work (4096 cycles per SIMD in the
+// two-point-tile 16-bit kernels: profiles/r04_ablation_pt2.md measured stage = skeleton + MFMA, not max).
+template <int CH, int NBUF, int WAVES = 4, bool ROTATE = false, bool STAGGER = false, int ISSUERS = 1>
 struct WStreamT {
     const float *g;
     float *buf;
@@ -217,15 +221,18 @@ struct WStreamT {
     bool counted;          // false: this wave's YOUNGER bounds do not hold (a wave whose points are out of range skips its predicated
                            // stores): it drains with vmcnt(0) instead
     static constexpr int SF = CH * CHUNK_F;
-    static constexpr int PER_WAVE = ROTATE ? CH : CH / WAVES;
+    static constexpr int PER_WAVE = ROTATE ? CH / ISSUERS : CH / WAVES;
     static_assert(CH % WAVES == 0 && (NBUF == 2 || PER_WAVE * (NBUF - 2) <= 63), "vmcnt is a 6-bit counter");
+    static_assert(ISSUERS >= 1 && WAVES % ISSUERS == 0 && CH % ISSUERS == 0 && (ISSUERS == 1 || ROTATE), "issuer sets tile the waves");
     __device__ __forceinline__ void fetch() {
 #if defined(VN_EXP) && (VN_EXP == 5 || VN_EXP == 18)
         if (n_left < -1000)                       // timing experiment only: no weight DMA
 #endif
         if (ROTATE) {
-            if (wave == turn) glds_run<PER_WAVE>(g + lane * 4, buf + fill * SF);
-            turn = turn + 1 == WAVES ? 0 : turn + 1;
+            const int rel = (wave - turn) & (WAVES - 1);          // (WAVES is a power of two in every ROTATE instantiation)
+            if (ISSUERS == 1) { if (wave == turn) glds_run<PER_WAVE>(g + lane * 4, buf + fill * SF); }
+            else if (rel < ISSUERS) glds_run<PER_WAVE>(g + (rel * PER_WAVE) * CHUNK_F + lane * 4, buf + fill * SF + (rel * PER_WAVE) * CHUNK_F);
+            turn = (turn + ISSUERS) & (WAVES - 1);
         } else {
             glds_run<PER_WAVE>(g + (wave * PER_WAVE) * CHUNK_F + lane * 4, buf + fill * SF + (wave * PER_WAVE) * CHUNK_F);
         }
@@ -270,12 +277,16 @@ struct WStreamT {
             // The data goes global -> LDS by DMA and LDS -> registers by ds_read: no cache to fence, a bare barrier
             // after the issuer's drain publishes it.
             __builtin_amdgcn_sched_barrier(0);
-            if (wave == cturn) {
+#if defined(VN_EXP) && VN_EXP == 46
+            if (false) {                          // timing experiment only (RACES): the issuer does not wait for its DMA -- what the vmcnt wait behind older stores costs
+#else
+            if (ISSUERS == 1 ? wave == cturn : ((wave - cturn) & (WAVES - 1)) < ISSUERS) {
+#endif
                 if (!counted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if (YOUNGER_FIRST != YOUNGER && first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER_FIRST) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
             }
-            cturn = cturn + 1 == WAVES ? 0 : cturn + 1;
+            cturn = (cturn + ISSUERS) & (WAVES - 1);
 #if !(defined(VN_EXP) && (VN_EXP == 16 || VN_EXP == 18))
             __builtin_amdgcn_s_barrier();         // (timing experiments 16 / 18 race without it)
 #endif
@@ -341,9 +352,7 @@ __device__ __forceinline__ void gemm_groups_bf(const float *base, ACC (&acc)[NT]
             const int lin = g * G + tt, ks = lin / NT, t = lin % NT;
             acc[t] = mfma_split<NS>(fr[g % NBUF][tt], B[ks0 + ks], acc[t]);
         }
-#ifndef VN_INTERLEAVE
-#define VN_INTERLEAVE 1
-#endif
+// build switch VN_INTERLEAVE (default 1, vipnerf_knobs.h)
 #pragma unroll
         for (int i = 0; i < (VN_INTERLEAVE ? R : 0); ++i) {    // MFMA, read, MFMA, read, ...: each read issues in the
             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);   // shadow of the MFMA before it (measured +3 % over
@@ -382,13 +391,9 @@ __device__ __forceinline__ void gemm_stage_bf(const float *stage, int lane, ACC 
     // single-MFMA modes (NS == 1): a cell is ONE 16-cycle MFMA, so groups of four tiles, two groups (128 cycles of this wave's
     // MFMAs, twice that with its SIMD partner's in between) ahead of the LDS latency; with two point tiles per wave a cell is two
     // MFMAs: groups of two tiles (the same 128 cycles, half the fragment registers)
-#ifndef VN_PT2_G
-#define VN_PT2_G 1
-#endif
+// build switch VN_PT2_G (default 1, vipnerf_knobs.h)
     constexpr int G = TIGHT ? 1 : (NS == 1 ? (FragTypeOf<BT>::npt == 2 ? VN_PT2_G : 4) : 2);
-#ifndef VN_PT2_D
-#define VN_PT2_D 2
-#endif
+// build switch VN_PT2_D (default 2, vipnerf_knobs.h)
     constexpr int D = FragTypeOf<BT>::npt == 2 ? VN_PT2_D : ((NS == 2 || TIGHT || NS == 1) ? 2 : 1);
     constexpr int NBUF = D + 1;
     constexpr int NG = NKS * NT / G;

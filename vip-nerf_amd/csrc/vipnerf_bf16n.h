@@ -38,8 +38,12 @@ __host__ __device__ constexpr int dir_feat16(int q, int e) {
 //   40: every activation / gradient / mask / encoding store (the kernels' compute floor)
 //   41: the fp32 "extras" only -- feature, view hidden, gamma(x), gamma(dir); dY_0, the fp32 dY_5 copy, dYv, sum dYv
 //   42: gamma(x) / gamma(dir) only
+//   43: (vipnerf_bf16.h) no MFMAs in the two-point-tile kernels: what their stores, weight stream and epilogues cost alone
+//   44: 40 and 43 together: neither stores nor MFMAs (weight stream, barriers, encodings, epilogues)
+//    0: nothing left out -- the product kernels, in a library that honours the experiment-only environment switch
+//       VIPNERF_EXP_SKIP_WGRAD (render_backward without its weight-gradient launches: the data-gradient kernels alone under rocm-smi)
 #if defined(VN_EXP)
-constexpr bool EXP_NO_STORES = VN_EXP == 40, EXP_NO_EXTRAS = VN_EXP == 40 || VN_EXP == 41, EXP_NO_PE = VN_EXP == 40 || VN_EXP == 41 || VN_EXP == 42;
+constexpr bool EXP_NO_STORES = VN_EXP == 40 || VN_EXP == 44, EXP_NO_EXTRAS = EXP_NO_STORES || VN_EXP == 41, EXP_NO_PE = EXP_NO_EXTRAS || VN_EXP == 42;
 #else
 constexpr bool EXP_NO_STORES = false, EXP_NO_EXTRAS = false, EXP_NO_PE = false;
 #endif
@@ -49,9 +53,7 @@ constexpr bool EXP_NO_STORES = false, EXP_NO_EXTRAS = false, EXP_NO_PE = false;
 // Needs three resident stages, hence half-size ones (32 KiB); WStreamSkew below.  Built, correct (all tests pass with
 // -DVN_SKEW=1) and measured on the same box: forward 4.63 vs 4.35 ms per step, data gradients 5.05 vs 5.01 -- what the
 // overlap gains, twice as many workgroup barriers take back.  Off by default.
-#ifndef VN_SKEW
-#define VN_SKEW 0
-#endif
+// build switch VN_SKEW (default 0, vipnerf_knobs.h)
 template <int NS>
 struct BnPlan {
     static constexpr int WAVES = 8;
@@ -170,10 +172,8 @@ struct WStreamSkew {
     __device__ __forceinline__ void prefetch() {}
     template <int g, int NG> __device__ __forceinline__ void prefetch_at() {}
 };
-#ifndef VN_DMA_MODE
-#define VN_DMA_MODE 1      // 1: one wave issues a whole stage (ROTATE); 2: every wave its share, staggered over the stage
-#endif
-template <typename PL, bool SK> struct StreamOf { typedef WStreamT<PL::CH, PL::NBUF, PL::WAVES, VN_DMA_MODE == 1, VN_DMA_MODE == 2> type; };
+// build switch VN_DMA_MODE (default 1, vipnerf_knobs.h): 1: one wave issues a whole stage (ROTATE); 2: every wave its share, staggered over the stage
+template <typename PL, bool SK> struct StreamOf { typedef WStreamT<PL::CH, PL::NBUF, PL::WAVES, VN_DMA_MODE == 1, VN_DMA_MODE == 2, VN_DMA_MODE == 1 ? VN_DMA_ISSUERS : 1> type; };
 template <typename PL> struct StreamOf<PL, true> { typedef WStreamSkew<PL::CH> type; };
 // every wave issues its eighth of a stage's DMA and drains it itself (plain vmcnt(0) + barrier): measured +1.8 % for the exact-fp32
 // EVAL kernel (0.887 -> 0.903 of the fp32 peak: no stores whose latency that vmcnt(0) would sit out, and no single wave 64 pieces
@@ -240,29 +240,21 @@ __device__ __forceinline__ floatx4 load_tile16(const float *base, int64_t p, int
 // step); it pays together with two things it makes possible: the stores leave from the next layer's stages
 // (VN_DEFER_STORES below) and the weight-gradient kernel hides its now cheap staging under its MFMAs:
 // 15.2 -> 14.3 ms per step.  (A first version with two separate [P][256]-half planes was clearly slower: 8-byte stores.)
-#ifndef VN_F16_PRESPLIT
-#define VN_F16_PRESPLIT 1
-#endif
+// build switch VN_F16_PRESPLIT (default 1, vipnerf_knobs.h)
 // When the stored form of a layer's output IS the next GEMM's B operand (the fp16 parts: FP16X3H, VN_F16_PRESPLIT), the
 // stores need not leave in a burst at the layer's epilogue: the operand registers stay live through the whole next layer,
 // so each of its weight stages sends a quarter of them -- in the shadow of the other wave's MFMAs.
-#ifndef VN_DEFER_STORES
-#define VN_DEFER_STORES 1
-#endif
+// build switch VN_DEFER_STORES (default 1, vipnerf_knobs.h)
 // VIPNERF_PREC_BF16 (single bf16 MFMA per product): 1 = the trunk activations h_1..h_8 and the gradients dY_1..dY_7, dY_feature are
 // stored as the bf16 operands the next GEMM consumes anyway (2 bytes per value, like VIPNERF_PREC_FP16; the 256x256 weight-gradient
 // GEMMs then run ONE bf16 MFMA per product on them); 0 = round 2's fp32 storage + bf16 hi/lo weight gradients.
-#ifndef VN_BF16_H16
-#define VN_BF16_H16 1
-#endif
+// build switch VN_BF16_H16 (default 1, vipnerf_knobs.h)
 // precisions whose 256-wide trunk activations / gradients are stored as 16-bit high parts only ([P][256] halves in the fp32 slot)
 // VN_T16 (default): in the single-MFMA modes EVERY operand of the weight-gradient GEMMs -- h_1..h_8, the feature, the view hidden per
 // direction, gamma(x), gamma(dir), dY_0..dY_7, dY_feature, dYv per direction, their sum, the head seeds -- is stored as 16-bit values in
 // the tile-blocked layout T16 (store_t16 below), which the weight-gradient kernels DMA straight into LDS and read with the hardware
 // transpose (vipnerf_wgrad16.hip); 0 = round 2's storage (row-major [P][256] halves for the 256x256 GEMMs, fp32 for everything else).
-#ifndef VN_T16
-#define VN_T16 1
-#endif
+// build switch VN_T16 (default 1, vipnerf_knobs.h)
 __host__ __device__ inline bool stores_t16(int precision) {
     return VN_T16 && (precision == VIPNERF_PREC_FP16 || precision == VIPNERF_PREC_FP16X3H || (precision == VIPNERF_PREC_BF16 && VN_BF16_H16));
 }
@@ -325,12 +317,8 @@ __device__ __forceinline__ void store_pair_f32(float *, int64_t, int, int, int, 
 // consistent order of an operand's features is a valid GEMM) and the chunk reduction undoes on the way into the nn.Linear layout.  Each
 // store instruction of the wave then writes two whole tiles = 1 KiB contiguous, and a layer costs 8 store instructions per wave and
 // point tile instead of 16.
-#ifndef VN_T16_X4
-#define VN_T16_X4 1
-#endif
-#ifndef VN_T16_NT
-#define VN_T16_NT 1       // nontemporal tile stores (the data is next read by another kernel, GBs later); 0: plain stores
-#endif
+// build switch VN_T16_X4 (default 1, vipnerf_knobs.h)
+// build switch VN_T16_NT (default 1, vipnerf_knobs.h): nontemporal tile stores (the data is next read by another kernel, GBs later); 0: plain stores
 constexpr int T16_SPK = VN_T16_X4 ? 1 : 2;       // store instructions store_t16 issues per k-step (what the counted stream waits assume)
 // stored feature index i (tile i >> 4, column i & 15) of a T16 array written from C/D fragments -> the feature it holds
 __host__ __device__ inline int t16_feature(int i) {
@@ -365,12 +353,8 @@ __device__ __forceinline__ void split_pair(const floatx4 &lo, const floatx4 &hi,
 // 0..3 behind MFMA group GA, those of the waves 4..7 behind group GB.  Wave w and wave w + 4 share a SIMD: while one of
 // them queues at the vector-memory port the other keeps the SIMD's MFMA pipe busy -- at the stage's end all eight queue
 // there together with nothing left to compute (and the first groups belong to the DMA burst).
-#ifndef VN_STORE_GROUP_A
-#define VN_STORE_GROUP_A 6
-#endif
-#ifndef VN_STORE_GROUP_B
-#define VN_STORE_GROUP_B 12
-#endif
+// build switch VN_STORE_GROUP_A (default 6, vipnerf_knobs.h)
+// build switch VN_STORE_GROUP_B (default 12, vipnerf_knobs.h)
 template <int H16, int NS, typename FR, int NSTEP = 2>
 struct DeferredStores {
     float *dst; int64_t p; int q, wave, s0;

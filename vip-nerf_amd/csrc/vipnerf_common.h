@@ -9,6 +9,7 @@
 // exactly the per-lane A-fragment order (vipnerf_pack.hip) and streamed L2 -> LDS in 32 KB stages shared by
 // the 4 waves of a workgroup.
 #pragma once
+#include "vipnerf_knobs.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -45,9 +46,7 @@ __host__ __device__ inline int feat_of(int r, int h) {
 // ----------------------------------------------------------------------------------------------- packed image
 // One chunk = the A operands of 4 consecutive k-steps for one 32-row tile: 64 lanes x float4 = 1 KiB.
 constexpr int CHUNK_F = 256;                    // floats per chunk
-#ifndef VN_STAGE_CHUNKS
-#define VN_STAGE_CHUNKS 64
-#endif
+// build switch VN_STAGE_CHUNKS (default 64, vipnerf_knobs.h)
 constexpr int STAGE_CHUNKS = VN_STAGE_CHUNKS;   // 64 KiB stages: half the workgroup barriers of 32 KiB ones
 constexpr int STAGE_F = CHUNK_F * STAGE_CHUNKS;
 constexpr int KGS8 = STAGE_CHUNKS / 8;          // kgroups per stage when a stage spans 8 row tiles

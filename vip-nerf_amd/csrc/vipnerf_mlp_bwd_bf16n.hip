@@ -5,12 +5,7 @@
 #include "vipnerf_mlp.h"
 #include "vipnerf_mlp_pt2.h"
 
-#ifndef VN_F32_DEFER
-#define VN_F32_DEFER 1
-#endif
-#ifndef VN_ROTATE_DMA
-#define VN_ROTATE_DMA true
-#endif
+// build switch VN_F32_DEFER (default 1, vipnerf_knobs.h)
 
 namespace vn {
 
@@ -270,8 +265,9 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
     if (precision == 0) return launch_one_bwd_n<2, false, VN_F32_DEFER ? 3 : 0, true>(a, grid, st);
     if (precision == 1) return launch_one_bwd_n<2>(a, grid, st);
     if (precision == 2) return launch_one_bwd_n<3>(a, grid, st);
-    if (precision == 6 && VN_PT2 && single_mfma_t16(precision)) return launch_mlp_bwd_pt2(a, precision, st);     // two point tiles per wave
-    if (precision == 6) return launch_one_bwd_n<1, false, VN_BF16_H16 ? (VN_T16 ? 4 : 1) : 0>(a, grid, st);
+    if ((precision == 5 || precision == 6) && !single_mfma_t16(precision)) {
+        set_error("this library was built without T16 storage (VN_T16 / VN_BF16_H16 = 0): no single-MFMA 16-bit kernels"); return VIPNERF_E_UNSUPPORTED; }
+    if (precision == 6) return launch_mlp_bwd_pt2(a, precision, st);     // two point tiles per wave (the 16-point NS = 1 form is retired)
     if (precision == 3 || precision == 4 || precision == 5) {
         // the level's largest seed first (one pass over 5+V floats per point)
         unsigned *slot = (unsigned *)(a.bwd + a.bl.gmax);
@@ -281,8 +277,7 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
         VN_HIP(hipGetLastError());
         MlpBwdArgs b = a;
         b.gmax = slot;
-        if (precision == 5 && VN_PT2 && single_mfma_t16(precision)) return launch_mlp_bwd_pt2(b, precision, st);
-        if (precision == 5) return launch_one_bwd_n<1, true, VN_T16 ? 4 : 1>(b, grid, st);
+        if (precision == 5) return launch_mlp_bwd_pt2(b, precision, st);
         return precision == 4 ? launch_one_bwd_n<2, true, VN_T16 ? 4 : 1>(b, grid, st) : launch_one_bwd_n<2, true, VN_F16_PRESPLIT ? 2 : 0>(b, grid, st);
     }
     set_error("mlp_bwd_bf16n: precision %d", precision);

@@ -6,12 +6,7 @@
 #include "vipnerf_bf16n.h"
 #include "vipnerf_mlp.h"
 
-#ifndef VN_F32_DEFER
-#define VN_F32_DEFER 1       // exact-fp32 narrow kernels: activation / gradient stores leave from the next GEMM's stages (H16 = 3)
-#endif
-#ifndef VN_ROTATE_DMA
-#define VN_ROTATE_DMA true
-#endif
+// build switch VN_F32_DEFER (default 1, vipnerf_knobs.h): exact-fp32 narrow kernels: activation / gradient stores leave from the next GEMM's stages (H16 = 3)
 
 namespace vn {
 
@@ -300,11 +295,7 @@ int launch_mlp_fwd_bf16n(const MlpFwdArgs &a, int precision, hipStream_t st) {
     if (precision == 2) return a.acts ? launch_one_n<true, 3>(a, grid, st) : launch_one_n<false, 3>(a, grid, st);
     if (precision == 3) return a.acts ? launch_one_n<true, 2, true, VN_F16_PRESPLIT ? 2 : 0>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);
     if (precision == 4) return a.acts ? launch_one_n<true, 2, true, VN_T16 ? 4 : 1>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);
-    constexpr int H5 = VN_T16 ? 4 : 1, H6 = VN_BF16_H16 ? (VN_T16 ? 4 : 1) : 0;
-    if (a.acts && stores_t16(precision) && a.src.P % 16) {
-        set_error("mlp_fwd: the 16-bit training kernels need a multiple of 16 points (got %lld)", (long long)a.src.P); return VIPNERF_E_UNSUPPORTED; }
-    if (precision == 5) return a.acts ? launch_one_n<true, 1, true, H5>(a, grid, st) : launch_one_n<false, 1, true>(a, grid, st);
-    if (precision == 6) return a.acts ? launch_one_n<true, 1, false, H6>(a, grid, st) : launch_one_n<false, 1>(a, grid, st);
+    // (VIPNERF_PREC_FP16 / BF16: the two-point-tile kernels of vipnerf_mlp_fwd_pt2.hip; their 16-point NS = 1 forms are retired)
     set_error("mlp_fwd_bf16n: precision %d", precision);
     return VIPNERF_E_ARG;
 }

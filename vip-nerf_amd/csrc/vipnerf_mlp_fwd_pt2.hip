@@ -9,7 +9,7 @@
 // arithmetics (2 or 3 operand parts) do not.
 //
 // Same algorithm, weight image (BnPlan<1>), stage order, T16 operand storage and ReLU masks as k_mlp_fwd_bf16n<., 1, ., 4> (the 16-point
-// kernel stays behind -DVN_PT2=0); lane (j, q) holds features 16 T + 4 q .. + 3 of C/D tile T for point j of EACH of its two point tiles.
+// kernel is retired); lane (j, q) holds features 16 T + 4 q .. + 3 of C/D tile T for point j of EACH of its two point tiles.
 #include "vipnerf_bf16n.h"
 #include "vipnerf_mlp.h"
 #include "vipnerf_mlp_pt2.h"
@@ -43,6 +43,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
         grp[pt] = (int64_t)blockIdx.x * (PT2_PTS_PER_WG / 16) + wave * 2 + pt;      // (valid is wave-uniform in training: P % 16 == 0)
     }
 
+    const int store_phase = pt2_store_phase(wave);
     typename StreamOf<PL, false>::type ws;
     ws.start(a.packed + PL::PK_FWD, PL::F_STAGES, stage_buf, lane, wave);
     ws.counted = !SAVE || (valid[0] && valid[1]);      // the counted waits assume the stores of BOTH point tiles
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
     // ReLU (trunk), ReLU bits, sigma head (layer 7), split into the next layer's B fragments, the feature's stores (layer 8)
     auto epilogue = [&](int layer) {
         const float lo = relu_bound<true>(layer < 8);
+        const int lo_i = layer < 8 ? 0 : (int)0x80000000;        // the same bound for relu_pt2's integer form (bf16 fragments)
         if (layer == 7) {
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) {
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
                 for (int u = 0; u < 2; ++u) {
                     const int t = 2 * s + u;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) x[u][r] = relu_lo<true>(x[u][r] * AU, lo);      // (+0 | positive | NaN: the bit masks)
+                    for (int r = 0; r < 4; ++r) x[u][r] = relu_pt2<F16>(x[u][r] * AU, lo, lo_i);      // (+0 | positive | NaN: the bit masks)
                     if (SAVE) { if (t < 8) mk0 = push_nibble(mk0, positive_nibble(x[u])); else mk1 = push_nibble(mk1, positive_nibble(x[u])); }
                 }
                 if (F16) { x[0] *= XS; x[1] *= XS; }
@@ -133,12 +135,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
 
     __syncthreads();                         // resident block visible
     // ---------------------------------------------------------------- layer 0: gamma(x) only (the first two k-steps of a stage whose other two are zero padding)
-#ifndef VN_PT2_TRAIN_KEEP
-#define VN_PT2_TRAIN_KEEP 0      // training: 0 = reloaded from the activation store at layer 5; 1 = kept in registers too (21 spilled registers instead of 7: forward 1.55 -> 1.67 ms per step, not kept)
-#endif
-#ifndef VN_PT2_EVAL_KEEP
-#define VN_PT2_EVAL_KEEP 1       // eval: 1 = gamma(x)'s fragments stay in 16 registers from layer 0 to layer 5 (measured: fp16 1023 -> 1080, bf16 1181 -> 1226 TFLOP/s); 0 = evaluated again at layer 5
-#endif
+    // (build switches VN_PT2_TRAIN_KEEP / VN_PT2_EVAL_KEEP, vipnerf_knobs.h: gamma(x)'s fragments kept in registers up to layer 5, or reloaded / evaluated again)
     BT bpe_keep[2][NS];
     {
         BT bpe[2][NS];
@@ -169,7 +166,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
             // younger than this stage's DMA: the mask stores of the previous epilogue (first stage), the deferred stores behind the stage before
             const float *st = jj == 0 ? ws.template wait<SAVE ? 2 : 0>() : ws.template wait<SAVE ? 2 * T16_SPK * S_PER_STAGE : 0>();
             if (SAVE) {
-                DeferredT16<FR, S_PER_STAGE> ds{a.acts + a.al.h[layer - 1], {grp[0], grp[1]}, {valid[0], valid[1]}, j, q, S_PER_STAGE * jj, bin};
+                DeferredT16<FR, S_PER_STAGE> ds{a.acts + a.al.h[layer - 1], {grp[0], grp[1]}, {valid[0], valid[1]}, j, q, S_PER_STAGE * jj, bin, store_phase};
                 gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws, ds);
             } else {
                 gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
@@ -196,6 +193,15 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
             gemm_stage_bf<16, 2, NS>(st, lane, acc, bpe, 0, ws);
         }
         epilogue(layer);
+#if defined(VN_EXP) && VN_EXP == 47
+        {   // timing experiment only: the layer epilogue's VALU work twice (profiles/r04_ablation_pt2.md: what a second copy costs)
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) asm volatile("" : "+v"(acc[t].v[pt]));
+            epilogue(layer);
+        }
+#endif
     }
 
 #pragma unroll
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
     {
         const float *st = ws.template wait<SAVE ? 2 * T16_SPK * S_PER_STAGE : 0>();      // behind the deferred stores of the feature layer's last stage
         if (SAVE) {          // the feature (= this GEMM's B operand) leaves from inside the stage like h_1..h_8
-            DeferredT16<FR, 8> ds{a.acts + a.al.feat, {grp[0], grp[1]}, {valid[0], valid[1]}, j, q, 0, bin};
+            DeferredT16<FR, 8> ds{a.acts + a.al.feat, {grp[0], grp[1]}, {valid[0], valid[1]}, j, q, 0, bin, store_phase};
             gemm_stage_bf<8, PL::KSV, NS>(st, lane, vb, bin, 0, ws, ds);
         } else {
             gemm_stage_bf<8, PL::KSV, NS>(st, lane, vb, bin, 0, ws);
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
 #pragma unroll
             for (int t = 0; t < 8; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) g[t][r] = relu_lo<true>(g[t][r] * AU, 0.f);
+                for (int r = 0; r < 4; ++r) g[t][r] = relu_pt2<F16>(g[t][r] * AU, 0.f, 0);
             if (SAVE && valid[pt] && !EXP_NO_EXTRAS) {
                 unsigned gm = 0u;
 #pragma unroll

@@ -3,9 +3,6 @@
 #include "vipnerf_bf16n.h"
 #include "vipnerf_mlp.h"
 
-#ifndef VN_PT2
-#define VN_PT2 1            // 0: the 16-point kernels (k_mlp_fwd_bf16n / k_mlp_bwd_bf16n with NS = 1, H16 = 4) for VIPNERF_PREC_FP16 / BF16
-#endif
 
 namespace vn {
 
@@ -22,20 +19,29 @@ struct DeferredT16 {
     bool valid[2];
     int j, q, s0;
     const BOp<FR, 2> (*bin)[1];
+    int phase = 0;                                       // VN_PT2_SKEW: this wave's slot among the NPH store phases (pt2_store_phase)
     // VN_PT2_SPREAD = 1: all of a stage's stores behind its last MFMA group; = NSTEP (4, the default): one k-step's stores (4 instructions)
     // behind every NG / NSTEP-th group, so that the stage's store instructions do not queue at the vector-memory port at once --
     // measured on one box (bf16, 4096 rays): forward 1.66 -> 1.60 ms, data gradients 1.73 -> 1.61; 8 parts (one point tile's k-step each):
     // forward 1.63, data gradients 2.15 (the extra scheduling barriers cost registers: spills)
-#ifndef VN_PT2_SPREAD
-#define VN_PT2_SPREAD 4
-#endif
-    // (VN_PT2_SPREAD = 2 NSTEP: one k-step of ONE point tile -- two instructions -- behind every NG / (2 NSTEP)-th group)
+    // (build switch VN_PT2_SPREAD, default 4, vipnerf_knobs.h; = 2 NSTEP: one k-step of ONE point tile -- two instructions -- behind every
+    // NG / (2 NSTEP)-th group)
     static constexpr int PARTS = VN_PT2_SPREAD > 1 ? (VN_PT2_SPREAD >= 2 * NSTEP ? 2 * NSTEP : NSTEP) : 1;
-    template <int g, int NG> static constexpr bool active() { return (g + 1) % (NG / PARTS) == 0; }
+    // VN_PT2_SKEW = n in {2, 4, 8}: the eight waves send a part's stores in n phases, 1 / n of the distance between two parts apart, SIMD
+    // partners (waves w, w + 4) half a distance apart: while one wave of a SIMD queues at the vector-memory port the other issues MFMAs,
+    // and the workgroup's stores reach the memory pipeline as a stream instead of 16 KiB bursts.  All of a stage's stores still leave
+    // inside the stage and behind its first group (the next stage's DMA): the counted waits of the stream hold as they are.
+    static constexpr int NPH = VN_PT2_SKEW > 1 ? VN_PT2_SKEW : 1;
+    template <int g, int NG> static constexpr bool active() {
+        static_assert((NG / PARTS) % NPH == 0, "store phases must divide the distance between two parts");
+        return (g + 1) % (NG / PARTS / NPH) == 0;
+    }
     template <int g, int NG>
     __device__ __forceinline__ void at() const {
         if (EXP_NO_STORES) return;
-        constexpr int part = (g + 1) / (NG / PARTS) - 1;
+        constexpr int idx = (g + 1) / (NG / PARTS / NPH) - 1;       // 0 .. PARTS NPH - 1
+        constexpr int part = idx / NPH, ph = idx % NPH;
+        if (NPH > 1 && ph != phase) return;
         constexpr bool split_pt = PARTS == 2 * NSTEP;
         constexpr int per = PARTS == 1 ? NSTEP : 1, sfirst = PARTS == 1 ? 0 : (split_pt ? part / 2 : part);
 #pragma unroll
@@ -48,6 +54,26 @@ struct DeferredT16 {
         }
     }
 };
+// the store phase of wave w (scalar): SIMD partners w, w + 4 are NPH / 2 phases apart, the last phase sits where the unskewed stores do
+__device__ __forceinline__ int pt2_store_phase(int wave) {
+    constexpr int NPH = VN_PT2_SKEW > 1 ? VN_PT2_SKEW : 1;
+    if (NPH == 1) return 0;
+    const int w = __builtin_amdgcn_readfirstlane(wave);
+    return (NPH - 1) - (((w >> 2) * (NPH / 2) + (w & (NPH / 2 - 1))) % NPH);
+}
+
+// ReLU with a runtime bound (0, or "none") as the two-point-tile kernels' epilogues evaluate it.  fp16 fragments: the compare-and-select
+// form of relu_lo<true> -- NaN (of either sign: the MFMA's inf - inf has its sign bit set) passes through, out-of-range inputs fail loudly
+// (tests/test_hip_bf16.py::test_fp16x3_range).  bf16 fragments (fp32's exponent range: nothing overflows on the way): a signed-integer
+// max of the bit pattern against lo_i = 0 / INT_MIN -- ONE instruction instead of v_cmp + two wait states + v_cndmask, the same result for
+// every number (negative and -0 -> +0, the rest unchanged) and for NaNs with a clear sign bit; a NaN with its sign bit set becomes +0.
+template <bool F16>
+__device__ __forceinline__ float relu_pt2(float x, float lo, int lo_i) {
+    if (F16) return relu_lo<true>(x, lo);
+    const int b = __float_as_int(x);
+    return __int_as_float(b > lo_i ? b : lo_i);
+}
+
 #endif
 
 int launch_mlp_fwd_pt2(const MlpFwdArgs &a, int precision, hipStream_t st);

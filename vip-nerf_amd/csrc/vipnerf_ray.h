@@ -53,7 +53,10 @@ int launch_losses(const LossArgs &a, hipStream_t st);
 struct ScaleArgs {
     vipnerf_scale_seg s[VIPNERF_MAX_SCALE_SEGS];
     int n;
-    const float *g;
+    const float *g;                   // (8) device: the factors by slot; NULL = w below
+    float w[8];                       // host-side factors (vipnerf_train_step: the loss weights)
+    const float *loss_values;         // with total: total[0] = sum_k w[k] * loss_values[k] (fixed order, block (0, 0) thread 0)
+    float *total;
 };
 int launch_scale_segments(const ScaleArgs &a, hipStream_t st);
 int launch_adam_step(int64_t n, float *p, float *m, float *v, const float *g, float lerp_w, float beta2, float sq_w, float inv_s, float eps,

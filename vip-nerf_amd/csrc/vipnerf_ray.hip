@@ -475,7 +475,12 @@ __global__ void k_loss_final(LossArgs a) {
 // out_k = g[slot_k] * in_k for all segments in one launch (blockIdx.y = segment): the fused losses' backward
 __global__ void k_scale_segments(ScaleArgs a) {
     const vipnerf_scale_seg sg = a.s[blockIdx.y];
-    const float w = a.g[sg.slot];
+    const float w = a.g ? a.g[sg.slot] : a.w[sg.slot];
+    if (a.total && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < 8; ++k) t = __fadd_rn(t, __fmul_rn(a.w[k], a.loss_values[k]));
+        a.total[0] = t;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < sg.numel; i += (int64_t)gridDim.x * blockDim.x) sg.out[i] = w * sg.in[i];
 }
 int launch_scale_segments(const ScaleArgs &a, hipStream_t st) {

@@ -29,12 +29,8 @@ __device__ __forceinline__ int wg_off(int f, int slot) {
     return row * 64 + ((slot ^ (((f & 3) ^ (f >> 4)) & 3)) << 4);
 }
 
-#ifndef VN_WGRAD_DMA
-#define VN_WGRAD_DMA 0          // exact-fp32 256 x 256 weight gradients: 1 = operand blocks HBM -> LDS by DMA instead of through registers -- built, correct, and measured SLOWER (9.10 vs 8.22 ms per step: DESIGN.md 5); off
-#endif
-#ifndef VN_WGRAD_W8
-#define VN_WGRAD_W8 2            // exact-fp32 256 x 256 weight gradients: 0 = the 4-wave k_wgrad<2,8,4>; 2 / 4 = k_wgrad256_w8 with 8 / 16 waves
-#endif
+// build switch VN_WGRAD_DMA (default 0, vipnerf_knobs.h): exact-fp32 256 x 256 weight gradients: 1 = operand blocks HBM -> LDS by DMA instead of through registers -- built, correct, and measured SLOWER (9.10 vs 8.22 ms per step: DESIGN.md 5); off
+// build switch VN_WGRAD_W8 (default 2, vipnerf_knobs.h): exact-fp32 256 x 256 weight gradients: 0 = the 4-wave k_wgrad<2,8,4>; 2 / 4 = k_wgrad256_w8 with 8 / 16 waves
 typedef _Float16 wg_half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wg_bf8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ floatx16 mfma16_32(wg_half8 a, wg_half8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
@@ -1170,9 +1166,7 @@ __device__ __forceinline__ void wgrad_split16_256_pipe(const WgArgs &a) {
         if (tid == 0) part[(size_t)Mp * Kp + Mp + 256] = (red[1024] + red[1025]) + (red[1026] + red[1027]);
     }
 }
-#ifndef VN_WGRAD_PIPE
-#define VN_WGRAD_PIPE 1
-#endif
+// build switch VN_WGRAD_PIPE (default 1, vipnerf_knobs.h)
 __global__ __launch_bounds__(256) void k_wgrad_split16_256(WgArgs a) {
     if ((int)blockIdx.x >= a.d[blockIdx.y].n_chunks) return;
 #if VN_WGRAD_PIPE
@@ -1262,9 +1256,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
                  const vipnerf_mlp_grads *G, int precision, hipStream_t st, const unsigned *gmax) {
     if (P == 0) return VIPNERF_OK;
     if (stores_t16(precision)) return launch_wgrad16(P, V, acts, al, bwd, bl, G, precision, st, gmax);
-#ifndef VN_WGRAD_ONE_ROUND
-#define VN_WGRAD_ONE_ROUND 1       // point chunks: one round of workgroups per launch where the level is large enough (like vipnerf_wgrad16.hip)
-#endif
+// build switch VN_WGRAD_ONE_ROUND (default 1, vipnerf_knobs.h): point chunks: one round of workgroups per launch where the level is large enough (like vipnerf_wgrad16.hip)
     int n_chunks = wgrad_chunks(P), n_pe = wgrad_chunks_split(P, WGRAD_SPLIT_PE), n_thin = wgrad_chunks_split(P, WGRAD_SPLIT_THIN),
         n_single = wgrad_chunks_split(P, WGRAD_SINGLE_SPLIT);
     int chunk_pts = wgrad_chunk_pts(P), chunk_pe = chunk_pts / WGRAD_SPLIT_PE, chunk_thin = chunk_pts / WGRAD_SPLIT_THIN,
@@ -1282,9 +1274,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
         };
         // (the 256 x 256 class keeps its chunks of <= 8192 points, three rounds at the fine level: in one round the exact-fp32 kernel measured
         // the same 8.22 ms per step and the HBM-bound split kernel of fp16x3 3.31 -> 3.61 -- one synchronised wave of workgroups streams worse)
-#ifndef VN_WGRAD_ROUNDS
-#define VN_WGRAD_ROUNDS 1
-#endif
+// build switch VN_WGRAD_ROUNDS (default 1, vipnerf_knobs.h)
         plan(n_pe, chunk_pe, 512 * VN_WGRAD_ROUNDS, 2);
         plan(n_sigma, chunk_sigma, 512 * VN_WGRAD_ROUNDS, 1);        // the sigma head's launch: 72 KiB of LDS, two workgroups per CU
         plan(n_single, chunk_single, 256 * VN_WGRAD_ROUNDS, 1);

@@ -54,17 +54,11 @@ __device__ __forceinline__ float dot_ones(const bf16x8 &v, float s) {
     s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, w.z), one, s, false);
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, w.w), one, s, false);
 }
-#ifndef VN_WG16_BIG_WM
-#define VN_WG16_BIG_WM 2           // wave grid and ring depth of the 256 x 256 kernel
-#define VN_WG16_BIG_WN 4
-#define VN_WG16_BIG_NB 4
-#endif
-#ifndef VN_WG16_HYBRID
-#define VN_WG16_HYBRID 1           // the 256 x 256 kernel streams half of each block by DMA, half through registers (k_wg16's HY)
-#endif
-#ifndef VN_WG16_SIGMA_FUSED
-#define VN_WG16_SIGMA_FUSED 1      // the sigma head rides in the feature layer's GEMM (XA below); 0: its own 16 x 256 launch
-#endif
+// build switch VN_WG16_BIG_WM (default 2, vipnerf_knobs.h): wave grid and ring depth of the 256 x 256 kernel
+// build switch VN_WG16_BIG_WN (default 4, vipnerf_knobs.h)
+// build switch VN_WG16_BIG_NB (default 4, vipnerf_knobs.h)
+// build switch VN_WG16_HYBRID (default 1, vipnerf_knobs.h): the 256 x 256 kernel streams half of each block by DMA, half through registers (k_wg16's HY)
+// build switch VN_WG16_SIGMA_FUSED (default 1, vipnerf_knobs.h): the sigma head rides in the feature layer's GEMM (XA below); 0: its own 16 x 256 launch
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // M = 16 MT, N = 16 NT; WM x WN waves, wave (wm, wn) owns MT / WM x NT / WN tiles; NB 32-point blocks resident in LDS.
@@ -186,9 +180,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wg16(WgArgs a) {
         // the ones trip b - 2 used), so at the start of a trip the wave has outstanding exactly that trip's operations, issued one trip
         // (two block times) earlier: ONE s_waitcnt vmcnt(0) per trip is exact, the register pieces go to LDS in front of the trip's only
         // barrier, and the compiler's own bookkeeping for the register loads (which cannot see the inline-asm DMA) costs nothing.
-#ifndef VN_WG16_DMA_PIECES
-#define VN_WG16_DMA_PIECES 2     // of a wave's 4 pieces per block (256 x 256 launch): measured 1.36 ms per 4096-ray step; see DESIGN.md 4.3a for 0 / 1 / 3
-#endif
+// build switch VN_WG16_DMA_PIECES (default 2, vipnerf_knobs.h): of a wave's 4 pieces per block (256 x 256 launch): measured 1.36 ms per 4096-ray step; see DESIGN.md 4.3a for 0 / 1 / 3
         constexpr int PWD = VN_WG16_DMA_PIECES < PW ? VN_WG16_DMA_PIECES : PW / 2, PWR = PW - PWD;     // pieces per wave and block by DMA / through registers
         static_assert(NB == 4 && PIECES % NW == 0 && PWR >= 1, "hybrid stream: four slots, every wave the same number of pieces");
         u4 r0[PWR], r1[PWR];
@@ -302,9 +294,7 @@ static int launch_all(const WgArgs &big, int nbig, int n_chunks, const WgArgs &p
         if ((rc = launch_wg16<BF, 16, 16, VN_WG16_BIG_WM, VN_WG16_BIG_WN, VN_WG16_HYBRID ? 4 : VN_WG16_BIG_NB, VN_WG16_SIGMA_FUSED != 0, VN_WG16_HYBRID != 0>(big, nbig, n_chunks, st))) return rc;
     }
     ProfScope ps("wgrad_small", st);
-#ifndef VN_WG16_THIN_HYBRID
-#define VN_WG16_THIN_HYBRID 0      // the 256 x 64 and 128 x 256 launches on the hybrid trip stream too (measured: DESIGN.md 4.3a)
-#endif
+// build switch VN_WG16_THIN_HYBRID (default 0, vipnerf_knobs.h): the 256 x 64 and 128 x 256 launches on the hybrid trip stream too (measured: DESIGN.md 4.3a)
     if ((rc = launch_wg16<BF, 16, 4, 4, 1, VN_WG16_THIN_HYBRID ? 4 : 3, false, VN_WG16_THIN_HYBRID != 0>(pe, npe, n_pe, st))) return rc;
     if ((rc = launch_wg16<BF, 8, 16, 2, 2, VN_WG16_THIN_HYBRID ? 4 : 3, false, VN_WG16_THIN_HYBRID != 0>(vf, nvf, n_single, st))) return rc;
     if ((rc = launch_wg16<BF, 1, 16, 1, 4, 4>(sg, nsg, n_single, st))) return rc;
@@ -327,9 +317,7 @@ int launch_wgrad16(size_t P, int V, const float *acts, const ActLayout &al, floa
         return Plan{(int)((P + pts - 1) / pts), pts};
     };
     const int cp0 = wgrad_chunk_pts(P);
-#ifndef VN_WG16_BIG_SLOTS
-#define VN_WG16_BIG_SLOTS 256      // workgroups of the 256 x 256 launch at a large level: one round of the chip (two / three rounds measured: DESIGN.md 4.3a)
-#endif
+// build switch VN_WG16_BIG_SLOTS (default 256, vipnerf_knobs.h): workgroups of the 256 x 256 launch at a large level: one round of the chip (two / three rounds measured: DESIGN.md 4.3a)
     const Plan pb = plan(wgrad_chunks(P), cp0, VN_WG16_BIG_SLOTS, 8);
     const Plan pp = plan(wgrad_chunks_split(P, WGRAD_SPLIT_PE), cp0 / WGRAD_SPLIT_PE, 512, 2);
     const Plan psg = plan(wgrad_chunks_split(P, WGRAD_SINGLE_SPLIT), cp0 / WGRAD_SINGLE_SPLIT, 512, 1);

@@ -63,7 +63,11 @@ class TrainerHip:
             batch = vdist.shard_batch(batch, self.rank, self.world, uneven='trim')
         self.bucket.release()                                # = optimizer.zero_grad(set_to_none=True)
         n = batch['rays_o'].shape[0]
-        sub = int(self.configs.get('sub_batch_size', n)) or n
+        if n == 0:
+            # a row class with fewer rows than ranks trims to nothing (the very short last batch of an epoch): every rank sees the same
+            # host-side counts, so every rank skips this iteration -- no backward, no collective, no optimizer step, identically everywhere
+            return {}
+        sub = max(1, int(self.configs.get('sub_batch_size', n)) or n)
         logged = {}
         for s in range(0, n, sub):
             sb = {k: (v[s:s + sub] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == n else v) for k, v in batch.items()}

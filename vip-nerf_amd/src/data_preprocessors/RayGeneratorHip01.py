@@ -205,8 +205,12 @@ class RayGeneratorHip:
         counts = None
         if not (isinstance(indices, torch.Tensor) and indices.is_cuda) and not (isinstance(row_is_sparse, torch.Tensor) and row_is_sparse.is_cuda):
             n_rows = int(len(indices))
-            n_sd = int(numpy.count_nonzero(numpy.asarray(row_is_sparse))) if row_is_sparse is not None else 0
-            counts = (n_rows - n_sd, n_sd)
+            flags = numpy.asarray(row_is_sparse, dtype=bool) if row_is_sparse is not None else numpy.zeros(0, dtype=bool)
+            n_sd = int(numpy.count_nonzero(flags))
+            # the counts promise "nerf rows first, then the sparse-depth rows" (what BatchIndexScheduler produces and dist.shard_row_ids'
+            # host path assumes); a caller's own interleaved rows get no counts and are sharded by the device masks instead
+            if n_sd == 0 or not flags[:n_rows - n_sd].any():
+                counts = (n_rows - n_sd, n_sd)
         indices = self._upload(indices, torch.int64)
         sparse_on = self.sparse_depths is not None
         if row_is_sparse is None and sparse_on:

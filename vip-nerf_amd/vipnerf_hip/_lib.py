@@ -8,7 +8,7 @@ import os
 
 VIPNERF_MAX_SEC = 3
 VIPNERF_N_PARAMS = 24
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VIPNERF_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libvipnerf_hip.so')
@@ -85,6 +85,20 @@ class ScaleSeg(C.Structure):
     _fields_ = [('in_', c_f), ('out', c_f), ('numel', C.c_int64), ('slot', C.c_int32), ('reserved', C.c_int32)]
 
 
+class TrainStepArgs(C.Structure):
+    _fields_ = [('cfg', C.POINTER(Config)), ('rays', C.POINTER(Rays)), ('rng', C.POINTER(Rng)), ('loss_in', C.POINTER(LossIn)),
+                ('loss_weights', C.c_float * 8),
+                ('params_coarse', C.POINTER(MlpParams)), ('params_fine', C.POINTER(MlpParams)),
+                ('packed_coarse', c_f), ('packed_fine', c_f),
+                ('out', C.POINTER(Outputs)), ('lout', C.POINTER(LossOut)), ('total_loss', c_f),
+                ('acts', c_f), ('bwd_ws', c_f),
+                ('grads_coarse', C.POINTER(MlpGrads)), ('grads_fine', C.POINTER(MlpGrads)),
+                ('poses', c_f), ('pixel_id', c_f), ('pixel_id_is_int64', C.c_int32), ('n_frames', C.c_int32), ('rays_o2_out', c_f),
+                ('adam_n', C.c_int64), ('adam_param', c_f), ('adam_exp_avg', c_f), ('adam_exp_avg_sq', c_f), ('adam_grad', c_f),
+                ('lerp_w', C.c_float), ('beta2', C.c_float), ('sq_w', C.c_float), ('inv_sqrt_bc2', C.c_float), ('eps', C.c_float),
+                ('neg_step', C.c_float), ('fma_mask', C.c_int32), ('reserved', C.c_int32)]
+
+
 class Camera(C.Structure):
     _fields_ = [('kinv', C.c_float * 9), ('pose', C.c_float * 12), ('ndc_cx', C.c_float), ('ndc_cy', C.c_float),
                 ('pad', C.c_float * 2)]
@@ -121,6 +135,8 @@ P = C.POINTER
 SYMBOLS = {
     'vipnerf_abi_version': (C.c_int32, []),
     'vipnerf_last_error': (C.c_int32, [C.c_char_p, C.c_size_t]),
+    'vipnerf_build_info': (C.c_char_p, []),
+    'vipnerf_build_is_experiment': (C.c_int32, []),
     'vipnerf_packed_weights_bytes': (C.c_size_t, []),
     'vipnerf_pack_weights': (C.c_int32, [P(MlpParams), c_f, c_f]),
     'vipnerf_packed_weights_bytes_p': (C.c_size_t, [C.c_int32]),
@@ -135,6 +151,7 @@ SYMBOLS = {
                                             P(MlpGrads), P(MlpGrads), c_f]),
     'vipnerf_losses_forward': (C.c_int32, [P(Config), C.c_int64, P(LossIn), P(Outputs), P(LossOut), c_f]),
     'vipnerf_scale_segments': (C.c_int32, [C.c_int32, P(ScaleSeg), c_f, c_f]),
+    'vipnerf_train_step': (C.c_int32, [P(TrainStepArgs), c_f]),
     'vipnerf_adam_step': (C.c_int32, [C.c_int64, c_f, c_f, c_f, c_f, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, c_f]),
     'vipnerf_coarse_depths': (C.c_int32, [C.c_int64, C.c_int32, C.c_int32, c_f, c_f, c_f, c_f, c_f]),
     'vipnerf_sample_fine': (C.c_int32, [C.c_int64, C.c_int32, C.c_int32, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
@@ -181,8 +198,25 @@ def load():
         fn.argtypes = args
     if lib.vipnerf_abi_version() != ABI_VERSION:
         raise VipNerfHipError(f'ABI mismatch: library {lib.vipnerf_abi_version()} != binding {ABI_VERSION}')
+    if lib.vipnerf_build_is_experiment():
+        import warnings
+        warnings.warn(f'{LIB_PATH} is a TIMING-ONLY experiment build ({lib.vipnerf_build_info().decode()}): its results are garbage; '
+                      f'bench.py and smoke() refuse it', RuntimeWarning, stacklevel=2)
     _lib = lib
     return lib
+
+
+def build_info() -> str:
+    """The loaded library's own account of how it was built (every VN_* switch with its value)."""
+    return load().vipnerf_build_info().decode()
+
+
+def require_product_build(who: str):
+    """Raise if the loaded library is a timing-only experiment build (-DVN_EXP=n)."""
+    lib = load()
+    if lib.vipnerf_build_is_experiment():
+        raise VipNerfHipError(f'{who}: {LIB_PATH} is a timing-only experiment build ({lib.vipnerf_build_info().decode()}); '
+                              f'rebuild with vip-nerf_amd/build.sh (no VN_EXP)')
 
 
 def check(rc, what):

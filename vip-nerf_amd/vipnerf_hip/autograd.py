@@ -45,10 +45,16 @@ class RenderFunction(torch.autograd.Function):
         if need_bwd:
             ab, bb = ops.query_workspace(cfg, n)
             state.recompute_chunk = _recompute_chunk(state, n, ab, bb, params[0].device)
+            if not state.recompute_chunk:
+                try:
+                    acts = torch.empty(ab // 4, dtype=torch.float32, device=params[0].device)
+                except torch.OutOfMemoryError:
+                    # the shortcut in _recompute_chunk (a workspace under a tenth of the device's memory is taken without asking the driver)
+                    # met a device that other tensors / processes have filled: ask now and fall back to the re-rendering backward
+                    torch.cuda.empty_cache()
+                    state.recompute_chunk = _recompute_chunk(state, n, ab, bb, params[0].device, ask_driver=True) or min(n, 256)
             if state.recompute_chunk:
                 cfg.save_acts = 0        # the activation store would not fit: backward re-renders chunk by chunk
-            else:
-                acts = torch.empty(ab // 4, dtype=torch.float32, device=params[0].device)
         if acts is None:
             ab, _ = ops.query_workspace(cfg, n)     # non-zero without save_acts for the generic-topology kernels only: their
             if ab:                                   # layers run through HBM
@@ -117,7 +123,7 @@ class RenderFunction(torch.autograd.Function):
 MAX_RECOMPUTE_CHUNK = 8192
 
 
-def _recompute_chunk(state: RenderState, n: int, acts_bytes: int, bwd_bytes: int, dev) -> int:
+def _recompute_chunk(state: RenderState, n: int, acts_bytes: int, bwd_bytes: int, dev, ask_driver: bool = False) -> int:
     """0 if the training workspace of an n-ray call (activation store + backward scratch, ~ 5 MB per ray) fits the
     budget, else the ray-chunk size for a re-rendering backward.  The reference bounds memory with its `chunk` host loop
     only in eval (every chunk's autograd graph stays alive in training, VipNeRF01.py:47-72); here a call that does not fit
@@ -127,7 +133,7 @@ def _recompute_chunk(state: RenderState, n: int, acts_bytes: int, bwd_bytes: int
     if limit is None:
         # a workspace under a tenth of the device's memory is taken without asking the driver (mem_get_info is a host <-> driver round
         # trip on every training forward); the allocator raises the usual out-of-memory error should even that not fit
-        if acts_bytes + bwd_bytes <= torch.cuda.get_device_properties(dev).total_memory // 10:
+        if not ask_driver and acts_bytes + bwd_bytes <= torch.cuda.get_device_properties(dev).total_memory // 10:
             return 0
         free, _ = torch.cuda.mem_get_info(dev)
         cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)

@@ -112,6 +112,13 @@ class FlatGradBucket:
         flat.mul_(1.0 / dist.get_world_size())
 
 
+def all_reduce_mean_flat(flat: torch.Tensor):
+    """sum over ranks, then 1 / world, of one flat gradient buffer in place (the FusedTrainStep hook); no-op in a single process."""
+    if _active():
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.mul_(1.0 / dist.get_world_size())
+
+
 def broadcast_parameters(module: torch.nn.Module, src: int = 0):
     if _active():
         for p in module.parameters():

@@ -131,6 +131,15 @@ def f32c(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(torch.float32).contiguous()
 
 
+def as_u8(t: torch.Tensor) -> torch.Tensor:
+    """A row mask as the uint8 array the ABI takes: a bool tensor is reinterpreted (same bytes, no launch), anything else converted."""
+    if t.dtype is torch.bool and t.is_contiguous():
+        return t.view(torch.uint8)
+    if t.dtype is torch.uint8 and t.is_contiguous():
+        return t
+    return t.to(torch.uint8).contiguous()
+
+
 def make_config(ndc, n_coarse, n_fine, n_sec, train, noise_std=0.0, lindisp=False, white_bkgd=False,
                 save_acts=False, perturb=None, precision=0, bf16_layout=0, topology=DEFAULT_TOPOLOGY) -> L.Config:
     c = L.Config()
@@ -417,6 +426,13 @@ def secondary_origins(poses: torch.Tensor, pixel_id: torch.Tensor, n_frames: int
     """VipNeRF.render_rays' index glue (VipNeRF01.py:84-98) in one launch: poses (nf,4,4), pixel_id (N,3) int32 / int64 ->
     rays_o2 (N, nf-1, 3), the centres of the other cameras of every row."""
     n = pixel_id.shape[0]
+    if poses.dim() != 3 or tuple(poses.shape[1:]) not in ((4, 4), (3, 4)):
+        raise L.VipNerfHipError(f'secondary_origins: poses must be (num_frames, 4, 4) or (num_frames, 3, 4) camera-to-world matrices, got {tuple(poses.shape)}')
+    if poses.device != pixel_id.device:
+        raise L.VipNerfHipError(f'secondary_origins: poses on {poses.device}, pixel_id on {pixel_id.device}')
+    if poses.shape[1] == 3:                     # the kernel strides by 16 floats per camera: a 3 x 4 pose gets its [0, 0, 0, 1] row
+        last = torch.tensor([0., 0., 0., 1.], dtype=poses.dtype, device=poses.device).expand(poses.shape[0], 1, 4)
+        poses = torch.cat([poses, last], dim=1)
     pc = f32c(poses)
     pid = pixel_id if pixel_id.dtype in (torch.int32, torch.int64) else pixel_id.to(torch.int64)
     pid = pid.contiguous()
@@ -458,11 +474,11 @@ def losses_forward(cfg: L.Config, n_rays, target_rgb, mask_nerf, prior, mask_spa
     li = L.LossIn()
     t = f32c(target_rgb); keep.append(t); li.target_rgb = _p(t)
     if mask_nerf is not None:
-        m = mask_nerf.to(torch.uint8).contiguous(); keep.append(m); li.mask_nerf = _p(m, torch.uint8)
+        m = as_u8(mask_nerf); keep.append(m); li.mask_nerf = _p(m, torch.uint8)
     if prior is not None:
         pr = f32c(prior); keep.append(pr); li.prior = _p(pr)
     if mask_sparse is not None:
-        m2 = mask_sparse.to(torch.uint8).contiguous(); keep.append(m2); li.mask_sparse = _p(m2, torch.uint8)
+        m2 = as_u8(mask_sparse); keep.append(m2); li.mask_sparse = _p(m2, torch.uint8)
         sd = f32c(sparse_depth.reshape(n_rays)); keep.append(sd); li.sparse_depth = _p(sd)
     out = L.Outputs()
     out.coarse = _level_struct(coarse)

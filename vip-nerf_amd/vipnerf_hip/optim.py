@@ -13,7 +13,9 @@ the flat buffer -- and one step is the six elementwise kernels of torch's own si
 of them contract into an fma, the division by a host scalar as a multiplication by its double-precision reciprocal rounded to float --
 found and pinned against torch on the device, tests/test_hip_fullsize.py::test_fused_adam_step_is_torch_adam; fused=False keeps the six)
 -- the same expressions, in the same order, as torch.optim.Adam(foreach=False, fused=False) (torch/optim/adam.py::_single_tensor_adam):
-elementwise, so bit-identical to it per parameter (tests/test_abi_cpu.py::test_flat_adam_is_torch_adam).  The reference's optimizer
+elementwise, so bit-identical to it per parameter (tests/test_abi_cpu.py::test_flat_adam_is_torch_adam) -- PROVIDED every parameter
+receives a gradient on every step, which the path's backward guarantees: torch skips a parameter whose .grad is None, one flat update cannot,
+so step() raises in that case instead of silently diverging, and load_state_dict() refuses a checkpoint with per-parameter step counts.  The reference's optimizer
 (torch.optim.Adam, Trainer01.py:505-515, betas (0.9, 0.999), no weight decay, no amsgrad) is this update.
 
 state_dict() / load_state_dict() speak torch.optim.Adam's format (per-parameter 'step' / 'exp_avg' / 'exp_avg_sq', one param group), so
@@ -66,13 +68,18 @@ class FlatAdam:
                 o += g.numel()
             if ok:
                 return torch.empty(0, dtype=self.flat.dtype, device=self.flat.device).set_(st, g0.storage_offset(), (self.flat.numel(),))
+        # torch.optim.Adam SKIPS a parameter whose .grad is None (its moments do not decay, it does not move); one flat update cannot skip a
+        # slice, and treating None as a zero gradient would keep the parameter moving on stale momentum (1.2e-2 apart from torch after two
+        # steps): every parameter must have received a gradient -- which the path's backward always provides (all 48 tensors, every call)
+        missing = [i for i, p in enumerate(self.params) if p.grad is None]
+        if missing:
+            raise RuntimeError(f'FlatAdam.step: parameter(s) {missing[:8]}{"..." if len(missing) > 8 else ""} have no gradient; unlike '
+                               f'torch.optim.Adam this optimizer cannot skip individual parameters (one flat update) -- give every parameter a gradient '
+                               f'(zeros to freeze its direction but decay its moments) or use torch.optim.Adam')
         o = 0
         for p in self.params:
             n = p.numel()
-            if p.grad is None:
-                self._grad[o:o + n].zero_()
-            else:
-                self._grad[o:o + n].copy_(p.grad.reshape(-1))
+            self._grad[o:o + n].copy_(p.grad.reshape(-1))
             o += n
         return self._grad
 
@@ -123,10 +130,18 @@ class FlatAdam:
             self.exp_avg.zero_()
             self.exp_avg_sq.zero_()
             return
-        steps = {int(float(state[i]['step'])) for i in ids}
-        if len(steps) != 1:
-            raise ValueError(f'FlatAdam.load_state_dict: parameters at different step counts {sorted(steps)}')
-        self.t, o = steps.pop(), 0
+        absent = [i for i in ids if i not in state or any(k not in state[i] for k in ('step', 'exp_avg', 'exp_avg_sq'))]
+        if absent:
+            raise ValueError(f'FlatAdam.load_state_dict: parameter(s) {absent[:8]} have no (or partial) optimizer state while others do -- a '
+                             f'torch.optim.Adam checkpoint in which some parameters never received a gradient; one flat update keeps ONE step count '
+                             f'for all parameters and cannot represent that')
+        steps = {i: int(float(state[i]['step'])) for i in ids}
+        if len(set(steps.values())) != 1:
+            common = max(set(steps.values()), key=list(steps.values()).count)
+            odd = [i for i, t in steps.items() if t != common]
+            raise ValueError(f'FlatAdam.load_state_dict: parameters at different step counts (most at {common}; parameter(s) {odd[:8]} at '
+                             f'{[steps[i] for i in odd[:8]]}): one flat update keeps ONE step count for all parameters')
+        self.t, o = next(iter(steps.values())), 0
         for i, p in zip(ids, self.params):
             n = p.numel()
             if tuple(state[i]['exp_avg'].shape) != tuple(p.shape):

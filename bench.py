@@ -278,7 +278,7 @@ def roofline_block(prec, prof, steps, rays, ms_per_step, sclk_mhz, n_sec=1, work
         r['frac_of_sustained'] = round(tf(dom) / F16_MFMA_SUSTAINED_TFLOPS, 4)
         r['frac_issued_of_sustained'] = round(min(tf(dom) * issued / F16_MFMA_SUSTAINED_TFLOPS, 9.99), 4)
         r['sustained_note'] = 'what a seconds-long dense 16-bit MFMA stream sustains on this part under its power limit (tools/' \
-                              'mfma_f16_sustained.hip, DESIGN.md 4.1b); informational -- frac is against the nominal 2.5 PFLOP/s'
+                              'mfma_f16_sustained.hip, docs/HISTORY.md 4.1b); informational -- frac is against the nominal 2.5 PFLOP/s'
     algo_bytes = ALGO_BYTES_PER_RAY * rays + ALGO_BYTES_FIXED
     r['algorithmic_bytes_per_step'] = algo_bytes
     tr, name = pmc_reference(prec, rays, workload)
@@ -461,7 +461,7 @@ def main():
             self.bucket.all_reduce_mean()
             self.opt.step()
 
-        def timed_run(self, prec):
+        def timed_run(self, prec, profile=True):
             """The contract's procedure for one arithmetic: [2 untimed initialisation passes: kernel loading, the caching
             allocator's multi-GB workspace blocks, Adam's state] W warm-up steps, then EXACTLY K steps between barrier +
             synchronize pairs; max over ranks."""
@@ -473,7 +473,7 @@ def main():
                 self.step(i)
             for i in range(args.warmup):
                 self.step(i)
-            ops.profile_enable(True)
+            ops.profile_enable(profile)
             ops.profile_read()
             barrier()
             t0 = time.perf_counter()
@@ -484,6 +484,8 @@ def main():
             prof = ops.profile_read()
             ops.profile_enable(False)
             elapsed = max_over_ranks(elapsed)
+            if not profile:
+                return elapsed, prof, None
             # shader clock under load: EVERY rank runs the extra steps (they contain the collective); rank 0 samples
             cs = ClockSampler(dev) if rank == 0 else None
             if cs is not None:
@@ -594,8 +596,9 @@ def main():
             for api in ('module', 'onecall'):
                 wls = Workload(scene, n, 'fp32', n_sparse=nsd, step_api=api)
                 for p in ('fp32', 'bf16'):
-                    el, pr, sc = wls.timed_run(p)
+                    el, pr, sc = wls.timed_run(p)            # (with the per-kernel HIP events on: the kernel time of a step)
                     kern = sum(v[1] for v in pr.values()) / args.steps
+                    el = wls.timed_run(p, profile=False)[0]  # the step time itself WITHOUT them: at 1.6 ms per step ~50 event records are 2 % of it
                     sizes[label].setdefault(p, {})[api] = {'ms_per_step': round(el / args.steps * 1e3, 3), 'rays_per_sec': round((n + nsd) * args.steps / el, 1),
                                                            'kernel_ms_per_step': round(kern, 3)}
                 wls.release()

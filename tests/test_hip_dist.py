@@ -293,8 +293,10 @@ def _rccl_worker(rank, world, port, ret):
     bucket = vdist.FlatGradBucket(model.parameters())
     opt = torch.optim.Adam(model.parameters(), lr=5e-4, fused=True)
     shard = vdist.shard_batch(rb, r, w)
+    poses = shard['common_data']['poses']
     for it in range(2):
         bucket.release()
+        shard['common_data'] = {'poses': poses}       # a fresh common_data per iteration, as the trainer's loader provides (forward unpacks it in place)
         _step(model, cfg, shard)
         flat = bucket.adopted()
         assert flat is not None and flat.numel() == 1191946

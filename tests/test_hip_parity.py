@@ -255,12 +255,11 @@ def test_eval_render_golden(dev):
             gk = f'out_{rk}_{lv}'
             if gk in g:
                 assert_close(out[f'{rk}_{lv}'], g[gk], what=f'{rk}_{lv}')
-    # free-running fine pass, measured against the claim (north_star: rendered RGB within 1e-4 of the reference): max error bounded by the
-    # reference's own fp32-vs-fp64 sensitivity (3e-4), and the share of rays beyond 1e-4 reported and bounded
+    # free-running fine pass against the claim (north_star: rendered RGB within 1e-4 of the reference): NO ray beyond 1e-4
     e = (plain['rgb_fine'].cpu() - torch.from_numpy(g['plain_rgb_fine'])).abs().max(dim=-1).values
     err, beyond = float(e.max()), float((e > 1e-4).float().mean())
     print(f'free-running rgb_fine: max abs err {err:.3e}, rays beyond 1e-4: {beyond:.4f}')
-    assert err <= 3e-4 and beyond <= 0.05, (err, beyond)
+    assert err <= 1e-5 and beyond == 0.0, (err, beyond)          # measured 3.6e-7 (48 rays); the statistics at 1024 rays: tests/test_hip_freerun.py
     assert_close(plain['rgb_coarse'], g['plain_rgb_coarse'], what='plain rgb_coarse')
 
 
@@ -344,8 +343,8 @@ def test_train_step_free_running_indices_golden(dev, tag):
     e = (out['rgb_fine'].cpu() - torch.from_numpy(g['out_rgb_fine'])).abs().max(dim=-1).values
     print(f'{tag}: free-running training indices equal to the reference\'s: {agree:.5f} of {ref_inds.numel()}; rgb_fine max abs err {float(e.max()):.3e}, '
           f'rays beyond 1e-4: {float((e > 1e-4).float().mean()):.4f}')
-    assert agree >= 0.999
-    assert float(e.max()) <= 3e-4 and float((e > 1e-4).float().mean()) <= 0.05
+    assert agree >= 0.9999
+    assert float(e.max()) <= 1e-4, 'north_star: rendered RGB within 1e-4 of the reference (measured 8.2e-5 / 2.4e-5: no ray beyond)'
 
 
 def test_gradients_arrive_in_one_flat_buffer(dev):

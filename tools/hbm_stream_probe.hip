@@ -1,4 +1,4 @@
-// HBM streaming plateaus of one MI355X for the access shapes the 16-bit training kernels use:
+// HBM streaming plateaus of one MI355X for the access shapes the 16-bit training kernels use (docs/HISTORY.md 4.1c):
 //   read   : 16 B per lane, wave-contiguous 1 KiB pieces (what k_wg16's DMA and every fragment load does)
 //   write  : 16 B per lane nontemporal stores, 1 KiB per wave instruction (store_t16)
 //   copy   : both at once (a kernel that reads as much as it writes)

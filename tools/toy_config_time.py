@@ -1,5 +1,5 @@
 """BASELINE configs[0] on the GPU: 64 x 64 toy scene, 2 views, 1024 rays per iteration, 4-layer x 64 coarse-only MLP -- the generic-
-topology kernels.  Training-step time and the CPU oracle's time for the same step.   python tools/toy_config_time.py"""
+topology kernels (docs/HISTORY.md 4.6).  Training-step time and the CPU oracle's time for the same step.   python tools/toy_config_time.py"""
 import os, sys, time, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'vip-nerf_amd'), os.path.join(ROOT, 'vip-nerf_amd', 'src')):

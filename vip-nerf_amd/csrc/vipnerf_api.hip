@@ -238,7 +238,18 @@ size_t vipnerf_packed_weights_bytes_c(const vipnerf_config *cfg) {
 int32_t vipnerf_pack_weights_c(const vipnerf_config *cfg, const vipnerf_mlp_params *params, void *packed, vipnerf_stream_t stream) {
     int rc = check_cfg(cfg);
     if (rc) return rc;
-    if (!cfg_generic(cfg)) return vipnerf_pack_weights_p(params, cfg->precision, packed, stream);
+    if (!cfg_generic(cfg)) {
+        // the images cfg's kernels read, and only those: the wide fp32 image at the buffer's head serves the wide exact-fp32 kernels and the
+        // unsuffixed stage API alone (vipnerf_pack_weights / _p fill it always) -- two launches per training step that nothing would read
+        const int prec = cfg->precision;
+        if (prec == VIPNERF_PREC_FP32 && !bf16_narrow(cfg->bf16_layout, prec)) return pack_wide_fp32(params, packed, stream);
+        if (!params || !packed) { set_error("pack_weights: NULL argument"); return VIPNERF_E_ARG; }
+        for (int i = 0; i < VIPNERF_N_PARAMS; ++i)
+            if (!params->p[i]) { set_error("pack_weights: parameter %d is NULL", i); return VIPNERF_E_ARG; }
+        if (prec != VIPNERF_PREC_FP32 && prec < VIPNERF_PREC_FP16X3 && !bf16_narrow(cfg->bf16_layout, prec))
+            return launch_pack_bf16(params, prec, (float *)packed + PK_TOTAL_F, (hipStream_t)stream);
+        return launch_pack_bf16n(params, prec, (float *)packed + packed_total_floats(prec), (hipStream_t)stream);
+    }
     if (!params || !packed) { set_error("pack_weights: NULL argument"); return VIPNERF_E_ARG; }
     return launch_gen_pack(cfg_topo(cfg), params, (float *)packed, (hipStream_t)stream);
 }

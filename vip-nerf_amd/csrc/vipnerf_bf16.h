@@ -22,7 +22,7 @@ struct BfPlan {
     // LDS stage ring; the DMA runs NBUF-1 stages ahead.  Measured: a deeper ring of smaller stages (4 x 32 KiB /
     // 5 x 24 KiB) is SLOWER than 2 x 64 / 2 x 48 KiB -- the stream's cost is the issue time of its
     // global_load_lds instructions (~60 cycles per 1 KiB piece with no second wave to feed the MFMA pipe), not its
-    // latency or fill rate, and the extra barriers cost more than the smoothing gains.
+    // latency or fill rate, and the extra barriers cost more than the smoothing gains (docs/HISTORY.md 4.1b).
     static constexpr int NBUF = 2;
     static constexpr int STAGE_F = CH * CHUNK_F;             // in float units
     static constexpr int ST_256 = 16 / KSB;                  // stages of a 256-deep contraction over 8 tiles

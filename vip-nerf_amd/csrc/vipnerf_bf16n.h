@@ -3,7 +3,7 @@
 //
 // Why: with one 32-point wave per SIMD (the wide layout) nothing feeds a SIMD's MFMA pipe while its only wave issues
 // the weight DMA (~60 cycles per 1 KiB piece), runs a layer's epilogue (bias/ReLU/mask/operand split: VALU) or sits
-// at the stage barrier -- 50-55 % of the bf16 kernels' time.  A 16-point wave needs half the
+// at the stage barrier -- 50-55 % of the bf16 kernels' time (docs/HISTORY.md 4.1b).  A 16-point wave needs half the
 // registers (64 accumulators + 64/96 operand registers), so two fit on a SIMD and cover for each other.  The price:
 // a 16x16x32 MFMA consumes a 1 KiB A fragment every 16 cycles instead of every 32, i.e. twice the LDS read traffic
 // (171 B/clk of 256 in bf16x3, 128 in bf16x6).
@@ -238,7 +238,7 @@ __device__ __forceinline__ floatx4 load_tile16(const float *base, int64_t p, int
 // replace (store_pair_split) -- and those GEMMs stage with a v_perm gather instead of ~320 VALU slots of conversion per
 // 32-point block (k_wgrad_split16_256).  On its own this measured within noise (weight gradients 5.37 vs 5.46 ms per
 // step); it pays together with two things it makes possible: the stores leave from the next layer's stages
-// (VN_DEFER_STORES below) and the weight-gradient kernel hides its now cheap staging under its MFMAs:
+// (VN_DEFER_STORES below) and the weight-gradient kernel hides its now cheap staging under its MFMAs (docs/HISTORY.md 4.3):
 // 15.2 -> 14.3 ms per step.  (A first version with two separate [P][256]-half planes was clearly slower: 8-byte stores.)
 // build switch VN_F16_PRESPLIT (default 1, vipnerf_knobs.h)
 // When the stored form of a layer's output IS the next GEMM's B operand (the fp16 parts: FP16X3H, VN_F16_PRESPLIT), the

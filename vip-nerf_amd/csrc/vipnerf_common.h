@@ -1,6 +1,6 @@
 // Internal definitions shared by the gfx950 kernels of libvipnerf_hip.so.
 //
-// Design in one paragraph (DESIGN.md has the long form): the MLP runs TRANSPOSED and REGISTER-CHAINED.  A
+// Design in one paragraph (DESIGN.md has the long form, docs/HISTORY.md the experiments): the MLP runs TRANSPOSED and REGISTER-CHAINED.  A
 // wave owns 32 points (MFMA columns); a layer is H_out^T[256 x 32] = W[256 x K] * H_in^T[K x 32] computed as
 // 8 row tiles of v_mfma_f32_32x32x2_f32.  In that orientation the C/D fragment of one layer (lane = point,
 // registers = output features) is, register for register, a valid B fragment of the next layer provided the

@@ -93,7 +93,7 @@
 #define VN_PT2_EVAL_KEEP 1       // eval: 1 = gamma(x)'s fragments stay in 16 registers from layer 0 to layer 5 (measured: fp16 1023 -> 1080, bf16 1181 -> 1226 TFLOP/s); 0 = evaluated again at layer 5
 #endif
 #ifndef VN_WGRAD_DMA
-#define VN_WGRAD_DMA 0           // exact-fp32 256 x 256 weight gradients: 1 = operand blocks HBM -> LDS by DMA instead of through registers -- built, correct, and measured SLOWER (9.10 vs 8.22 ms per step: DESIGN.md 5); off
+#define VN_WGRAD_DMA 0           // exact-fp32 256 x 256 weight gradients: 1 = operand blocks HBM -> LDS by DMA instead of through registers -- built, correct, and measured SLOWER (9.10 vs 8.22 ms per step: docs/HISTORY.md 5); off
 #endif
 #ifndef VN_WGRAD_W8
 #define VN_WGRAD_W8 2            // exact-fp32 256 x 256 weight gradients: 0 = the 4-wave k_wgrad<2,8,4>; 2 / 4 = k_wgrad256_w8 with 8 / 16 waves
@@ -123,13 +123,13 @@
 #define VN_WG16_SIGMA_FUSED 1    // the sigma head rides in the feature layer's GEMM (XA); 0: its own 16 x 256 launch
 #endif
 #ifndef VN_WG16_DMA_PIECES
-#define VN_WG16_DMA_PIECES 2     // of a wave's 4 pieces per block (256 x 256 launch): measured 1.36 ms per 4096-ray step; see DESIGN.md 4.3a for 0 / 1 / 3
+#define VN_WG16_DMA_PIECES 2     // of a wave's 4 pieces per block (256 x 256 launch): measured 1.36 ms per 4096-ray step; see docs/HISTORY.md 4.3a for 0 / 1 / 3
 #endif
 #ifndef VN_WG16_THIN_HYBRID
-#define VN_WG16_THIN_HYBRID 0    // the 256 x 64 and 128 x 256 launches on the hybrid trip stream too (measured: DESIGN.md 4.3a)
+#define VN_WG16_THIN_HYBRID 0    // the 256 x 64 and 128 x 256 launches on the hybrid trip stream too (measured: docs/HISTORY.md 4.3a)
 #endif
 #ifndef VN_WG16_BIG_SLOTS
-#define VN_WG16_BIG_SLOTS 256    // workgroups of the 256 x 256 launch at a large level: one round of the chip (two / three rounds measured: DESIGN.md 4.3a)
+#define VN_WG16_BIG_SLOTS 256    // workgroups of the 256 x 256 launch at a large level: one round of the chip (two / three rounds measured: docs/HISTORY.md 4.3a)
 #endif
 #ifndef VN_WG16_SKIP_FUSED
 #define VN_WG16_SKIP_FUSED 0     // 1: layer 5's gamma(x) columns ride in its 256 x 256 GEMM as four extra B tiles (dY_5 is read once)

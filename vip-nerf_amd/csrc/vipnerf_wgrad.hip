@@ -29,7 +29,7 @@ __device__ __forceinline__ int wg_off(int f, int slot) {
     return row * 64 + ((slot ^ (((f & 3) ^ (f >> 4)) & 3)) << 4);
 }
 
-// build switch VN_WGRAD_DMA (default 0, vipnerf_knobs.h): exact-fp32 256 x 256 weight gradients: 1 = operand blocks HBM -> LDS by DMA instead of through registers -- built, correct, and measured SLOWER (9.10 vs 8.22 ms per step: DESIGN.md 5); off
+// build switch VN_WGRAD_DMA (default 0, vipnerf_knobs.h): exact-fp32 256 x 256 weight gradients: 1 = operand blocks HBM -> LDS by DMA instead of through registers -- built, correct, and measured SLOWER (9.10 vs 8.22 ms per step: docs/HISTORY.md 5); off
 // build switch VN_WGRAD_W8 (default 2, vipnerf_knobs.h): exact-fp32 256 x 256 weight gradients: 0 = the 4-wave k_wgrad<2,8,4>; 2 / 4 = k_wgrad256_w8 with 8 / 16 waves
 typedef _Float16 wg_half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wg_bf8 __attribute__((ext_vector_type(8)));
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
 // second wave keeps a SIMD's MFMA pipe busy while the first one issues its vector-memory instructions.  Why it matters: a
 // global_load_dwordx4 holds a wave's issue port ~60 cycles whatever else is going on; the 4-wave kernel above issues 16 of them per
 // wave and 32-point block -- ~960 of the block's 16384 MFMA cycles with nothing else to issue on that SIMD, wherever in the block they
-// are placed (spreading them over the k-steps, or issuing the LDS stores at the block's start, measured no different: DESIGN.md 5).
+// are placed (spreading them over the k-steps, or issuing the LDS stores at the block's start, measured no different: docs/HISTORY.md 5).
 // Same tiles, same LDS layout, same partial-product format as k_wgrad<2, 8, 4>.
 template <int WK>       // waves along K: 2 -> 8 waves (2 x 4 tiles each), 4 -> 16 waves (2 x 2 tiles each)
 __global__ __launch_bounds__(256 * WK) void k_wgrad256_w8(WgArgs a) {

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wg16(WgArgs a) {
         // the ones trip b - 2 used), so at the start of a trip the wave has outstanding exactly that trip's operations, issued one trip
         // (two block times) earlier: ONE s_waitcnt vmcnt(0) per trip is exact, the register pieces go to LDS in front of the trip's only
         // barrier, and the compiler's own bookkeeping for the register loads (which cannot see the inline-asm DMA) costs nothing.
-// build switch VN_WG16_DMA_PIECES (default 2, vipnerf_knobs.h): of a wave's 4 pieces per block (256 x 256 launch): measured 1.36 ms per 4096-ray step; see DESIGN.md 4.3a for 0 / 1 / 3
+// build switch VN_WG16_DMA_PIECES (default 2, vipnerf_knobs.h): of a wave's 4 pieces per block (256 x 256 launch): measured 1.36 ms per 4096-ray step; see docs/HISTORY.md 4.3a for 0 / 1 / 3
         constexpr int PWD = VN_WG16_DMA_PIECES < PW ? VN_WG16_DMA_PIECES : PW / 2, PWR = PW - PWD;     // pieces per wave and block by DMA / through registers
         static_assert(NB == 4 && PIECES % NW == 0 && PWR >= 1, "hybrid stream: four slots, every wave the same number of pieces");
         u4 r0[PWR], r1[PWR];
@@ -294,7 +294,7 @@ static int launch_all(const WgArgs &big, int nbig, int n_chunks, const WgArgs &p
         if ((rc = launch_wg16<BF, 16, 16, VN_WG16_BIG_WM, VN_WG16_BIG_WN, VN_WG16_HYBRID ? 4 : VN_WG16_BIG_NB, VN_WG16_SIGMA_FUSED != 0, VN_WG16_HYBRID != 0>(big, nbig, n_chunks, st))) return rc;
     }
     ProfScope ps("wgrad_small", st);
-// build switch VN_WG16_THIN_HYBRID (default 0, vipnerf_knobs.h): the 256 x 64 and 128 x 256 launches on the hybrid trip stream too (measured: DESIGN.md 4.3a)
+// build switch VN_WG16_THIN_HYBRID (default 0, vipnerf_knobs.h): the 256 x 64 and 128 x 256 launches on the hybrid trip stream too (measured: docs/HISTORY.md 4.3a)
     if ((rc = launch_wg16<BF, 16, 4, 4, 1, VN_WG16_THIN_HYBRID ? 4 : 3, false, VN_WG16_THIN_HYBRID != 0>(pe, npe, n_pe, st))) return rc;
     if ((rc = launch_wg16<BF, 8, 16, 2, 2, VN_WG16_THIN_HYBRID ? 4 : 3, false, VN_WG16_THIN_HYBRID != 0>(vf, nvf, n_single, st))) return rc;
     if ((rc = launch_wg16<BF, 1, 16, 1, 4, 4>(sg, nsg, n_single, st))) return rc;
@@ -317,7 +317,7 @@ int launch_wgrad16(size_t P, int V, const float *acts, const ActLayout &al, floa
         return Plan{(int)((P + pts - 1) / pts), pts};
     };
     const int cp0 = wgrad_chunk_pts(P);
-// build switch VN_WG16_BIG_SLOTS (default 256, vipnerf_knobs.h): workgroups of the 256 x 256 launch at a large level: one round of the chip (two / three rounds measured: DESIGN.md 4.3a)
+// build switch VN_WG16_BIG_SLOTS (default 256, vipnerf_knobs.h): workgroups of the 256 x 256 launch at a large level: one round of the chip (two / three rounds measured: docs/HISTORY.md 4.3a)
     const Plan pb = plan(wgrad_chunks(P), cp0, VN_WG16_BIG_SLOTS, 8);
     const Plan pp = plan(wgrad_chunks_split(P, WGRAD_SPLIT_PE), cp0 / WGRAD_SPLIT_PE, 512, 2);
     const Plan psg = plan(wgrad_chunks_split(P, WGRAD_SINGLE_SPLIT), cp0 / WGRAD_SINGLE_SPLIT, 512, 1);

@@ -112,9 +112,12 @@ class VipNeRFHip(torch.nn.Module):
     # ---- reference contract ------------------------------------------------------------------------------
     def forward(self, input_batch: dict, retraw: bool = False, sec_views_vis: bool = False):
         if 'common_data' in input_batch.keys():
-            for key in input_batch['common_data'].keys():           # same in-place unpacking as the reference
-                if isinstance(input_batch['common_data'][key], torch.Tensor):
-                    input_batch['common_data'][key] = input_batch['common_data'][key][0]
+            for key in input_batch['common_data'].keys():           # same in-place unpacking as the reference (VipNeRF01.py:35-39) ...
+                v = input_batch['common_data'][key]
+                if isinstance(v, torch.Tensor) and not (key == 'poses' and v.dim() == 3):
+                    # ... except that poses already unpacked to (num_frames, 4, 4) -- the same dict handed to forward() a second time --
+                    # stay as they are: the reference would take poses[0] again and index cameras out of a single matrix
+                    input_batch['common_data'][key] = v[0]
         return self.render_rays(input_batch, retraw or self.training, sec_views_vis or self.training)
 
     def _rng_key(self, input_dict: dict, dev: torch.device):

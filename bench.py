@@ -230,10 +230,10 @@ class ClockSampler:
 
 
 def pmc_reference(prec, rays, workload):
-    """HBM bytes per step from the committed rocprofv3 --pmc passes of this very command (profiles/r03_pmc_traffic_<prec>.json;
+    """HBM bytes per step from the committed rocprofv3 --pmc passes of this very command (profiles/r04_pmc_traffic_<prec>.json;
     counters cannot be collected from inside the process).  Used only when the workload matches the one profiled; the block
     says which file, of which commit and date, it quotes -- the figure goes stale when a kernel changes without re-profiling."""
-    for name in ('r03_pmc_traffic_%s.json' % prec, 'r02_pmc_traffic_%s.json' % prec):
+    for name in ('r04_pmc_traffic_%s.json' % prec, 'r03_pmc_traffic_%s.json' % prec, 'r02_pmc_traffic_%s.json' % prec):
         try:
             tr = json.load(open(os.path.join(ROOT, 'profiles', name)))
             if tr['workload']['rays_per_gpu'] == rays and tr['workload']['precision'] == prec and tr['workload'].get('scene', 'fern') == workload:

@@ -139,3 +139,23 @@ def test_build_info_names_every_switch_and_is_a_product_build():
     for k in ('VN_PT2_SPREAD=', 'VN_T16=', 'VN_WG16_HYBRID=', 'VN_DMA_MODE=', 'VN_ADAM_FMA_MASK='):
         assert k in info
     L.require_product_build('test')
+
+
+def test_trainer_one_call_iterations_equal_the_module_contract():
+    """TrainerHip01 steps through vipnerf_train_step by default (one sub-batch per iteration: the reference's shipped configs); with
+    `one_call_step: False` it walks the module contract.  Same scene, schedule and seeds: bit-identical parameters after six iterations,
+    the same logged losses."""
+    import test_hip_dist as thd
+    dev = torch.device('cuda:0')
+    runs = {}
+    for one_call in (True, False):
+        tr = thd._trainer(dev, 0, 1, None)
+        tr.configs['one_call_step'] = one_call
+        if not one_call:
+            tr.stepper = None
+        assert (tr.stepper is not None) == one_call
+        hist = tr.train()
+        runs[one_call] = (torch.cat([p.detach().flatten() for p in tr.model.parameters()]).clone(), [h['MSEHip01'] for h in hist], [h['TotalLoss'] for h in hist])
+    assert torch.equal(runs[True][0], runs[False][0]), 'parameters after six iterations differ between the two entry points'
+    np.testing.assert_allclose(runs[True][1], runs[False][1], rtol=1e-6)
+    np.testing.assert_allclose(runs[True][2], runs[False][2], rtol=1e-6)

@@ -53,6 +53,6 @@ def test_free_running_index_agreement_and_rgb_error_1024_rays(scene, nf, train):
     print(f'{scene} {"train" if train else "eval"}: {open_cols.numel()} free-running indices, agreement {agree:.6f} ({int((~open_cols).sum())} differ, by at most '
           f'{worst}); fine depths max abs diff {dz:.2e}; rgb_fine error median {q[0]:.1e}, p99 {q[1]:.1e}, p99.9 {q[2]:.1e}, max {float(e.max()):.2e}, '
           f'rays beyond 1e-4: {beyond:.4f}' + ('' if train else f'; u = 1 column: {float(same[:, -1].float().mean()):.3f} equal'))
-    assert agree >= 0.9999, f'{scene}: index agreement {agree:.6f}'
+    assert agree >= 0.99995, f'{scene}: index agreement {agree:.6f}'          # measured: 0 of 131,072 differ in training, 1 of 130,048 in eval (fern)
     assert worst <= 1, 'a differing index is a neighbouring bin (a cdf value within rounding of the draw)'
-    assert beyond <= 0.002 and float(e.max()) <= 5e-4, (beyond, float(e.max()))
+    assert beyond == 0.0 and float(e.max()) <= 1e-4, (beyond, float(e.max()))   # north_star: rendered RGB within 1e-4 (measured max 5.9e-5 training, 3.6e-7 eval)

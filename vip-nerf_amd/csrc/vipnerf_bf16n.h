@@ -388,6 +388,17 @@ __device__ __forceinline__ float pow2f(int l) { return __uint_as_float((unsigned
 
 // gamma(x) in the slot order of pe_feat16 (vipnerf_bf16n.h): lane group q evaluates levels (5q)>>1 .. +2 only.
 // out[s][e], u = 8s + e: u = 3 gg + d < 15 -> triple gg of this lane group, component d; u = 15 -> x[q] / unused
+// sin / cos for the encodings of the SINGLE-MFMA 16-bit kernels (build switch VN_PT2_FAST_PE): the hardware's v_sin_f32 / v_cos_f32 on the
+// argument in revolutions, reduced with v_fract first (their input range is +-256 revolutions; 2^9 x of a non-NDC scene exceeds it) --
+// 5 instructions and no branch against sincosf's ~40 with two range-reduction branches.  Error: the fp32 product x 2^l / (2 pi) carries
+// 2^-24 relative, i.e. <= 5e-5 rad at 2^9 |x| = 768, plus the instructions' own ~1e-6: a fifth of ONE fp16 rounding of the encoded value
+// (2.4e-4), a fortieth of a bf16 one -- below the accuracy class of the modes that use it.  Never used by the fp32-grade arithmetics.
+__device__ __forceinline__ void sincos_rev(float x, float *s, float *c) {
+    const float r = __builtin_amdgcn_fractf(x * 0.15915494309189535f);
+    *s = __builtin_amdgcn_sinf(r);
+    *c = __builtin_amdgcn_cosf(r);
+}
+template <bool FAST = false>
 __device__ __forceinline__ void encode_x16(const float v[3], int q, float (&out)[2][8]) {
     const int lb = (5 * q) >> 1;
     float S[3][3], C[3][3];
@@ -399,7 +410,8 @@ __device__ __forceinline__ void encode_x16(const float v[3], int q, float (&out)
 #if defined(VN_EXP) && VN_EXP == 7
             S[li][d] = v[d] * f; C[li][d] = S[li][d] + 1.f;   // timing experiment only: no sincos
 #else
-            sincosf(v[d] * f, &S[li][d], &C[li][d]);
+            if (FAST) sincos_rev(v[d] * f, &S[li][d], &C[li][d]);
+            else sincosf(v[d] * f, &S[li][d], &C[li][d]);
 #endif
         }
     }
@@ -420,10 +432,14 @@ __device__ __forceinline__ void encode_x16(const float v[3], int q, float (&out)
         for (int e = 0; e < 8; ++e) out[s][e] = val[8 * s + e];
 }
 // gamma(dir) in the slot order of dir_feat16: lane group q evaluates level q only
+template <bool FAST = false>
 __device__ __forceinline__ void encode_d16(const float v[3], int q, float (&out)[1][8]) {
     const float f = pow2f(q);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) sincosf(v[d] * f, &out[0][d], &out[0][3 + d]);
+    for (int d = 0; d < 3; ++d) {
+        if (FAST) sincos_rev(v[d] * f, &out[0][d], &out[0][3 + d]);
+        else sincosf(v[d] * f, &out[0][d], &out[0][3 + d]);
+    }
     out[0][6] = q == 0 ? v[0] : (q == 1 ? v[2] : 0.f);
     out[0][7] = q == 0 ? v[1] : 0.f;
 }

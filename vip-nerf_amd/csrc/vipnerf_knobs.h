@@ -15,11 +15,10 @@
     X(VN_STORE_GROUP_A) X(VN_STORE_GROUP_B) X(VN_F32_DEFER)                                                              \
     /* single-MFMA 16-bit modes: storage and the two-point-tile kernels (vipnerf_bf16n.h, vipnerf_mlp_pt2.h, vipnerf_mlp_*_pt2.hip) */    \
     X(VN_BF16_H16) X(VN_T16) X(VN_T16_X4) X(VN_T16_NT) X(VN_PT2_SPREAD) X(VN_PT2_SKEW) X(VN_PT2_G) X(VN_PT2_D)                  \
-    X(VN_PT2_TRAIN_KEEP) X(VN_PT2_EVAL_KEEP)                                                                                              \
+    X(VN_PT2_TRAIN_KEEP) X(VN_PT2_EVAL_KEEP) X(VN_PT2_FAST_PE)                                                                                              \
     /* weight gradients (vipnerf_wgrad.hip, vipnerf_wgrad16.hip) */                                                                       \
     X(VN_WGRAD_DMA) X(VN_WGRAD_W8) X(VN_WGRAD_PIPE) X(VN_WGRAD_ONE_ROUND) X(VN_WGRAD_ROUNDS) X(VN_WG16_BIG_WM) X(VN_WG16_BIG_WN)        \
     X(VN_WG16_BIG_NB) X(VN_WG16_HYBRID) X(VN_WG16_SIGMA_FUSED) X(VN_WG16_DMA_PIECES) X(VN_WG16_THIN_HYBRID) X(VN_WG16_BIG_SLOTS)          \
-    X(VN_WG16_SKIP_FUSED)                                                                                                                 \
     /* optimizer (vipnerf_api.hip) */                                                                                                     \
     X(VN_ADAM_FMA_MASK)
 
@@ -92,6 +91,9 @@
 #ifndef VN_PT2_EVAL_KEEP
 #define VN_PT2_EVAL_KEEP 1       // eval: 1 = gamma(x)'s fragments stay in 16 registers from layer 0 to layer 5 (measured: fp16 1023 -> 1080, bf16 1181 -> 1226 TFLOP/s); 0 = evaluated again at layer 5
 #endif
+#ifndef VN_PT2_FAST_PE
+#define VN_PT2_FAST_PE 1         // single-MFMA 16-bit kernels: gamma(x), gamma(dir) with v_fract + v_sin_f32 / v_cos_f32 (vipnerf_bf16n.h sincos_rev); 0: sincosf
+#endif
 #ifndef VN_WGRAD_DMA
 #define VN_WGRAD_DMA 0           // exact-fp32 256 x 256 weight gradients: 1 = operand blocks HBM -> LDS by DMA instead of through registers -- built, correct, and measured SLOWER (9.10 vs 8.22 ms per step: docs/HISTORY.md 5); off
 #endif
@@ -130,9 +132,6 @@
 #endif
 #ifndef VN_WG16_BIG_SLOTS
 #define VN_WG16_BIG_SLOTS 256    // workgroups of the 256 x 256 launch at a large level: one round of the chip (two / three rounds measured: docs/HISTORY.md 4.3a)
-#endif
-#ifndef VN_WG16_SKIP_FUSED
-#define VN_WG16_SKIP_FUSED 0     // 1: layer 5's gamma(x) columns ride in its 256 x 256 GEMM as four extra B tiles (dY_5 is read once)
 #endif
 #ifndef VN_ADAM_FMA_MASK
 #define VN_ADAM_FMA_MASK 7       // which of torch's three update expressions its kernels contract into an fma on gfx950 (tests/test_hip_fullsize.py)

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
             {
                 PointCtx pc0;
                 load_point(a.src, p[pt], pc0);
-                encode_x16(pc0.x, q, pe);
+                encode_x16<VN_PT2_FAST_PE != 0>(pc0.x, q, pe);
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
             if (dsel == 0) { dir[0] = pc.dir[0]; dir[1] = pc.dir[1]; dir[2] = pc.dir[2]; }
             else secondary_dir(a.src, pc, dsel - 1, dir);
             float ped[1][8];
-            encode_d16(dir, q, ped);
+            encode_d16<VN_PT2_FAST_PE != 0>(dir, q, ped);
             FR bpd[1][NS];
             {
                 float sc[8];

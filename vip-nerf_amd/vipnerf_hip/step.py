@@ -288,11 +288,11 @@ class FusedTrainStep:
 
 def named_losses(res: dict) -> Dict[str, torch.Tensor]:
     """{loss name: value} like LossComputer.compute_losses reports them (coarse + fine per loss), from a FusedTrainStep result."""
-    v, out = res['loss_values'], {}
+    v, out = res['loss_values'].clone(), {}          # (the step's buffers are overwritten by the next call: what is handed out is a copy)
     for name, slots in res['loss_slots'].items():
         if slots is None:
             out[name] = v[7]
         else:
             out[name] = (v[slots[0]] + v[slots[1]]) if (res['two_levels'] and slots[1] != 7) else v[slots[0]]
-    out['TotalLoss'] = res['TotalLoss'][0]
+    out['TotalLoss'] = res['TotalLoss'][0].clone()
     return out

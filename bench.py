@@ -2,9 +2,9 @@
 """Benchmark of the ViP-NeRF per-ray hot path on MI355X (BASELINE.json: train rays/sec + full-frame render ms,
 LLFF-fern 2-view geometry, synthetic data).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py spawns its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             (a WORLD_SIZE that contradicts --gpus is an error)
 
 A step = one training iteration over one ray batch per GPU (BASELINE configs[1]: 4096 rays x (64 + 128) samples, coarse +
 fine 8x256 MLP, fp32): forward -> fused losses (MSE 1, Visibility 0.1, VisibilityPrior 0.001 @ iter 40000) -> backward ->
@@ -16,7 +16,9 @@ arithmetics (`--also`, default fp16x3, fp16x3h, fp16, bf16) are timed by the sam
 beside it (`value_fp16x3`, ...), each with its own `roofline` block (MFMA-bound path, algorithmic 630,272 MAC/point
 against the dense MFMA peak of the operand dtype).  At N = 1 the line also carries `configs4_dtu`: BASELINE configs[4]'s per-GPU
 shard (DTU geometry, non-NDC, 3 views = 2 secondary views, 131,072 / 8 = 16,384 rays per iteration, bf16 / fp16 mixed precision)
-timed the same way.  `--workload fern|realestate|dtu` selects the scene of `value` itself; `--scaling strong` runs the
+timed the same way, `configs2_realestate`: BASELINE configs[2] (RealEstate geometry, 3 views, 2048 nerf + 2048 sparse-depth rows, the
+sparse-depth loss in the list; fp32 and bf16), and `sizes`: the batch sizes the reference's shipped configs train at (1024 rays;
+2048 + 2048) through the module contract and through the one-call step (vipnerf_train_step).  `--workload fern|realestate|dtu` selects the scene of `value` itself; `--scaling strong` runs the
 ray-sharded statement of configs[3] / configs[4] (`--global-rays` rays per iteration split over the ranks) instead of the
 weak-scaling default (`--rays` per GPU).  `--force-dist` makes a single process take the multi-rank code path (RCCL process group
 with world_size 1, broadcast, all-reduce of the flat gradient bucket inside the timed step, barriers).

@@ -194,6 +194,13 @@ template <bool NAN_THROUGH>
 __device__ __forceinline__ float relu_bound(bool relu) { return relu ? 0.f : -INFINITY; }
 template <bool NAN_THROUGH>
 __device__ __forceinline__ float relu_lo(float x, float lo) { return NAN_THROUGH ? (x <= lo ? lo : x) : fmaxf(x, lo); }
+// The same bound as a signed-integer max of the bit pattern (lo_i = 0: ReLU, INT_MIN: none): ONE instruction, +0 | positive | NaN like
+// relu_lo<true> for every input but a NaN whose sign bit is set (-> +0).  For the arithmetics with fp32's exponent range (exact fp32,
+// bf16), where no intermediate overflows into inf - inf; the fp16 fragments keep relu_lo<true> (their range test relies on it).
+__device__ __forceinline__ float relu_bits(float x, int lo_i) {
+    const int b = __float_as_int(x);
+    return __int_as_float(b > lo_i ? b : lo_i);
+}
 // 1 if y > 0, for a y that went through relu_lo<true>(., 0) (+0, positive or NaN: "bits != 0").  v_min_u32 + shifts
 // instead of v_cmp + v_cndmask + or: on gfx950 a VALU that reads VCC needs two wait states behind the v_cmp that wrote
 // it, ~3.5 issue slots per element against 2.  Inline asm: the compiler turns umin(b, 1) back into the compare form.

@@ -121,6 +121,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
         // Kept free of per-tile branches on `layer`: ReLU is a max with a per-layer bound (0, or -inf for the feature
         // layer), the sigma head is one block for layer 7.
         const float lo = relu_bound<F16>(layer < 8);
+        const int lo_i = layer < 8 ? 0 : (int)0x80000000;      // the bound of relu_bits (exact-fp32 training: the ReLU as one integer max)
         if (layer == 7) {
             float sg[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             for (int u = 0; u < 2; ++u) {
                 const int t = 2 * s + u;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) x[u][r] = relu_lo<F16 || (F32 && SAVE)>(x[u][r] * AU, lo);   // (+0 | positive | NaN for the bit masks)
+                for (int r = 0; r < 4; ++r) x[u][r] = (F32 && SAVE && !F16) ? relu_bits(x[u][r] * AU, lo_i) : relu_lo<F16>(x[u][r] * AU, lo);   // (+0 | positive | NaN for the bit masks)
                 if (SAVE) {
                     if (!(H16 && layer < 8) && !T16 && !(layer < 8 ? EXP_NO_STORES : EXP_NO_EXTRAS)) store_tile16(dst, p, W, q, t, x[u]);
                     if (F16 || F32) {

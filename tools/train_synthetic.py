@@ -26,8 +26,9 @@ cfg = e2e.configs(iters, prec)
 cfg['model_save_interval'] = 0
 cfg['validation_interval'] = 250 if iters <= 3000 else 1000
 gen = RayGeneratorHip((h, w), K[None], poses, 2.0, 4.0, False, dev, images=images, visibility_prior=torch.ones(n, n - 1, h, w))
-if rays > 1024:
+if rays > 1024 or os.environ.get('ONE_SUB'):
     cfg['sub_batch_size'] = 0      # one sub-batch (the default configuration splits its 1024 rays into two of 512)
+cfg['one_call_step'] = os.environ.get('ONE_CALL', '1') != '0'     # ONE_CALL=0: the module-contract sequence instead of vipnerf_train_step
 tr = TrainerHip(cfg, gen, BatchIndexScheduler(n, h, w, num_rays=rays), output_dirpath=tempfile.mkdtemp(), rank=rank, world=world)
 torch.cuda.synchronize(); t0 = time.time()
 hist = tr.train()
@@ -37,5 +38,5 @@ psnr = [(i + 1, round(x['validation_psnr'], 2)) for i, x in enumerate(hist) if '
 if world > 1:
     torch.distributed.barrier()
 if rank == 0:
-  print((f'[{world} ranks] ' if world > 1 else '') + f'{prec}: {iters} iterations of {rays} rays ({side} x {side} images) in {dt:.1f} s ({iters * rays / dt / 1e3:.0f} k rays/s incl. validation renders); '
+  print((f'[{world} ranks] ' if world > 1 else '') + ('one-call step, ' if tr.stepper is not None and cfg['sub_batch_size'] == 0 else 'module contract, ') + f'{prec}: {iters} iterations of {rays} rays ({side} x {side} images) in {dt:.1f} s ({iters * rays / dt / 1e3:.0f} k rays/s incl. validation renders); '
         f'MSE {mse[:10].mean():.4f} -> {mse[-50:].mean():.5f}; all finite: {bool(np.isfinite(mse).all())}; PSNR of the training views: {psnr}')

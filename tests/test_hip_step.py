@@ -46,7 +46,8 @@ def _fresh(b, it):
 
 
 @pytest.mark.parametrize('scene,n,n_sparse,prec', [('fern', 1024, 0, 'fp32'), ('fern', 1024, 0, 'bf16'), ('realestate', 256, 256, 'fp32'),
-                                                   ('realestate', 512, 512, 'bf16'), ('dtu', 300, 0, 'fp16'), ('fern', 96, 0, 'fp16x3')])
+                                                   ('realestate', 512, 512, 'bf16'), ('dtu', 300, 0, 'fp16'), ('fern', 96, 0, 'fp16x3'),
+                                                   ('realestate', 2048, 2048, 'bf16')])        # BASELINE configs[2] at its full batch: 2048 nerf + 2048 sparse-depth rows
 def test_one_call_step_is_the_five_call_step(scene, n, n_sparse, prec):
     from loss_functions.FusedLossesHip01 import CACHE_ATTR
     from loss_functions.LossComputerHip01 import LossComputerHip

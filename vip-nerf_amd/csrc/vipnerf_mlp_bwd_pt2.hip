@@ -10,7 +10,9 @@ namespace vn {
 
 // x where bit (4 t + r) of the 64-bit ReLU mask (m0: tiles 0..7, m1: tiles 8..15) is set, +0 elsewhere
 __device__ __forceinline__ float mask_apply_pt2(float x, unsigned m0, unsigned m1, int t, int r) {
-    const int sel = __builtin_amdgcn_sbfe((int)(t < 8 ? m0 : m1), (unsigned)(4 * (t & 7) + r), 1u);
+    // inline asm: the compiler turns sbfe + and back into v_and (one bit) + v_cmp + v_cndmask, three instructions and a VCC hazard
+    int sel;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(t < 8 ? m0 : m1), "s"(4 * (t & 7) + r));
     return __uint_as_float(__float_as_uint(x) & (unsigned)sel);
 }
 
@@ -163,27 +165,38 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_bwd_pt2(MlpBwdArgs a) {
             gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws, ds);
         }
         float *dst = a.bwd + a.bl.dy[layer];
+        // ReLU bits applied AFTER the conversion, two gradients per instruction (vipnerf_mlp_pt2.h mask_pk16): 2.25 VALU instructions
+        // per value with the conversion where the select on fp32 values was 2.5 .. 3 (the epilogue of a SIMD's later wave runs with the
+        // MFMA pipe idle: its instruction count is kernel time, profiles/r04_ablation_pt2.md 5)
+        unsigned one2 = 0x00010001u;
+        asm volatile("" : "+s"(one2));
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
+        for (int pt = 0; pt < 2; ++pt) {
+            const unsigned ab[4] = {unfold_pk_bits(mk[pt].x & 0xffffu), unfold_pk_bits(mk[pt].x >> 16),
+                                    unfold_pk_bits(mk[pt].y & 0xffffu), unfold_pk_bits(mk[pt].y >> 16)};
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 floatx4 x[2] = {acc[2 * s].v[pt] * AU, acc[2 * s + 1].v[pt] * AU};
+                if (it == 0) {                                   // h_8 also feeds the sigma head
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int t = 2 * s + u;
-                    if (it == 0) {                               // h_8 also feeds the sigma head
-                        const float4 w4 = *(const float4 *)(rf + PL::N_WSIG + 16 * t + 4 * q);
+                    for (int u = 0; u < 2; ++u) {
+                        const float4 w4 = *(const float4 *)(rf + PL::N_WSIG + 16 * (2 * s + u) + 4 * q);
                         x[u][0] = fmaf(w4.x, dsig_raw[pt], x[u][0]); x[u][1] = fmaf(w4.y, dsig_raw[pt], x[u][1]);
                         x[u][2] = fmaf(w4.z, dsig_raw[pt], x[u][2]); x[u][3] = fmaf(w4.w, dsig_raw[pt], x[u][3]);
                     }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) x[u][r] = mask_apply_pt2(x[u][r], mk[pt].x, mk[pt].y, t, r);
                 }
                 FR t1[NS];
                 split_pair<NS>(x[0], x[1], t1);
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                const u4 w4 = __builtin_bit_cast(u4, t1[0]);
+                u4 r4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r4[i] = mask_pk16(w4[i], ab[s >> 1], 4 * (s & 1) + i, one2);
+                t1[0] = __builtin_bit_cast(FR, r4);
                 bin[s][0].v[pt] = t1[0];
                 if (it == 7 && valid[pt] && !EXP_NO_EXTRAS) store_t16(dst, grp[pt], 16, s, j, q, t1[0]);     // dY_0 (the others leave from the next GEMM's stages)
             }
+        }
     }
     if (EXP_NO_EXTRAS) {          // timing-only builds without stores: keep the whole chain alive (a store that never happens)
         typedef unsigned u4 __attribute__((ext_vector_type(4)));

@@ -16,6 +16,15 @@
 
 namespace vn {
 
+// VN_EXP == 50 (timing experiment: tools/pt2_timeline.py): one workgroup in the middle of the grid records s_memtime at the kernel's phase
+// boundaries, per wave, into a device array that vipnerf_exp_timeline() copies out.  TS() is nothing in every other build.
+#if defined(VN_EXP) && VN_EXP == 50
+__device__ unsigned long long g_pt2_timeline[8 * 128];
+#define TS() do { if (ts_rec) { g_pt2_timeline[wave * 128 + (ts_n < 127 ? ts_n : 127)] = __builtin_readcyclecounter(); ++ts_n; } } while (0)
+#else
+#define TS() do { } while (0)
+#endif
+
 template <bool SAVE, bool F16>
 __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
     typedef BnPlan<1> PL;
@@ -33,6 +42,11 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, j = lane & 15;
+#if defined(VN_EXP) && VN_EXP == 50
+    const bool ts_rec = blockIdx.x == gridDim.x / 2 && lane == 0;
+    int ts_n = 0;
+#endif
+    TS();                                    // 0: entry
     int64_t p[2], grp[2];
     bool valid[2];
 #pragma unroll
@@ -99,8 +113,8 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
                     const float4 w4 = *(const float4 *)(rf + PL::N_WSIG + 16 * t + 4 * q);
-                    sg[0] = fmaf(w4.x, relu_lo<true>(acc[t].v[pt][0] * AU, 0.f), sg[0]); sg[1] = fmaf(w4.y, relu_lo<true>(acc[t].v[pt][1] * AU, 0.f), sg[1]);
-                    sg[2] = fmaf(w4.z, relu_lo<true>(acc[t].v[pt][2] * AU, 0.f), sg[2]); sg[3] = fmaf(w4.w, relu_lo<true>(acc[t].v[pt][3] * AU, 0.f), sg[3]);
+                    sg[0] = fmaf(w4.x, relu_pt2<F16>(acc[t].v[pt][0] * AU, 0.f, 0), sg[0]); sg[1] = fmaf(w4.y, relu_pt2<F16>(acc[t].v[pt][1] * AU, 0.f, 0), sg[1]);
+                    sg[2] = fmaf(w4.z, relu_pt2<F16>(acc[t].v[pt][2] * AU, 0.f, 0), sg[2]); sg[3] = fmaf(w4.w, relu_pt2<F16>(acc[t].v[pt][3] * AU, 0.f, 0), sg[3]);
                 }
                 float s = (sg[0] + sg[1]) + (sg[2] + sg[3]);
                 s += __shfl_xor(s, 16, 64);
@@ -111,6 +125,30 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
             unsigned mk0 = 0u, mk1 = 0u;
+            if constexpr (!F16 && NS == 1) {
+                // bf16: convert, then ReLU and ReLU bits on the packed halves (vipnerf_mlp_pt2.h relu_pk16): 2 (4 with the bits) VALU
+                // instructions per two values instead of 3 (7)
+                unsigned lo16 = layer < 8 ? 0u : 0x80008000u, one2 = 0x00010001u;
+                asm volatile("" : "+s"(lo16), "+s"(one2));      // one SGPR operand: the compiler otherwise selects between two results per value
+                unsigned cb[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    FR t1[NS];
+                    split_pair<NS>(acc[2 * s].v[pt], acc[2 * s + 1].v[pt], t1);
+                    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                    const u4 w4 = __builtin_bit_cast(u4, t1[0]);
+                    unsigned w[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) w[i] = relu_pk16(w4[i], lo16);
+                    if (SAVE) cb[s] = positive_pk_bits(w, one2);
+                    const u4 r4 = {w[0], w[1], w[2], w[3]};
+                    bin[s][0].v[pt] = __builtin_bit_cast(FR, r4);
+                }
+                if (SAVE) {
+                    mk0 = fold_pk_bits(cb[0], cb[1]) | (fold_pk_bits(cb[2], cb[3]) << 16);
+                    mk1 = fold_pk_bits(cb[4], cb[5]) | (fold_pk_bits(cb[6], cb[7]) << 16);
+                }
+            } else {
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 floatx4 x[2] = {acc[2 * s].v[pt], acc[2 * s + 1].v[pt]};
@@ -126,6 +164,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
                 split_pair<NS>(x[0], x[1], t1);
                 bin[s][0].v[pt] = t1[0];
             }
+            }
             // valid tiles only: a tile beyond P runs on point P - 1's position but reloads gamma(x) of group 0 at layer 5 (below) -- from there on
             // its ReLU bits are not point P - 1's, and an unpredicated store would race the owner's (the 16-point kernels keep gamma(x) in
             // registers: their out-of-range lanes write point P - 1's own bits again)
@@ -134,12 +173,14 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
     };
 
     __syncthreads();                         // resident block visible
+    TS();                                    // 1: resident block in
     // ---------------------------------------------------------------- layer 0: gamma(x) only (the first two k-steps of a stage whose other two are zero padding)
     // (build switches VN_PT2_TRAIN_KEEP / VN_PT2_EVAL_KEEP, vipnerf_knobs.h: gamma(x)'s fragments kept in registers up to layer 5, or reloaded / evaluated again)
     BT bpe_keep[2][NS];
     {
         BT bpe[2][NS];
         encode_pe(bpe);
+        TS();                                // 2: gamma(x) encoded
         if ((!SAVE && VN_PT2_EVAL_KEEP) || (SAVE && VN_PT2_TRAIN_KEEP)) { bpe_keep[0][0] = bpe[0][0]; bpe_keep[1][0] = bpe[1][0]; }
         if (SAVE) {
 #pragma unroll
@@ -153,8 +194,11 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
             }
         }
         init_acc(0);
+        TS();
         const float *st = ws.template wait<SAVE ? 4 : 0>();      // behind gamma(x)'s own stores
+        TS();
         gemm_stage_bf<16, 2, NS>(st, lane, acc, bpe, 0, ws);
+        TS();
         epilogue(0);
     }
     // ---------------------------------------------------------------- layers 1..7 + feature layer (8)
@@ -164,13 +208,16 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
 #pragma unroll
         for (int jj = 0; jj < PL::ST_256; ++jj) {
             // younger than this stage's DMA: the mask stores of the previous epilogue (first stage), the deferred stores behind the stage before
+            TS();
             const float *st = jj == 0 ? ws.template wait<SAVE ? 2 : 0>() : ws.template wait<SAVE ? 2 * T16_SPK * S_PER_STAGE : 0>();
+            TS();
             if (SAVE) {
                 DeferredT16<FR, S_PER_STAGE> ds{a.acts + a.al.h[layer - 1], {grp[0], grp[1]}, {valid[0], valid[1]}, j, q, S_PER_STAGE * jj, bin, store_phase};
                 gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws, ds);
             } else {
                 gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
             }
+            TS();
         }
         if (layer == SKIP_LAYER) {           // gamma(x) columns last: h's operand registers are dead by then
             BT bpe[2][NS];
@@ -189,8 +236,11 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
             } else {
                 encode_pe(bpe);              // eval: evaluated again rather than held in 16 registers across layers 1..4
             }
+            TS();
             const float *st = ws.template wait<SAVE ? 2 * T16_SPK * S_PER_STAGE : 0>();      // behind the deferred stores of the stage before
+            TS();
             gemm_stage_bf<16, 2, NS>(st, lane, acc, bpe, 0, ws);
+            TS();
         }
         epilogue(layer);
 #if defined(VN_EXP) && VN_EXP == 47
@@ -223,7 +273,9 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
     }
     static_assert(PL::ST_VIEW_F == 1, "the feature's deferred stores assume one view stage");
     {
+        TS();
         const float *st = ws.template wait<SAVE ? 2 * T16_SPK * S_PER_STAGE : 0>();      // behind the deferred stores of the feature layer's last stage
+        TS();
         if (SAVE) {          // the feature (= this GEMM's B operand) leaves from inside the stage like h_1..h_8
             DeferredT16<FR, 8> ds{a.acts + a.al.feat, {grp[0], grp[1]}, {valid[0], valid[1]}, j, q, 0, bin, store_phase};
             gemm_stage_bf<8, PL::KSV, NS>(st, lane, vb, bin, 0, ws, ds);
@@ -232,6 +284,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
         }
     }
 
+    TS();                                    // view stage done
     // ... then per point tile and direction a K = 32 GEMM from the LDS-resident direction columns, ReLU, the 128 -> 4 head
 #pragma unroll 1
     for (int pt = 0; pt < 2; ++pt) {
@@ -274,9 +327,10 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
                 char *row = (char *)(a.acts + a.al.ped[dsel]) + ((size_t)grp[pt] * 2 + (q >> 1)) * 512 + j * 32 + (q & 1) * 16;
                 __builtin_nontemporal_store(__builtin_bit_cast(u4, bpd[0][0]), (u4 *)row);
             }
-            float qv[4];
+            float qv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
+                if (c < 3 && dsel != 0) continue;          // a secondary direction: the visibility only
                 const float *wo = rf + PL::N_WOUT + c * WV + 4 * q;
                 float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -303,7 +357,14 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
             }
         }
     }
+    TS();                                    // last: view tail done
 }
+
+#if defined(VN_EXP) && VN_EXP == 50
+extern "C" int vipnerf_exp_timeline(unsigned long long *out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pt2_timeline), sizeof(unsigned long long) * (n < 1024 ? n : 1024));
+}
+#endif
 
 template <bool SAVE, bool F16>
 static int launch_pt2(const MlpFwdArgs &a, hipStream_t st) {

@@ -74,6 +74,48 @@ __device__ __forceinline__ float relu_pt2(float x, float lo, int lo_i) {
     return __int_as_float(b > lo_i ? b : lo_i);
 }
 
+// bf16 fragments, the trunk's epilogue: the ReLU AFTER the conversion, on the packed halves -- v_pk_max_i16 against lo16 = 0 / 0x8000 per half
+// (ReLU / none), one instruction per TWO values where relu_pt2 + v_cvt_pk is three per two; bf16(relu(x)) == relu(bf16(x)) for every x
+// (round-to-nearest-even keeps the sign, -0 -> +0 either way).  A wave's VALU instruction is 4 cycles of its SIMD, and the epilogue of
+// the SIMD's LATER wave runs with the MFMA pipe idle (profiles/r04_ablation_pt2.md 5): its instruction count is kernel time.
+__device__ __forceinline__ unsigned relu_pk16(unsigned w, unsigned lo16) {
+    unsigned r;
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(w), "s"(lo16));
+    return r;
+}
+// The ReLU bits of the eight packed values of a k-step operand that went through relu_pk16(., 0) (halves +0 | positive | NaN): bits
+// 0..3 = elements 0..3 > 0 (C/D tile 2s), 4..7 = elements 4..7 (tile 2s + 1) for the even elements' bits IN PLACE (0, 2, 4, 6) and the
+// odd elements' 16 bits higher -- fold_pk_bits() of two of them brings the halves together.  v_pk_min_u16 against 1 per half: two
+// values per instruction (positive_bit: one).
+__device__ __forceinline__ unsigned positive_pk_bits(const unsigned (&w)[4], unsigned one2) {
+    unsigned m[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm("v_pk_min_u16 %0, %1, %2" : "=v"(m[i]) : "v"(w[i]), "s"(one2));
+    unsigned ta, tb, c;
+    asm("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(ta) : "v"(m[1]), "v"(m[0]));
+    asm("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(tb) : "v"(m[3]), "v"(m[2]));
+    asm("v_lshl_or_b32 %0, %1, 4, %2" : "=v"(c) : "v"(tb), "v"(ta));
+    return c;
+}
+// k-steps s, s + 1 (s even) -> the 16 mask bits of their four tiles in push_nibble's order (tile t's nibble at 4 (t & 7))
+__device__ __forceinline__ unsigned fold_pk_bits(unsigned c0, unsigned c1) {
+    unsigned a;
+    asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(a) : "v"(c1), "v"(c0));
+    return (a | (a >> 15)) & 0xffffu;
+}
+
+// The inverse for the data-gradient pass: 16 stored ReLU bits (four tiles = two k-steps, push_nibble's order) -> even bits in place, odd
+// bits 15 higher, so that (a >> 2 i) & 0x00010001 holds packed pair i's two bits (elements 2i, 2i + 1 of the first k-step; i + 4: of
+// the second) one per half -- and v_pk_mul_lo_u16 by it keeps or zeroes the two converted gradients in ONE instruction.
+__device__ __forceinline__ unsigned unfold_pk_bits(unsigned m16) { return (m16 & 0x5555u) | ((m16 & 0xaaaau) << 15); }
+// packed pair w (two 16-bit gradients) times its two ReLU bits: a = unfold_pk_bits(.), i = the pair's index in it (0..7)
+__device__ __forceinline__ unsigned mask_pk16(unsigned w, unsigned a, int i, unsigned one2) {
+    unsigned b, r;
+    asm("v_and_b32 %0, %1, %2" : "=v"(b) : "s"(one2), "v"(a >> (2 * i)));
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(w), "v"(b));
+    return r;
+}
+
 #endif
 
 int launch_mlp_fwd_pt2(const MlpFwdArgs &a, int precision, hipStream_t st);

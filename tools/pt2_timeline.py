@@ -1,6 +1,7 @@
-"""Where one workgroup of k_mlp_fwd_pt2 spends its cycles (experiment build -DVN_EXP=50: s_memtime at the phase boundaries, per wave):
-    tools/build_variant.sh exp50 "-DVN_EXP=50" vipnerf_mlp_fwd_pt2
-    VIPNERF_HIP_LIB=vip-nerf_amd/lib/libvipnerf_hip_exp50.so python tools/pt2_timeline.py [eval|train]
+"""Where one workgroup of k_mlp_fwd_pt2 / k_mlp_bwd_pt2 spends its cycles (experiment build -DVN_EXP=50: s_memtime at the phase boundaries,
+per wave, tagged -- vipnerf_mlp_pt2.h TS_AT):
+    tools/build_variant.sh exp50 "-DVN_EXP=50" vipnerf_mlp_fwd_pt2 vipnerf_mlp_bwd_pt2
+    VIPNERF_HIP_LIB=vip-nerf_amd/lib/libvipnerf_hip_exp50.so python tools/pt2_timeline.py [eval|train|bwd]
 The recorded workgroup is the one in the middle of the FINE level's grid of the last launch."""
 import ctypes as C, os, sys, warnings
 warnings.filterwarnings('ignore')
@@ -18,44 +19,60 @@ bd = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items()
 pa = vo.init_params(3)
 pc = ops.pack_weights([cu(pa['coarse_model.' + k]) for k in ops.PARAM_ORDER], precision=prec)
 pf = ops.pack_weights([cu(pa['fine_model.' + k]) for k in ops.PARAM_ORDER], precision=prec)
-train = mode == 'train'
+train = mode in ('train', 'bwd')
 V = 1 if train else 0
 cfg = ops.make_config(True, 64, 128, V, train, noise_std=1.0 if train else 0.0, precision=prec, save_acts=train)
 if train:
     bd['rays_o2'] = torch.zeros(n, 1, 3, device=dev) + torch.tensor([0.2, 0.0, 0.0], device=dev)
 acts = None
 if train:
-    ab, _ = ops.query_workspace(cfg, n)
+    ab, bb = ops.query_workspace(cfg, n)
     acts = torch.empty(ab // 4, dtype=torch.float32, device=dev)
 for _ in range(3):
-    ops.render_forward(cfg, bd, {'seed': 1, 'offset': 2} if train else None, pc, pf, acts)
+    c, f, _ = ops.render_forward(cfg, bd, {'seed': 1, 'offset': 2} if train else None, pc, pf, acts)
+if mode == 'bwd':
+    os.environ['VIPNERF_EXP_SKIP_WGRAD'] = '1'
+    bwd_ws = torch.empty(bb // 4, dtype=torch.float32, device=dev)
+    shapes = ops.param_shapes(ops.topology_of(cfg))
+    gc = [torch.zeros(s, device=dev) for s in shapes]; gf = [torch.zeros(s, device=dev) for s in shapes]
+    gen = torch.Generator(device=dev).manual_seed(3)
+    g_rgb = torch.randn(n, 3, device=dev, generator=gen) * 1e-4
+    g = {'rgb': g_rgb, 'visibility': torch.randn(n, 64, device=dev, generator=gen) * 1e-5, 'vis2': torch.randn(n, V, device=dev, generator=gen) * 1e-4}
+    g['raw_vis'] = g['visibility']
+    gfine = dict(g, visibility=torch.randn(n, 192, device=dev, generator=gen) * 1e-5); gfine['raw_vis'] = gfine['visibility']
+    for _ in range(3):
+        ops.render_backward(cfg, bd, pc, pf, c, f, g, gfine, acts, bwd_ws, gc, gf)
 torch.cuda.synchronize()
 lib = L.load()
-lib.vipnerf_exp_timeline.restype = C.c_int
+fn = lib.vipnerf_exp_timeline_bwd if mode == 'bwd' else lib.vipnerf_exp_timeline
+fn.restype = C.c_int
 buf = (C.c_ulonglong * 1024)()
-assert lib.vipnerf_exp_timeline(buf, 1024) == 0
-t = np.array(buf, dtype=np.uint64).reshape(8, 128).astype(np.int64)
-labels = ['entry', 'resident', 'pe', ('L0', 1)] + [(f'L{l}.{j}', 1) for l in range(1, 9) for j in ((0, 1, 'pe') if l == 5 else (0, 1))]
+assert fn(buf, 1024) == 0
+raw = np.array(buf, dtype=np.uint64).reshape(8, 128)
+ENTRY, RESIDENT, HEAD, PRE, POST, END, VIEW, LAST = range(8)
 print(f'{mode} {os.environ.get("HIP_PRECISION", "bf16")}: cycles (s_memtime ticks) of the recorded workgroup, per wave')
 rows = []
 for w in range(8):
-    x = t[w]; i = 3
-    rec = {'resident': x[1] - x[0], 'pe': x[2] - x[1], 'wait': 0, 'gemm': 0, 'between': 0}
+    ev = [(int(x >> np.uint64(56)), int(x & np.uint64((1 << 56) - 1))) for x in raw[w] if x]
+    assert ev[0][0] == ENTRY and ev[-1][0] == LAST, [e[0] for e in ev]
+    rec = {'resident': 0, 'head': 0, 'wait': 0, 'gemm': 0, 'between': 0, 'tail': 0}
     stages = []
-    for s in range(1 + 16 + 1):            # layer 0, 8 layers x 2 stages, layer 5's gamma(x) stage
-        pre, post, end = x[i], x[i + 1], x[i + 2]; i += 3
-        stages.append((post - pre, end - post))
-        rec['wait'] += post - pre; rec['gemm'] += end - post
-        if s: rec['between'] += pre - prev_end
-        prev_end = end
-    pre, post, vdone, last = x[i], x[i + 1], x[i + 2], x[i + 3]
-    rec['between'] += pre - prev_end; rec['wait'] += post - pre; rec['gemm'] += vdone - post
-    rec['tail'] = last - vdone; rec['total'] = last - x[0]
+    prev_tag, prev_t = ev[0]
+    for tag, t in ev[1:]:
+        d = t - prev_t
+        if tag == RESIDENT: rec['resident'] += d
+        elif tag == HEAD: rec['head'] += d                  # forward: gamma(x); backward: the heads and the view hidden layer of every direction
+        elif tag == PRE: rec['between'] += d                # epilogue of the layer before, accumulator set-up, operand reloads
+        elif tag == POST: rec['wait'] += d; stages.append([d, 0])
+        elif tag in (END, VIEW): rec['gemm'] += d; stages[-1][1] = d
+        elif tag == LAST: rec['tail'] += d                  # forward: per-direction view tail; backward: the last epilogue and dY_0's stores
+        prev_tag, prev_t = tag, t
+    rec['total'] = ev[-1][1] - ev[0][1]
     rows.append(rec)
-    print(f'wave {w}: total {rec["total"]:7d} | resident load {rec["resident"]:5d}  gamma(x) {rec["pe"]:5d} | 19 stages: MFMA loops {rec["gemm"]:7d}  waits+barriers {rec["wait"]:6d}  '
-          f'between stages (epilogues, sigma head, operand reloads) {rec["between"]:6d} | view tail {rec["tail"]:6d}')
+    print(f'wave {w}: total {rec["total"]:7d} | resident load {rec["resident"]:5d}  head {rec["head"]:6d} | {len(stages)} stages: MFMA loops {rec["gemm"]:7d}  waits+barriers {rec["wait"]:6d}  '
+          f'between stages {rec["between"]:6d} | tail {rec["tail"]:6d}')
     if w in (0, 4):
         print('        per stage (wait, loop):', ' '.join(f'{a}/{b}' for a, b in stages))
 m = {k: int(np.mean([r[k] for r in rows])) for k in rows[0]}
 print('mean over waves:', m, '| shares of total:', {k: round(v / m['total'], 3) for k, v in m.items() if k != 'total'})
-print('MFMA pipe time of the workgroup per SIMD at 16 cycles per MFMA: 2 waves x 2336 MFMAs x 16 =', 2 * 2336 * 16)
+print('MFMA pipe time of the workgroup per SIMD at 16 cycles per MFMA: 2 waves x %d MFMAs x 16 = %d' % ((2176 if mode == 'bwd' else 2336), 2 * 16 * (2176 if mode == 'bwd' else 2336)))

@@ -204,13 +204,8 @@ __device__ __forceinline__ void load_point(const PointSrc &s, int64_t p, PointCt
         }
     }
 }
-// direction from secondary camera v to the point (VipNeRF01.py:218-226)
-__device__ __forceinline__ void secondary_dir(const PointSrc &s, const PointCtx &c, int v, float out[3]) {
-    if (!s.rays_mode) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) out[i] = s.dirs2[(c.p * s.V + v) * 3 + i];
-        return;
-    }
+// the rays-mode arithmetic of secondary_dir with the secondary camera's origin already in registers (callers that load it ahead of use)
+__device__ __forceinline__ void secondary_dir_from(const PointSrc &s, const PointCtx &c, const float (&o2)[3], float out[3]) {
     float t = c.z;
     if (s.ndc) {
         const float tn = __fdiv_rn(-(1.f + c.o[2]), c.d[2]);
@@ -222,12 +217,24 @@ __device__ __forceinline__ void secondary_dir(const PointSrc &s, const PointCtx 
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const float pt = __fadd_rn(c.o[i], __fmul_rn(t, c.d[i]));
-        w[i] = __fsub_rn(pt, s.rays_o2[(c.n * s.V + v) * 3 + i]);
+        w[i] = __fsub_rn(pt, o2[i]);
         n2 = __fadd_rn(n2, __fmul_rn(w[i], w[i]));
     }
     const float nrm = sqrtf(n2);
 #pragma unroll
     for (int i = 0; i < 3; ++i) out[i] = __fdiv_rn(w[i], nrm);
+}
+// direction from secondary camera v to the point (VipNeRF01.py:218-226)
+__device__ __forceinline__ void secondary_dir(const PointSrc &s, const PointCtx &c, int v, float out[3]) {
+    if (!s.rays_mode) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) out[i] = s.dirs2[(c.p * s.V + v) * 3 + i];
+        return;
+    }
+    float o2[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o2[i] = s.rays_o2[(c.n * s.V + v) * 3 + i];
+    secondary_dir_from(s, c, o2, out);
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }

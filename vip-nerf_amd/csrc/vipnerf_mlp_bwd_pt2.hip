@@ -16,6 +16,9 @@ __device__ __forceinline__ float mask_apply_pt2(float x, unsigned m0, unsigned m
     return __uint_as_float(__float_as_uint(x) & (unsigned)sel);
 }
 
+TS_DECL(g_pt2_timeline_bwd);
+#define TSB(tag) TS_AT(g_pt2_timeline_bwd, tag)
+
 template <bool F16>
 __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_bwd_pt2(MlpBwdArgs a) {
     typedef BnPlan<1> PL;
@@ -44,6 +47,28 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_bwd_pt2(MlpBwdArgs a) {
         grp[pt] = (int64_t)blockIdx.x * (PT2_PTS_PER_WG / 16) + wave * 2 + pt;
     }
 
+    TS_INIT();
+    TSB(TS_ENTRY);
+    // Every scalar input of the view-branch head below -- outputs, their upstream gradients, the view layer's ReLU bits; both point tiles,
+    // directions 0 and 1 -- loaded FIRST: under the step's store traffic a global load takes thousands of cycles to come back, and the head
+    // used to pay that once per point tile and direction with the MFMA pipe idle (22 % of the workgroup's time, profiles/r04_ablation_pt2.md
+    // 5).  Here they land behind the weight image's resident block.
+    const float *gb = a.bwd;
+    float h_y[2][4], h_dy[2][4], h_sig[2], h_dsg[2], h_y2[2] = {0.f, 0.f}, h_dy2[2] = {0.f, 0.f};
+    unsigned h_gm[2][2] = {{0u, 0u}, {0u, 0u}};
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+        const int64_t pp = p[pt];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { h_y[pt][c] = a.rgb[3 * pp + c]; h_dy[pt][c] = gb[a.bl.drgb + 3 * pp + c]; }
+        h_y[pt][3] = a.vis[pp]; h_dy[pt][3] = gb[a.bl.dvis + pp];
+        h_sig[pt] = a.sigma[pp]; h_dsg[pt] = gb[a.bl.dsig + pp];
+        h_gm[pt][0] = ((const unsigned *)(a.acts + a.al.g[0] + (size_t)a.src.P * (WV / 2)))[(size_t)pp * 4 + q];
+        if (V >= 1) {
+            h_y2[pt] = a.vis2[pp * V]; h_dy2[pt] = gb[a.bl.dvis2 + pp * V];
+            h_gm[pt][1] = ((const unsigned *)(a.acts + a.al.g[1] + (size_t)a.src.P * (WV / 2)))[(size_t)pp * 4 + q];
+        }
+    }
     const int store_phase = pt2_store_phase(wave);
     typename StreamOf<PL, false>::type ws;
     ws.start(a.packed + PL::PK_BWD, PL::B_STAGES, stage_buf, lane, wave);
@@ -54,8 +79,8 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_bwd_pt2(MlpBwdArgs a) {
         for (int i = tid; i < PL::R_TOTAL_PAD / 4; i += PL::WG) l4[i] = g4[i];
     }
     __syncthreads();
+    TSB(TS_RESIDENT);
 
-    const float *gb = a.bwd;
     BT bin[8][NS];
     float dsig_raw[2];
 
@@ -65,26 +90,25 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_bwd_pt2(MlpBwdArgs a) {
         const int64_t pp = p[pt];
         float dq0[4];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float y = a.rgb[3 * pp + c];
-            dq0[c] = gb[a.bl.drgb + 3 * pp + c] * gs * ((1.f - y) * y);
-        }
-        {
-            const float y = a.vis[pp];
-            dq0[3] = gb[a.bl.dvis + pp] * gs * ((1.f - y) * y);
-        }
-        dsig_raw[pt] = a.sigma[pp] > 0.f ? gb[a.bl.dsig + pp] * gs : 0.f;
+        for (int c = 0; c < 4; ++c) dq0[c] = h_dy[pt][c] * gs * ((1.f - h_y[pt][c]) * h_y[pt][c]);
+        dsig_raw[pt] = h_sig[pt] > 0.f ? h_dsg[pt] * gs : 0.f;
         floatx4 vsum[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) vsum[t] = (floatx4)(0.f);
 #pragma unroll 1
         for (int dsel = 0; dsel <= V; ++dsel) {
             float dq[4];
-            if (dsel == 0) { dq[0] = dq0[0]; dq[1] = dq0[1]; dq[2] = dq0[2]; dq[3] = dq0[3]; }
+            unsigned gmask;
+            if (dsel == 0) { dq[0] = dq0[0]; dq[1] = dq0[1]; dq[2] = dq0[2]; dq[3] = dq0[3]; gmask = h_gm[pt][0]; }
             else {
-                const float y = a.vis2[pp * V + (dsel - 1)];
+                float y = h_y2[pt], dy = h_dy2[pt];
+                gmask = h_gm[pt][1];
+                if (dsel >= 2) {             // directions beyond the first secondary one: loaded here
+                    y = a.vis2[pp * V + (dsel - 1)]; dy = gb[a.bl.dvis2 + pp * V + (dsel - 1)];
+                    gmask = ((const unsigned *)(a.acts + a.al.g[dsel] + (size_t)a.src.P * (WV / 2)))[(size_t)pp * 4 + q];
+                }
                 dq[0] = dq[1] = dq[2] = 0.f;
-                dq[3] = gb[a.bl.dvis2 + pp * V + (dsel - 1)] * gs * ((1.f - y) * y);
+                dq[3] = dy * gs * ((1.f - y) * y);
             }
             if (valid[pt] && !EXP_NO_EXTRAS) {     // head seeds as a 16-column T16 tile: columns 0..3 d(pre-sigmoid rgb, vis), column 4 d(sigma_raw) (direction 0), zeros
                 const float x8[8] = {dq[0], dq[1], dq[2], dq[3], dsel == 0 ? dsig_raw[pt] : 0.f, 0.f, 0.f, 0.f};
@@ -96,7 +120,6 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_bwd_pt2(MlpBwdArgs a) {
                 const u2 mine = {q == 0 ? w[0] : (q == 1 ? w[2] : 0u), q == 0 ? w[1] : (q == 1 ? w[3] : 0u)};
                 __builtin_nontemporal_store(mine, (u2 *)((char *)(a.bwd + a.bl.dq[dsel]) + (size_t)grp[pt] * 512 + j * 32 + q * 8));
             }
-            const unsigned gmask = ((const unsigned *)(a.acts + a.al.g[dsel] + (size_t)a.src.P * (WV / 2)))[(size_t)pp * 4 + q];
             floatx4 dprev = (floatx4)(0.f);
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -130,14 +153,18 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_bwd_pt2(MlpBwdArgs a) {
         }
     }
 
+    TSB(TS_HEAD);                            // heads and view hidden layer of both point tiles, every direction
     // ---------------------------------------------------------------- d(feature) = W_vf^T sum_a dYv_a   (K = 128: 4 k-steps)
     AT acc[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) { acc[t].v[0] = (floatx4)(0.f); acc[t].v[1] = (floatx4)(0.f); }
 #pragma unroll
     for (int jj = 0; jj < PL::ST_VIEW_B; ++jj) {
+        TSB(TS_PRE);
         const float *st = ws.wait();
+        TSB(TS_POST);
         gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
+        TSB(TS_END);
     }
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt)
@@ -160,9 +187,12 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_bwd_pt2(MlpBwdArgs a) {
 #pragma unroll
         for (int jj = 0; jj < PL::ST_256; ++jj) {
             // younger than the stage's DMA: the deferred stores behind the stage before (nothing reliable before the first layer)
+            TSB(TS_PRE);
             const float *st = jj == 0 ? ws.template wait<2 * T16_SPK * S_PER_STAGE, 0>(it == 0) : ws.template wait<2 * T16_SPK * S_PER_STAGE>();
+            TSB(TS_POST);
             DeferredT16<FR, S_PER_STAGE> ds{a.bwd + (it == 0 ? a.bl.dyf : a.bl.dy[layer + 1]), {grp[0], grp[1]}, {valid[0], valid[1]}, j, q, S_PER_STAGE * jj, bin, store_phase};
             gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws, ds);
+            TSB(TS_END);
         }
         float *dst = a.bwd + a.bl.dy[layer];
         // ReLU bits applied AFTER the conversion, two gradients per instruction (vipnerf_mlp_pt2.h mask_pk16): 2.25 VALU instructions
@@ -198,6 +228,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_bwd_pt2(MlpBwdArgs a) {
             }
         }
     }
+    TSB(TS_LAST);
     if (EXP_NO_EXTRAS) {          // timing-only builds without stores: keep the whole chain alive (a store that never happens)
         typedef unsigned u4 __attribute__((ext_vector_type(4)));
         unsigned x = 0u;
@@ -208,6 +239,12 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_bwd_pt2(MlpBwdArgs a) {
         if (x == 0x7fc12345u) a.bwd[a.bl.dy[0]] = 1.f;
     }
 }
+
+#if defined(VN_EXP) && VN_EXP == 50
+extern "C" int vipnerf_exp_timeline_bwd(unsigned long long *out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pt2_timeline_bwd), sizeof(unsigned long long) * (n < 1024 ? n : 1024));
+}
+#endif
 
 template <bool F16>
 static int launch_bwd_pt2(const MlpBwdArgs &a, hipStream_t st) {

@@ -16,14 +16,8 @@
 
 namespace vn {
 
-// VN_EXP == 50 (timing experiment: tools/pt2_timeline.py): one workgroup in the middle of the grid records s_memtime at the kernel's phase
-// boundaries, per wave, into a device array that vipnerf_exp_timeline() copies out.  TS() is nothing in every other build.
-#if defined(VN_EXP) && VN_EXP == 50
-__device__ unsigned long long g_pt2_timeline[8 * 128];
-#define TS() do { if (ts_rec) { g_pt2_timeline[wave * 128 + (ts_n < 127 ? ts_n : 127)] = __builtin_readcyclecounter(); ++ts_n; } } while (0)
-#else
-#define TS() do { } while (0)
-#endif
+TS_DECL(g_pt2_timeline);
+#define TS(tag) TS_AT(g_pt2_timeline, tag)
 
 template <bool SAVE, bool F16>
 __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
@@ -42,11 +36,8 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, j = lane & 15;
-#if defined(VN_EXP) && VN_EXP == 50
-    const bool ts_rec = blockIdx.x == gridDim.x / 2 && lane == 0;
-    int ts_n = 0;
-#endif
-    TS();                                    // 0: entry
+    TS_INIT();
+    TS(TS_ENTRY);                                    // 0: entry
     int64_t p[2], grp[2];
     bool valid[2];
 #pragma unroll
@@ -173,14 +164,14 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
     };
 
     __syncthreads();                         // resident block visible
-    TS();                                    // 1: resident block in
+    TS(TS_RESIDENT);                                    // 1: resident block in
     // ---------------------------------------------------------------- layer 0: gamma(x) only (the first two k-steps of a stage whose other two are zero padding)
     // (build switches VN_PT2_TRAIN_KEEP / VN_PT2_EVAL_KEEP, vipnerf_knobs.h: gamma(x)'s fragments kept in registers up to layer 5, or reloaded / evaluated again)
     BT bpe_keep[2][NS];
     {
         BT bpe[2][NS];
         encode_pe(bpe);
-        TS();                                // 2: gamma(x) encoded
+        TS(TS_HEAD);                                // 2: gamma(x) encoded
         if ((!SAVE && VN_PT2_EVAL_KEEP) || (SAVE && VN_PT2_TRAIN_KEEP)) { bpe_keep[0][0] = bpe[0][0]; bpe_keep[1][0] = bpe[1][0]; }
         if (SAVE) {
 #pragma unroll
@@ -194,11 +185,11 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
             }
         }
         init_acc(0);
-        TS();
+        TS(TS_PRE);
         const float *st = ws.template wait<SAVE ? 4 : 0>();      // behind gamma(x)'s own stores
-        TS();
+        TS(TS_POST);
         gemm_stage_bf<16, 2, NS>(st, lane, acc, bpe, 0, ws);
-        TS();
+        TS(TS_END);
         epilogue(0);
     }
     // ---------------------------------------------------------------- layers 1..7 + feature layer (8)
@@ -208,16 +199,16 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
 #pragma unroll
         for (int jj = 0; jj < PL::ST_256; ++jj) {
             // younger than this stage's DMA: the mask stores of the previous epilogue (first stage), the deferred stores behind the stage before
-            TS();
+            TS(TS_PRE);
             const float *st = jj == 0 ? ws.template wait<SAVE ? 2 : 0>() : ws.template wait<SAVE ? 2 * T16_SPK * S_PER_STAGE : 0>();
-            TS();
+            TS(TS_POST);
             if (SAVE) {
                 DeferredT16<FR, S_PER_STAGE> ds{a.acts + a.al.h[layer - 1], {grp[0], grp[1]}, {valid[0], valid[1]}, j, q, S_PER_STAGE * jj, bin, store_phase};
                 gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws, ds);
             } else {
                 gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
             }
-            TS();
+            TS(TS_END);
         }
         if (layer == SKIP_LAYER) {           // gamma(x) columns last: h's operand registers are dead by then
             BT bpe[2][NS];
@@ -236,11 +227,11 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
             } else {
                 encode_pe(bpe);              // eval: evaluated again rather than held in 16 registers across layers 1..4
             }
-            TS();
+            TS(TS_PRE);
             const float *st = ws.template wait<SAVE ? 2 * T16_SPK * S_PER_STAGE : 0>();      // behind the deferred stores of the stage before
-            TS();
+            TS(TS_POST);
             gemm_stage_bf<16, 2, NS>(st, lane, acc, bpe, 0, ws);
-            TS();
+            TS(TS_END);
         }
         epilogue(layer);
 #if defined(VN_EXP) && VN_EXP == 47
@@ -272,10 +263,24 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
         vb[t].v[0] = b; vb[t].v[1] = b;
     }
     static_assert(PL::ST_VIEW_F == 1, "the feature's deferred stores assume one view stage");
+    PointCtx pc0, pc1;
+    float sec0[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     {
-        TS();
+        TS(TS_PRE);
         const float *st = ws.template wait<SAVE ? 2 * T16_SPK * S_PER_STAGE : 0>();      // behind the deferred stores of the feature layer's last stage
-        TS();
+        TS(TS_POST);
+        // the per-direction tail's global loads (the ray behind each point tile, the first secondary view's origin / direction) issued
+        // HERE, behind the last counted wait: they come back during the stage instead of stalling the tail, which runs with the MFMA pipe
+        // idle (and under the training step's store traffic a load is thousands of cycles).  Training only: the eval kernel's loads come
+        // back fast and it measured 3 % slower with them up here (profiles/r04_ablation_pt2.md 5).
+        if (SAVE) { load_point(a.src, p[0], pc0); load_point(a.src, p[1], pc1); }
+        if (SAVE && a.src.V >= 1) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                sec0[0][i] = a.src.rays_mode ? a.src.rays_o2[(pc0.n * a.src.V) * 3 + i] : a.src.dirs2[(pc0.p * a.src.V) * 3 + i];
+                sec0[1][i] = a.src.rays_mode ? a.src.rays_o2[(pc1.n * a.src.V) * 3 + i] : a.src.dirs2[(pc1.p * a.src.V) * 3 + i];
+            }
+        }
         if (SAVE) {          // the feature (= this GEMM's B operand) leaves from inside the stage like h_1..h_8
             DeferredT16<FR, 8> ds{a.acts + a.al.feat, {grp[0], grp[1]}, {valid[0], valid[1]}, j, q, 0, bin, store_phase};
             gemm_stage_bf<8, PL::KSV, NS>(st, lane, vb, bin, 0, ws, ds);
@@ -284,16 +289,28 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
         }
     }
 
-    TS();                                    // view stage done
+    TS(TS_VIEW);                                    // view stage done
     // ... then per point tile and direction a K = 32 GEMM from the LDS-resident direction columns, ReLU, the 128 -> 4 head
 #pragma unroll 1
     for (int pt = 0; pt < 2; ++pt) {
-        PointCtx pc;
-        load_point(a.src, p[pt], pc);
+        PointCtx pc;                         // field by field: a struct select goes through scratch memory
+        if (!SAVE) load_point(a.src, p[pt], pc);
+        else
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            pc.x[i] = pt == 0 ? pc0.x[i] : pc1.x[i]; pc.dir[i] = pt == 0 ? pc0.dir[i] : pc1.dir[i];
+            pc.o[i] = pt == 0 ? pc0.o[i] : pc1.o[i]; pc.d[i] = pt == 0 ? pc0.d[i] : pc1.d[i];
+        }
+        if (SAVE) { pc.z = pt == 0 ? pc0.z : pc1.z; pc.p = pt == 0 ? pc0.p : pc1.p; pc.n = pt == 0 ? pc0.n : pc1.n; }
+        const float s0[3] = {pt == 0 ? sec0[0][0] : sec0[1][0], pt == 0 ? sec0[0][1] : sec0[1][1], pt == 0 ? sec0[0][2] : sec0[1][2]};
 #pragma unroll 1
         for (int dsel = 0; dsel <= a.src.V; ++dsel) {
             float dir[3];
             if (dsel == 0) { dir[0] = pc.dir[0]; dir[1] = pc.dir[1]; dir[2] = pc.dir[2]; }
+            else if (SAVE && dsel == 1) {
+                if (a.src.rays_mode) secondary_dir_from(a.src, pc, s0, dir);
+                else { dir[0] = s0[0]; dir[1] = s0[1]; dir[2] = s0[2]; }
+            }
             else secondary_dir(a.src, pc, dsel - 1, dir);
             float ped[1][8];
             encode_d16<VN_PT2_FAST_PE != 0>(dir, q, ped);
@@ -357,7 +374,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
             }
         }
     }
-    TS();                                    // last: view tail done
+    TS(TS_LAST);                                    // last: view tail done
 }
 
 #if defined(VN_EXP) && VN_EXP == 50

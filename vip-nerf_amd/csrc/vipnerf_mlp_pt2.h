@@ -62,6 +62,20 @@ __device__ __forceinline__ int pt2_store_phase(int wave) {
     return (NPH - 1) - (((w >> 2) * (NPH / 2) + (w & (NPH / 2 - 1))) % NPH);
 }
 
+// VN_EXP == 50 (timing experiment: tools/pt2_timeline.py): one workgroup in the middle of the grid records s_memtime at the kernel's phase
+// boundaries, per wave, with a tag in the top byte (TS_ENTRY ...), into a device array that vipnerf_exp_timeline() / _bwd() copy out.
+// TS(tag) is nothing in every other build.
+enum { TS_ENTRY = 0, TS_RESIDENT = 1, TS_HEAD = 2, TS_PRE = 3, TS_POST = 4, TS_END = 5, TS_VIEW = 6, TS_LAST = 7 };
+#if defined(VN_EXP) && VN_EXP == 50
+#define TS_DECL(buf) __device__ unsigned long long buf[8 * 128]
+#define TS_INIT() const bool ts_rec = blockIdx.x == gridDim.x / 2 && lane == 0; int ts_n = 0
+#define TS_AT(buf, tag) do { if (ts_rec) { buf[wave * 128 + (ts_n < 127 ? ts_n : 127)] = ((unsigned long long)(tag) << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull); ++ts_n; } } while (0)
+#else
+#define TS_DECL(buf)
+#define TS_INIT() do { } while (0)
+#define TS_AT(buf, tag) do { } while (0)
+#endif
+
 // ReLU with a runtime bound (0, or "none") as the two-point-tile kernels' epilogues evaluate it.  fp16 fragments: the compare-and-select
 // form of relu_lo<true> -- NaN (of either sign: the MFMA's inf - inf has its sign bit set) passes through, out-of-range inputs fail loudly
 // (tests/test_hip_bf16.py::test_fp16x3_range).  bf16 fragments (fp32's exponent range: nothing overflows on the way): a signed-integer

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_bwd_pt2(MlpBwdArgs a) {
                 float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
+                    if (c < 3 && dsel != 0) continue;      // a secondary direction seeds the visibility output only (its other dq are +0: the same bits)
                     const float4 w4 = *(const float4 *)(rf + PL::N_WOUT + c * WV + 16 * t + 4 * q);
                     dg.x = fmaf(w4.x, dq[c], dg.x); dg.y = fmaf(w4.y, dq[c], dg.y);
                     dg.z = fmaf(w4.z, dq[c], dg.z); dg.w = fmaf(w4.w, dq[c], dg.w);

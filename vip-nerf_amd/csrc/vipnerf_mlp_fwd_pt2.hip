@@ -330,15 +330,25 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) g[t][r] = relu_pt2<F16>(g[t][r] * AU, 0.f, 0);
             if (SAVE && valid[pt] && !EXP_NO_EXTRAS) {
-                unsigned gm = 0u;
+                unsigned gm = 0u, cb[4];
+                unsigned one2 = 0x00010001u;
+                asm volatile("" : "+s"(one2));
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     FR gh[NS];
                     split_pair<NS>(g[2 * s], g[2 * s + 1], gh);
                     store_t16(a.acts + a.al.g[dsel], grp[pt], 8, s, j, q, gh[0]);
-                    gm = push_nibble(gm, positive_nibble(g[2 * s]));
-                    gm = push_nibble(gm, positive_nibble(g[2 * s + 1]));
+                    if constexpr (!F16 && NS == 1) {       // bf16: the ReLU bits from the packed halves, two values per instruction (like the trunk's)
+                        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                        const u4 w4 = __builtin_bit_cast(u4, gh[0]);
+                        const unsigned w[4] = {w4[0], w4[1], w4[2], w4[3]};
+                        cb[s] = positive_pk_bits(w, one2);
+                    } else {
+                        gm = push_nibble(gm, positive_nibble(g[2 * s]));
+                        gm = push_nibble(gm, positive_nibble(g[2 * s + 1]));
+                    }
                 }
+                if constexpr (!F16 && NS == 1) gm = fold_pk_bits(cb[0], cb[1]) | (fold_pk_bits(cb[2], cb[3]) << 16);
                 ((unsigned *)(a.acts + a.al.g[dsel] + (size_t)a.src.P * (WV / 2)))[(size_t)p[pt] * 4 + q] = gm;
                 typedef unsigned u4 __attribute__((ext_vector_type(4)));
                 char *row = (char *)(a.acts + a.al.ped[dsel]) + ((size_t)grp[pt] * 2 + (q >> 1)) * 512 + j * 32 + (q & 1) * 16;

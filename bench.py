@@ -302,6 +302,14 @@ def roofline_block(prec, prof, steps, rays, ms_per_step, sclk_mhz, n_sec=1, work
         mb = tr.get('mfma_busy', {})
         if mb:
             r['mfma_busy_pmc'] = mb
+        # the same stages against the HBM roofline: PMC bytes of the stage / its device time in THIS run (a stage that moves its bytes at
+        # the part's measured plateau -- 5.5-5.9 TB/s written, 6-6.3 read -- is HBM-bound whatever its MFMA fraction says)
+        hv = {}
+        for g, b in tr['bytes_per_step'].items():
+            ms = wg_ms if g == 'wgrad' else stage_ms.get(g, 0.0)
+            if ms > 0:
+                hv[g] = {'bytes': b['total'], 'gb_per_s': round(b['total'] / (ms * 1e-3) / 1e9, 1), 'frac_of_8000': round(b['total'] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        r['hbm_view'] = hv
     return r
 
 

@@ -1,7 +1,8 @@
 """Where one workgroup of k_mlp_fwd_pt2 / k_mlp_bwd_pt2 spends its cycles (experiment build -DVN_EXP=50: s_memtime at the phase boundaries,
 per wave, tagged -- vipnerf_mlp_pt2.h TS_AT):
     tools/build_variant.sh exp50 "-DVN_EXP=50" vipnerf_mlp_fwd_pt2 vipnerf_mlp_bwd_pt2
-    VIPNERF_HIP_LIB=vip-nerf_amd/lib/libvipnerf_hip_exp50.so python tools/pt2_timeline.py [eval|train|bwd]
+    VIPNERF_HIP_LIB=vip-nerf_amd/lib/libvipnerf_hip_exp50.so [HIP_PRECISION=fp32] python tools/pt2_timeline.py [eval|train|bwd]
+(HIP_PRECISION=fp32: the 16-point exact-fp32 forward kernel k_mlp_fwd_bf16n, eval / train)
 The recorded workgroup is the one in the middle of the FINE level's grid of the last launch."""
 import ctypes as C, os, sys, warnings
 warnings.filterwarnings('ignore')
@@ -44,7 +45,8 @@ if mode == 'bwd':
         ops.render_backward(cfg, bd, pc, pf, c, f, g, gfine, acts, bwd_ws, gc, gf)
 torch.cuda.synchronize()
 lib = L.load()
-fn = lib.vipnerf_exp_timeline_bwd if mode == 'bwd' else lib.vipnerf_exp_timeline
+narrow = os.environ.get('HIP_PRECISION', 'bf16') not in ('bf16', 'fp16')      # the 16-point kernels (exact fp32, split arithmetics): forward only
+fn = lib.vipnerf_exp_timeline_n if narrow else (lib.vipnerf_exp_timeline_bwd if mode == 'bwd' else lib.vipnerf_exp_timeline)
 fn.restype = C.c_int
 buf = (C.c_ulonglong * 1024)()
 assert fn(buf, 1024) == 0
@@ -75,4 +77,4 @@ for w in range(8):
         print('        per stage (wait, loop):', ' '.join(f'{a}/{b}' for a, b in stages))
 m = {k: int(np.mean([r[k] for r in rows])) for k in rows[0]}
 print('mean over waves:', m, '| shares of total:', {k: round(v / m['total'], 3) for k, v in m.items() if k != 'total'})
-print('MFMA pipe time of the workgroup per SIMD at 16 cycles per MFMA: 2 waves x %d MFMAs x 16 = %d' % ((2176 if mode == 'bwd' else 2336), 2 * 16 * (2176 if mode == 'bwd' else 2336)))
+if not narrow: print('MFMA pipe time of the workgroup per SIMD at 16 cycles per MFMA: 2 waves x %d MFMAs x 16 = %d' % ((2176 if mode == 'bwd' else 2336), 2 * 16 * (2176 if mode == 'bwd' else 2336)))

@@ -5,6 +5,7 @@
 #include <type_traits>
 #include "vipnerf_bf16n.h"
 #include "vipnerf_mlp.h"
+#include "vipnerf_mlp_pt2.h"
 
 // build switch VN_F32_DEFER (default 1, vipnerf_knobs.h): exact-fp32 narrow kernels: activation / gradient stores leave from the next GEMM's stages (H16 = 3)
 
@@ -19,6 +20,9 @@ namespace vn {
 // h_1..h_8, the feature, the view hidden and its ReLU bits per direction, gamma(x) / gamma(dir) in their slot order -- written from the
 // B fragments the GEMMs consume anyway.
 // F32: exact-fp32 fragments (f32q, vipnerf_bf16.h): v_mfma_f32_16x16x4_f32, one MFMA per product, no split, no scaling.
+TS_DECL(g_n_timeline);
+#define TSN(tag) TS_AT(g_n_timeline, tag)
+
 template <bool SAVE, int NS, bool F16, int H16 = 0, bool F32 = false>
 __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) {
     typedef BnPlan<NS> PL;
@@ -43,6 +47,8 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
     const int64_t p = valid ? p_raw : a.src.P - 1;
     const int64_t grp = (int64_t)blockIdx.x * (MLP_PTS_PER_WG / 16) + wave;   // T16: this wave's 16-point group (valid is wave-uniform: P % 16 == 0)
 
+    TS_INIT();
+    TSN(TS_ENTRY);
     typename std::conditional<F32 && !SAVE, typename StreamShared<PL>::type, typename StreamOf<PL, PL::SKEW>::type>::type ws;
     ws.start(a.packed + PL::PK_FWD, PL::F_STAGES, stage_buf, lane, wave);
     stream_counted(ws, !T16 || valid);      // a wave beyond P skips its (predicated) T16 stores: its counted waits would not hold
@@ -72,6 +78,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
 
     // ---------------------------------------------------------------- trunk (layers 0..7) + feature layer (8)
     __syncthreads();                         // resident block visible
+    TSN(TS_RESIDENT);
     stream_begin(ws);
 #pragma unroll 1
     for (int layer = 0; layer < 9; ++layer) {
@@ -87,13 +94,16 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             for (int jj = 0; jj < PL::ST_256; ++jj) {
                 // younger than the stage's DMA -- first stage: the previous layer's epilogue (>= 16 tile stores, or just
                 // the mask store when the tiles are deferred); later stages: the deferred stores behind the stage before
+                TSN(TS_PRE);
                 const float *st = jj == 0 ? ws.template wait<DEFER ? 1 : EPI_STORES>() : ws.template wait<DEFER ? DEF_SPK * S_PER_STAGE : 0>();
+                TSN(TS_POST);
                 if (DEFER) {                             // bin = the fp16 parts of h_layer, the output of layer - 1
                     DeferredStores<H16, NS, FR, S_PER_STAGE> ds{a.acts + a.al.h[layer - 1], p, q, wave, S_PER_STAGE * jj, bin, grp, j, valid};
                     gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws, ds);
                 } else {
                     gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
                 }
+                TSN(TS_END);
             }
         }
         if (layer == 0 || layer == SKIP_LAYER) {         // gamma(x) columns last: bin is dead, its registers hold bpe
@@ -113,8 +123,11 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             }
 #pragma unroll
             for (int jj = 0; jj < PL::ST_PE; ++jj) {
+                TSN(TS_PRE);
                 const float *st = ws.wait();
+                TSN(TS_POST);
                 gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bpe, PL::KSB * jj, ws);
+                TSN(TS_END);
             }
         }
         // epilogue: ReLU (trunk), activation store, mask, sigma head, split into the next layer's B fragments.
@@ -192,8 +205,11 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
     }
 #pragma unroll
     for (int jj = 0; jj < PL::ST_VIEW_F; ++jj) {
+        TSN(TS_PRE);
         const float *st = jj == 0 ? ws.template wait<EPI_STORES>() : ws.template wait<0>();   // behind the feature layer's epilogue
+        TSN(TS_POST);
         gemm_stage_bf<8, PL::KSV, NS>(st, lane, vb, bin, PL::KSV * jj, ws);
+        TSN(TS_VIEW);
     }
     stream_end(ws);
 
@@ -276,7 +292,14 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             }
         }
     }
+    TSN(TS_LAST);
 }
+
+#if defined(VN_EXP) && VN_EXP == 50
+extern "C" int vipnerf_exp_timeline_n(unsigned long long *out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_n_timeline), sizeof(unsigned long long) * (n < 1024 ? n : 1024));
+}
+#endif
 
 template <bool SAVE, int NS, bool F16 = false, int H16 = 0, bool F32 = false>
 static int launch_one_n(const MlpFwdArgs &a, unsigned grid, hipStream_t st) {

@@ -302,24 +302,57 @@ __global__ __launch_bounds__(RAY_WG) void k_sample_fine(SampleArgs a) {
         for (int i = 0; i < 8; ++i) f = __fadd_rn(f, __shfl(part, i, 64));
         tot = f;
     }
-    // cdf = torch.cumsum(pdf): the CPU kernel accumulates float inputs in double and rounds each output
-    double run = 0.0;
-    for (int k = 0; k < NW; ++k) {
-        run += (double)__fdiv_rn(cdf[1 + k], tot);
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) cdf[1 + k] = (float)run;
+    // cdf = torch.cumsum(pdf): the CPU kernel accumulates float inputs in double and rounds each output.  The divisions in parallel
+    // (lane k + 64 i holds pdf[k + 64 i]), then the serial chain on registers alone: v_readlane of the next pdf, one double add, the
+    // rounded sum kept by the lane that owns the element -- no LDS round trip and no division inside the chain (it was 62 x ~400 cycles).
+    {
+        constexpr int MAXR = 16;                   // NW <= 1021 (vipnerf_sample_fine: n_coarse + n_fine <= 1024)
+        float pdfr[MAXR], outr[MAXR];
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int k = lane + 64 * i;
+            pdfr[i] = k < NW ? __fdiv_rn(cdf[1 + k], tot) : 0.f;
+            outr[i] = 0.f;
+        }
+        double run = 0.0;
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int cntk = min(64, NW - 64 * i);
+            for (int l = 0; l < cntk; ++l) {
+                run += (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(pdfr[i]), l));
+                if (lane == l) outr[i] = (float)run;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();          // every lane has read its w before anyone overwrites the slots
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int k = lane + 64 * i;
+            if (k < NW) cdf[1 + k] = outr[i];
+        }
     }
     if (lane == 0) cdf[0] = 0.f;
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
+
+    // z_coarse ascending (it is, for near <= far: stratified samples of increasing bins)?  Then a value's rank among the coarse depths is a
+    // binary search instead of Sc compares; any other input takes the general count below.
+    bool asc = true;
+    for (int k = lane; k + 1 < Sc; k += 64) asc = asc && (vals[k] <= vals[k + 1]);
+    asc = __all(asc);
 
     for (int jj = lane; jj < Sf; jj += 64) {
         float u;
         if (a.u) u = a.u[nn * Sf + jj];
         else if (a.device_rng) u = rng_uniform(a.seed, a.offset, RS_U, (a.ray_ids ? (uint64_t)a.ray_ids[nn] : a.ray_base + (uint64_t)nn) * (uint64_t)Sf + (uint64_t)jj);
         else u = linspace01(jj, Sf);
-        int cnt = 0;                                           // searchsorted(cdf, u, right=True): #{cdf <= u}
-        for (int k = 0; k < NB; ++k) cnt += (cdf[k] <= u) ? 1 : 0;
+        // searchsorted(cdf, u, right=True) = #{cdf <= u}: the cdf is a rounded running sum of positive terms, i.e. non-decreasing -- upper bound
+        // by bisection (8 steps for 255 bins instead of 255 compares); a NaN cdf (NaN weights) compares false everywhere in both forms' first step
+        int lo_i = 0, hi_i = NB;
+        while (lo_i < hi_i) {
+            const int mid = (lo_i + hi_i) >> 1;
+            if (cdf[mid] <= u) lo_i = mid + 1; else hi_i = mid;
+        }
+        const int cnt = lo_i;
         const int lo = max(cnt - 1, 0), hi = min(cnt, NB - 1);
         const float cl = cdf[lo], ch = cdf[hi], bl = bins[lo], bh = bins[hi];
         float dnm = __fsub_rn(ch, cl);
@@ -334,11 +367,27 @@ __global__ __launch_bounds__(RAY_WG) void k_sample_fine(SampleArgs a) {
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
-    // stable rank sort of the Sc+Sf values (torch.sort of the concatenation, values only)
+    // stable rank sort of the Sc+Sf values (torch.sort of the concatenation, values only): rank = #{o < v} + #{o == v, earlier index}
     for (int i = lane; i < ST; i += 64) {
         const float v = vals[i];
         int rank = 0;
-        for (int k = 0; k < ST; ++k) {
+        int k0 = 0;
+        if (asc) {
+            // among the ascending coarse depths: a coarse element's rank is its own index (ties are contiguous and the earlier ones are exactly
+            // those before it); a sample's is #{o <= v} (every coarse index is earlier)
+            if (i < Sc) rank = i;
+            else {
+                int lo_i = 0, hi_i = Sc;
+                while (lo_i < hi_i) {
+                    const int mid = (lo_i + hi_i) >> 1;
+                    if (vals[mid] <= v) lo_i = mid + 1; else hi_i = mid;
+                }
+                rank = lo_i;
+            }
+            k0 = Sc;
+        }
+#pragma unroll 8
+        for (int k = k0; k < ST; ++k) {           // (unrolled: eight LDS reads in flight instead of one)
             const float o = vals[k];
             rank += (o < v || (o == v && k < i)) ? 1 : 0;
         }

@@ -134,7 +134,8 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
         // Kept free of per-tile branches on `layer`: ReLU is a max with a per-layer bound (0, or -inf for the feature
         // layer), the sigma head is one block for layer 7.
         const float lo = relu_bound<F16>(layer < 8);
-        const int lo_i = layer < 8 ? 0 : (int)0x80000000;      // the bound of relu_bits (exact-fp32 training: the ReLU as one integer max)
+        int lo_i = layer < 8 ? 0 : (int)0x80000000;            // the bound of relu_bits (exact-fp32 training: the ReLU as one integer max)
+        asm volatile("" : "+s"(lo_i));                           // one SGPR operand: the compiler otherwise emits max(x, 0) AND a select on `layer` per value
         if (layer == 7) {
             float sg[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

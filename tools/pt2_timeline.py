@@ -51,13 +51,13 @@ fn.restype = C.c_int
 buf = (C.c_ulonglong * 1024)()
 assert fn(buf, 1024) == 0
 raw = np.array(buf, dtype=np.uint64).reshape(8, 128)
-ENTRY, RESIDENT, HEAD, PRE, POST, END, VIEW, LAST = range(8)
+ENTRY, RESIDENT, HEAD, PRE, POST, END, VIEW, LAST, EPI_A, EPI_B = range(10)
 print(f'{mode} {os.environ.get("HIP_PRECISION", "bf16")}: cycles (s_memtime ticks) of the recorded workgroup, per wave')
 rows = []
 for w in range(8):
     ev = [(int(x >> np.uint64(56)), int(x & np.uint64((1 << 56) - 1))) for x in raw[w] if x]
     assert ev[0][0] == ENTRY and ev[-1][0] == LAST, [e[0] for e in ev]
-    rec = {'resident': 0, 'head': 0, 'wait': 0, 'gemm': 0, 'between': 0, 'tail': 0}
+    rec = {'resident': 0, 'head': 0, 'wait': 0, 'gemm': 0, 'between': 0, 'tail': 0, 'epi_operands': 0, 'epi_valu': 0}
     stages = []
     prev_tag, prev_t = ev[0]
     for tag, t in ev[1:]:
@@ -67,6 +67,8 @@ for w in range(8):
         elif tag == PRE: rec['between'] += d                # epilogue of the layer before, accumulator set-up, operand reloads
         elif tag == POST: rec['wait'] += d; stages.append([d, 0])
         elif tag in (END, VIEW): rec['gemm'] += d; stages[-1][1] = d
+        elif tag == EPI_A: rec['epi_operands'] += d; rec['between'] += d      # (backward) the epilogue's operands ready: last accumulators, ReLU bits
+        elif tag == EPI_B: rec['epi_valu'] += d; rec['between'] += d           # (backward) conversion + ReLU bits applied
         elif tag == LAST: rec['tail'] += d                  # forward: per-direction view tail; backward: the last epilogue and dY_0's stores
         prev_tag, prev_t = tag, t
     rec['total'] = ev[-1][1] - ev[0][1]

@@ -201,6 +201,10 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_bwd_pt2(MlpBwdArgs a) {
         // MFMA pipe idle: its instruction count is kernel time, profiles/r04_ablation_pt2.md 5)
         unsigned one2 = 0x00010001u;
         asm volatile("" : "+s"(one2));
+#if defined(VN_EXP) && VN_EXP == 50
+        asm volatile("" : "+v"(mk[0].x), "+v"(mk[1].x), "+v"(acc[0].v[0]), "+v"(acc[15].v[1]));     // the ReLU bits and the first / last accumulators are there
+#endif
+        TSB(TS_EPI_A);
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
             const unsigned ab[4] = {unfold_pk_bits(mk[pt].x & 0xffffu), unfold_pk_bits(mk[pt].x >> 16),
@@ -228,6 +232,10 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_bwd_pt2(MlpBwdArgs a) {
                 if (it == 7 && valid[pt] && !EXP_NO_EXTRAS) store_t16(dst, grp[pt], 16, s, j, q, t1[0]);     // dY_0 (the others leave from the next GEMM's stages)
             }
         }
+#if defined(VN_EXP) && VN_EXP == 50
+        asm volatile("" : "+v"(bin[7][0].v[1]));
+#endif
+        TSB(TS_EPI_B);
     }
     TSB(TS_LAST);
     if (EXP_NO_EXTRAS) {          // timing-only builds without stores: keep the whole chain alive (a store that never happens)

@@ -65,7 +65,7 @@ __device__ __forceinline__ int pt2_store_phase(int wave) {
 // VN_EXP == 50 (timing experiment: tools/pt2_timeline.py): one workgroup in the middle of the grid records s_memtime at the kernel's phase
 // boundaries, per wave, with a tag in the top byte (TS_ENTRY ...), into a device array that vipnerf_exp_timeline() / _bwd() copy out.
 // TS(tag) is nothing in every other build.
-enum { TS_ENTRY = 0, TS_RESIDENT = 1, TS_HEAD = 2, TS_PRE = 3, TS_POST = 4, TS_END = 5, TS_VIEW = 6, TS_LAST = 7 };
+enum { TS_ENTRY = 0, TS_RESIDENT = 1, TS_HEAD = 2, TS_PRE = 3, TS_POST = 4, TS_END = 5, TS_VIEW = 6, TS_LAST = 7, TS_EPI_A = 8, TS_EPI_B = 9 };
 #if defined(VN_EXP) && VN_EXP == 50
 #define TS_DECL(buf) __device__ unsigned long long buf[8 * 128]
 #define TS_INIT() const bool ts_rec = blockIdx.x == gridDim.x / 2 && lane == 0; int ts_n = 0

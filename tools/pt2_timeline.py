@@ -20,7 +20,7 @@ bd = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items()
 pa = vo.init_params(3)
 pc = ops.pack_weights([cu(pa['coarse_model.' + k]) for k in ops.PARAM_ORDER], precision=prec)
 pf = ops.pack_weights([cu(pa['fine_model.' + k]) for k in ops.PARAM_ORDER], precision=prec)
-train = mode in ('train', 'bwd')
+train = mode in ('train', 'bwd', 'wg')
 V = 1 if train else 0
 cfg = ops.make_config(True, 64, 128, V, train, noise_std=1.0 if train else 0.0, precision=prec, save_acts=train)
 if train:
@@ -31,8 +31,8 @@ if train:
     acts = torch.empty(ab // 4, dtype=torch.float32, device=dev)
 for _ in range(3):
     c, f, _ = ops.render_forward(cfg, bd, {'seed': 1, 'offset': 2} if train else None, pc, pf, acts)
-if mode == 'bwd':
-    os.environ['VIPNERF_EXP_SKIP_WGRAD'] = '1'
+if mode in ('bwd', 'wg'):
+    if mode == 'bwd': os.environ['VIPNERF_EXP_SKIP_WGRAD'] = '1'
     bwd_ws = torch.empty(bb // 4, dtype=torch.float32, device=dev)
     shapes = ops.param_shapes(ops.topology_of(cfg))
     gc = [torch.zeros(s, device=dev) for s in shapes]; gf = [torch.zeros(s, device=dev) for s in shapes]
@@ -45,6 +45,20 @@ if mode == 'bwd':
         ops.render_backward(cfg, bd, pc, pf, c, f, g, gfine, acts, bwd_ws, gc, gf)
 torch.cuda.synchronize()
 lib = L.load()
+if mode == 'wg':          # the exact-fp32 256 x 256 weight-gradient kernel: per 32-point block -- loads issued / MFMA loop / LDS stores / barrier
+    fn = lib.vipnerf_exp_timeline_wg; fn.restype = C.c_int
+    buf = (C.c_ulonglong * 1024)(); assert fn(buf, 1024) == 0
+    raw = np.array(buf, dtype=np.uint64).reshape(8, 128)
+    for w in range(8):
+        ev = [(int(x >> np.uint64(56)), int(x & np.uint64((1 << 56) - 1))) for x in raw[w] if x][:-1]
+        acc = {'top (next block loads issued)': [], 'mfma loop': [], 'lds stores': [], 'barrier': []}
+        prev = ev[0][1]
+        for tag, t in ev[1:]:
+            key = {4: 'top (next block loads issued)', 5: 'mfma loop', 8: 'lds stores', 3: 'barrier'}.get(tag)
+            if key: acc[key].append(t - prev)
+            prev = t
+        print(f'wave {w}:', {k: (int(np.mean(v[2:])) if len(v) > 2 else None) for k, v in acc.items()}, 'blocks', len(acc['mfma loop']))
+    sys.exit(0)
 narrow = os.environ.get('HIP_PRECISION', 'bf16') not in ('bf16', 'fp16')      # the 16-point kernels (exact fp32, split arithmetics): forward only
 fn = lib.vipnerf_exp_timeline_n if narrow else (lib.vipnerf_exp_timeline_bwd if mode == 'bwd' else lib.vipnerf_exp_timeline)
 fn.restype = C.c_int

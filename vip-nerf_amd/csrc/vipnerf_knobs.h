@@ -17,7 +17,7 @@
     X(VN_BF16_H16) X(VN_T16) X(VN_T16_X4) X(VN_T16_NT) X(VN_PT2_SPREAD) X(VN_PT2_SKEW) X(VN_PT2_G) X(VN_PT2_D)                  \
     X(VN_PT2_TRAIN_KEEP) X(VN_PT2_EVAL_KEEP) X(VN_PT2_FAST_PE)                                                                                              \
     /* weight gradients (vipnerf_wgrad.hip, vipnerf_wgrad16.hip) */                                                                       \
-    X(VN_WGRAD_DMA) X(VN_WGRAD_W8) X(VN_WGRAD_PIPE) X(VN_WGRAD_ONE_ROUND) X(VN_WGRAD_ROUNDS) X(VN_WG16_BIG_WM) X(VN_WG16_BIG_WN)        \
+    X(VN_WGRAD_LATE_LOAD) X(VN_WGRAD_LATE_STORE) X(VN_WGRAD_DMA) X(VN_WGRAD_W8) X(VN_WGRAD_PIPE) X(VN_WGRAD_ONE_ROUND) X(VN_WGRAD_ROUNDS) X(VN_WG16_BIG_WM) X(VN_WG16_BIG_WN)        \
     X(VN_WG16_BIG_NB) X(VN_WG16_HYBRID) X(VN_WG16_SIGMA_FUSED) X(VN_WG16_DMA_PIECES) X(VN_WG16_THIN_HYBRID) X(VN_WG16_BIG_SLOTS)          \
     /* optimizer (vipnerf_api.hip) */                                                                                                     \
     X(VN_ADAM_FMA_MASK)
@@ -93,6 +93,12 @@
 #endif
 #ifndef VN_PT2_FAST_PE
 #define VN_PT2_FAST_PE 1         // single-MFMA 16-bit kernels: gamma(x), gamma(dir) with v_fract + v_sin_f32 / v_cos_f32 (vipnerf_bf16n.h sincos_rev); 0: sincosf
+#endif
+#ifndef VN_WGRAD_LATE_LOAD
+#define VN_WGRAD_LATE_LOAD 2       // exact-fp32 256 x 256 weight gradients: the k-step (of 16) behind which a wave issues the next block's global loads (a SIMD's second wave: 4 steps later); -1: at the block's top, stores at its end
+#endif
+#ifndef VN_WGRAD_LATE_STORE
+#define VN_WGRAD_LATE_STORE 12     // ... and behind which it stores them to LDS (a SIMD's second wave: 2 steps later)
 #endif
 #ifndef VN_WGRAD_DMA
 #define VN_WGRAD_DMA 0           // exact-fp32 256 x 256 weight gradients: 1 = operand blocks HBM -> LDS by DMA instead of through registers -- built, correct, and measured SLOWER (9.10 vs 8.22 ms per step: docs/HISTORY.md 5); off

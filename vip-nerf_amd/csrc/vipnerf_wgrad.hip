@@ -13,6 +13,7 @@
 #include "vipnerf_wgrad.h"
 #include "vipnerf_bf16n.h"
 #include "vipnerf_prof.h"
+#include "vipnerf_mlp_pt2.h"
 
 namespace vn {
 
@@ -155,6 +156,10 @@ __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
 // wave and 32-point block -- ~960 of the block's 16384 MFMA cycles with nothing else to issue on that SIMD, wherever in the block they
 // are placed (spreading them over the k-steps, or issuing the LDS stores at the block's start, measured no different: docs/HISTORY.md 5).
 // Same tiles, same LDS layout, same partial-product format as k_wgrad<2, 8, 4>.
+// (The 128 x 256 and 256 x 64 GEMMs were tried on this kernel too -- templated on the tile counts -- and measured the same 1.99 ms per step as
+// on the 4-wave kernel above: they are not issue-bound; profiles/r04_ablation_pt2.md 8.)
+TS_DECL(g_wg_timeline);            // VN_EXP == 50: per-block time stamps of one workgroup (tools/pt2_timeline.py wg)
+#define TSW(tag) TS_AT(g_wg_timeline, tag)
 template <int WK>       // waves along K: 2 -> 8 waves (2 x 4 tiles each), 4 -> 16 waves (2 x 2 tiles each)
 __global__ __launch_bounds__(256 * WK) void k_wgrad256_w8(WgArgs a) {
     constexpr int MTW = 2, KTW = 8 / WK, Mp = 256, Kp = 256, NTH = 256 * WK, NLD = 2048 / NTH;   // float4 of A and of B per thread and block
@@ -168,6 +173,10 @@ __global__ __launch_bounds__(256 * WK) void k_wgrad256_w8(WgArgs a) {
     const int64_t p0 = (int64_t)blockIdx.x * a.chunk_pts;
     const int64_t p1 = p0 + a.chunk_pts < a.P ? p0 + a.chunk_pts : a.P;
     const int nblk = (int)((p1 - p0 + 31) / 32);
+#if defined(VN_EXP) && VN_EXP == 50
+    const bool ts_rec = blockIdx.x == gridDim.x / 2 && blockIdx.y == 3 && lane == 0 && wave < 8; int ts_n = 0;
+#endif
+    TSW(TS_ENTRY);
 
     floatx16 acc[MTW][KTW];
     float bsum[MTW];
@@ -221,6 +230,13 @@ __global__ __launch_bounds__(256 * WK) void k_wgrad256_w8(WgArgs a) {
         if (nblk > 0) { gload(0); lstore(0); }
         __syncthreads();
     }
+    // Every wave fetches the next block behind k-step VN_WGRAD_LATE_LOAD (the second wave of a SIMD four steps later) and stores it to LDS
+    // behind k-step VN_WGRAD_LATE_STORE (the second wave two steps later) instead of at the block's two ends: after the block barrier
+    // both waves of a SIMD start their MFMAs at once, and at the block's end they go straight to the barrier.  Per-block timeline of one
+    // workgroup (tools/pt2_timeline.py wg, profiles/r04_ablation_pt2.md 8): with the loads at the top and the stores at the end 1.9k of
+    // a block's 19.7k cycles had no MFMA in flight on the SIMD (the block's MFMAs are 16.4k); now 18.8k per block.
+    const bool late = VN_WGRAD_LATE_LOAD >= 0;
+    const int second = (wave >> 2) & 1;
     int cur = 0;
     for (int blk = 0; blk < nblk; ++blk) {
         if (dma) {
@@ -228,10 +244,12 @@ __global__ __launch_bounds__(256 * WK) void k_wgrad256_w8(WgArgs a) {
             __builtin_amdgcn_s_barrier();                    // every wave's pieces are in, every wave is done with the other buffer
             asm volatile("" ::: "memory");
             if (blk + 1 < nblk) issue(blk + 1, cur ^ 1);
-        } else if (blk + 1 < nblk) gload(blk + 1);
+        } else if (!late && blk + 1 < nblk) gload(blk + 1);
+        TSW(TS_POST);
         const float *la = lds + cur * TILE_F, *lb = la + 32 * Mp;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
+            if (!dma && late && s == VN_WGRAD_LATE_LOAD + 4 * second && blk + 1 < nblk) gload(blk + 1);
             float af[MTW], bf[KTW];
 #pragma unroll
             for (int i = 0; i < MTW; ++i) af[i] = la[(2 * s + h) * Mp + 32 * (wm * MTW + i) + l31];
@@ -243,11 +261,15 @@ __global__ __launch_bounds__(256 * WK) void k_wgrad256_w8(WgArgs a) {
 #pragma unroll
                 for (int j = 0; j < KTW; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
             }
+            if (!dma && late && s == VN_WGRAD_LATE_STORE + 2 * second && blk + 1 < nblk) lstore(cur ^ 1);
         }
+        TSW(TS_END);
         if (!dma) {
-            if (blk + 1 < nblk) lstore(cur ^ 1);
+            if (!late && blk + 1 < nblk) lstore(cur ^ 1);
+            TSW(TS_EPI_A);
             __syncthreads();
         }
+        TSW(TS_PRE);
         cur ^= 1;
     }
     float *part = a.partial + d.part_off + (size_t)blockIdx.x * d.part_stride;
@@ -1423,6 +1445,12 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
     if ((rc = launch_class<1, 1, 1>(c14, n14, n_thin, st))) return rc;
     return launch_wgrad_reduce(red, ng, st);
 }
+
+#if defined(VN_EXP) && VN_EXP == 50
+extern "C" int vipnerf_exp_timeline_wg(unsigned long long *out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_timeline), sizeof(unsigned long long) * (n < 1024 ? n : 1024));
+}
+#endif
 
 int launch_wgrad_reduce(const WgReduceArgs &red, int ng, hipStream_t st) {
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(512, ng), dim3(256), 0, st, red);

@@ -48,6 +48,9 @@ __global__ void k_seed_absmax(MlpBwdArgs a, unsigned *slot) {
 // stored as the fp16 parts of the split that is made for the next GEMM anyway: 1 = high parts only (FP16X3H), 2 = high
 // and low parts in the fp32 slot (FP16X3, store_pair_split), sent from the next GEMM's weight stages (DEFER); with high
 // parts only, dY_5 additionally in fp32 for layer 5's gamma(x) GEMM; dY_0 stays fp32.
+TS_DECL(g_nb_timeline);
+#define TSNB(tag) TS_AT(g_nb_timeline, tag)
+
 template <int NS, bool F16, int H16 = 0, bool F32 = false>
 __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) {
     typedef BnPlan<NS> PL;
@@ -74,6 +77,8 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
     const int64_t grp = (int64_t)blockIdx.x * (MLP_PTS_PER_WG / 16) + wave;   // T16: the wave's 16-point group (valid is wave-uniform)
     const int V = a.src.V;
 
+    TS_INIT();
+    TSNB(TS_ENTRY);
     typename StreamOf<PL, PL::SKEW>::type ws;
     ws.start(a.packed + PL::PK_BWD, PL::B_STAGES, stage_buf, lane, wave);
     stream_counted(ws, !T16 || valid);      // a wave beyond P skips its (predicated) T16 stores: its counted waits would not hold
@@ -96,6 +101,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
     }
     const float dsig_raw = a.sigma[p] > 0.f ? gb[a.bl.dsig + p] * gs : 0.f;
     __syncthreads();
+    TSNB(TS_RESIDENT);
 
     // ---------------------------------------------------------------- view branch, per direction
     floatx4 vsum[8];
@@ -162,6 +168,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
 #pragma unroll
     for (int t = 0; t < 8; ++t) if (!EXP_NO_EXTRAS && !T16) store_tile16(a.bwd + a.bl.dyvsum, p, WV, q, t, vsum[t]);
 
+    TSNB(TS_HEAD);
     // ---------------------------------------------------------------- d(feature) = W_vf^T sum_a dYv_a   (K = 128: 4 k-steps)
     FR bin[8][NS];
     floatx4 acc[16];
@@ -175,8 +182,11 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
     stream_begin(ws);
 #pragma unroll
     for (int jj = 0; jj < PL::ST_VIEW_B; ++jj) {
+        TSNB(TS_PRE);
         const float *st = ws.wait();
+        TSNB(TS_POST);
         gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
+        TSNB(TS_END);
     }
     // dY of the feature layer: store (fp32, for wgrad) and split
 #pragma unroll
@@ -210,14 +220,17 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
             // with deferred stores only those behind the previous GEMM's last stage, and nothing before the first layer);
             // later stages: the deferred stores behind the stage before
             constexpr int DEF_SPK = H16 == 4 ? T16_SPK : 2;          // deferred store instructions per operand k-step
+            TSNB(TS_PRE);
             const float *st = jj == 0 ? ws.template wait<DEFER ? DEF_SPK * S_PER_STAGE : 16, DEFER ? 0 : 16>(it == 0)
                                       : ws.template wait<DEFER ? DEF_SPK * S_PER_STAGE : 0>();
+            TSNB(TS_POST);
             if (DEFER) {                                 // bin = the fp16 parts of the gradient this GEMM consumes
                 DeferredStores<H16, NS, FR, S_PER_STAGE> ds{a.bwd + (it == 0 ? a.bl.dyf : a.bl.dy[layer + 1]), p, q, wave, S_PER_STAGE * jj, bin, grp, j, valid};
                 gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws, ds);
             } else {
                 gemm_stage_bf<16, PL::KSB, NS>(st, lane, acc, bin, PL::KSB * jj, ws);
             }
+            TSNB(TS_END);
         }
         float *dst = a.bwd + a.bl.dy[layer];
 #pragma unroll
@@ -248,7 +261,14 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
         }
     }
     stream_end(ws);
+    TSNB(TS_LAST);
 }
+
+#if defined(VN_EXP) && VN_EXP == 50
+extern "C" int vipnerf_exp_timeline_nb(unsigned long long *out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nb_timeline), sizeof(unsigned long long) * (n < 1024 ? n : 1024));
+}
+#endif
 
 template <int NS, bool F16 = false, int H16 = 0, bool F32 = false>
 static int launch_one_bwd_n(const MlpBwdArgs &a, unsigned grid, hipStream_t st) {

@@ -93,7 +93,15 @@ def test_eight_hip_ranks_on_one_gpu_equal_one_process():
     assert torch.cuda.is_available()
     world, port = 8, 30000 + (os.getpid() % 900)
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    try:
+        mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    except mp.ProcessExitedException as e:
+        # eight processes opening ONE device at once: now and then a rank dies by a signal inside the runtime before its first kernel
+        # (see test_bench_self_spawns_eight_ranks_strong_scaling); such a start is repeated once, on another port
+        import warnings
+        warnings.warn(f'a rank died while eight processes opened the device ({e}); repeating the launch once')
+        ret = mp.Manager().dict()
+        mp.spawn(_worker, args=(world, port + 901, ret), nprocs=world, join=True)
     from oracle import vipnerf_oracle as vo
     import test_hip_parity as tp
     dev = torch.device('cuda:0')

@@ -235,7 +235,7 @@ def pmc_reference(prec, rays, workload):
     """HBM bytes per step from the committed rocprofv3 --pmc passes of this very command (profiles/r04_pmc_traffic_<prec>.json;
     counters cannot be collected from inside the process).  Used only when the workload matches the one profiled; the block
     says which file, of which commit and date, it quotes -- the figure goes stale when a kernel changes without re-profiling."""
-    for name in ('r04_pmc_traffic_%s.json' % prec, 'r03_pmc_traffic_%s.json' % prec, 'r02_pmc_traffic_%s.json' % prec):
+    for name in ('r05_pmc_traffic_%s.json' % prec, 'r04_pmc_traffic_%s.json' % prec, 'r03_pmc_traffic_%s.json' % prec):
         try:
             tr = json.load(open(os.path.join(ROOT, 'profiles', name)))
             if tr['workload']['rays_per_gpu'] == rays and tr['workload']['precision'] == prec and tr['workload'].get('scene', 'fern') == workload:
@@ -259,11 +259,7 @@ def roofline_block(prec, prof, steps, rays, ms_per_step, sclk_mhz, n_sec=1, work
     tf = lambda g: macs[g] * 2.0 * points / (stage_ms[g] * 1e-3) / 1e12 if stage_ms[g] > 0 else 0.0
     wg_ms = stage_ms['wgrad_256x256'] + stage_ms['wgrad_small']
     r = {'bound': 'mfma', 'kernel': STAGE_KERNEL[dom], 'achieved': round(tf(dom), 2), 'peak': peak, 'unit': 'TFLOP/s',
-         'frac': round(tf(dom) / peak, 4),
-         'definition': 'algorithmic MACs of the dominant kernel (%d MAC/point of the pass\'s %d) x 2 x %d points per step / device time '
-                       'of its launches in a step (mean over %d timed steps, HIP events on the launch stream) / dense MFMA peak of the operand '
-                       'dtype; forward, data-gradient and weight-gradient passes each count the full MAC/point (SURVEY.md 8d, the 3x convention)'
-                       % (macs[dom], macs['mlp_fwd'], points, steps),
+         'frac': round(tf(dom) / peak, 4), 'mac_per_point': macs[dom], 'points_per_step': points,
          'avg_launch_ms': round(stage_ms[dom] / max(launches[dom], 1), 4), 'launches_per_step': launches[dom],
          'mfmas_issued_per_product': issued, 'frac_issued': round(min(tf(dom) * issued / peak, 9.99), 4),
          'stages': dict({g: {'ms_per_step': round(stage_ms[g], 3), 'achieved_tflops': round(tf(g), 1), 'frac': round(tf(g) / peak, 4)}
@@ -279,8 +275,6 @@ def roofline_block(prec, prof, steps, rays, ms_per_step, sclk_mhz, n_sec=1, work
         r['sustained_peak'] = F16_MFMA_SUSTAINED_TFLOPS
         r['frac_of_sustained'] = round(tf(dom) / F16_MFMA_SUSTAINED_TFLOPS, 4)
         r['frac_issued_of_sustained'] = round(min(tf(dom) * issued / F16_MFMA_SUSTAINED_TFLOPS, 9.99), 4)
-        r['sustained_note'] = 'what a seconds-long dense 16-bit MFMA stream sustains on this part under its power limit (tools/' \
-                              'mfma_f16_sustained.hip, docs/HISTORY.md 4.1b); informational -- frac is against the nominal 2.5 PFLOP/s'
     algo_bytes = ALGO_BYTES_PER_RAY * rays + ALGO_BYTES_FIXED
     r['algorithmic_bytes_per_step'] = algo_bytes
     tr, name = pmc_reference(prec, rays, workload)
@@ -290,9 +284,7 @@ def roofline_block(prec, prof, steps, rays, ms_per_step, sclk_mhz, n_sec=1, work
         r['traffic_step'] = step_bytes
         r['traffic_ratio'] = round(step_bytes / algo_bytes, 1)
         r['hbm_gbs_step'] = round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1)
-        r['traffic_note'] = 'HBM bytes per step (dominant kernel / whole step): FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc ' \
-                            'passes of this command, profiles/%s (profiled at commit %s on %s -- NOT a measurement of this run); traffic_ratio ' \
-                            '= whole step / SURVEY 8d algorithmic bytes' % (name, tr.get('git_head', 'unknown'), tr.get('date', 'unknown'))
+        r['traffic_source'] = 'profiles/%s @ %s %s' % (name, str(tr.get('git_head', 'unknown'))[:12], tr.get('date', 'unknown'))
         try:                                     # is the quoted profile one of the CURRENT kernel sources?
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
             from pmc_traffic import csrc_sha16
@@ -311,6 +303,84 @@ def roofline_block(prec, prof, steps, rays, ms_per_step, sclk_mhz, n_sec=1, work
                 hv[g] = {'bytes': b['total'], 'gb_per_s': round(b['total'] / (ms * 1e-3) / 1e9, 1), 'frac_of_8000': round(b['total'] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         r['hbm_view'] = hv
     return r
+
+
+# Said ONCE in the full report (bench_full.json), never in the stdout line: what the fields of every roofline block mean.
+NOTES = {
+    'roofline': 'SURVEY.md 8d: the path is MFMA-bound.  achieved = algorithmic MACs of the dominant kernel (mac_per_point) x 2 x points_per_step / '
+                'device time of its launches in a step (mean over the timed steps, HIP events on the launch stream inside the timed region); frac = '
+                'achieved / dense MFMA peak of the operand dtype (157.3 TFLOP/s fp32, 2500 fp16 / bf16: always the nominal figure); forward, '
+                'data-gradient and weight-gradient passes each count the full MAC/point (the 3x convention): step_frac = 3 x pass FLOP / ms_per_step / peak',
+    'sustained': 'sustained_peak / frac_of_sustained: what a seconds-long dense 16-bit MFMA stream sustains on this part under its power limit '
+                 '(tools/mfma_f16_sustained.hip, docs/HISTORY.md 4.1b); informational -- frac is against the nominal 2.5 PFLOP/s',
+    'traffic': 'HBM bytes per step (dominant kernel / whole step): FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command, '
+               'collected and corrected as MI355X_MICROARCH.md prescribes; quoted from the committed file named in traffic_source -- NOT a measurement '
+               'of this run (counters cannot be collected from inside the process); traffic_profile_is_of_current_kernels compares a hash of csrc/; '
+               'traffic_ratio = whole step / SURVEY 8d algorithmic bytes; hbm_view = PMC bytes of a stage / its device time in THIS run',
+    'sizes': 'ms per training step (K timed steps, same procedure as `value`, per-kernel events off); module = VipNeRFHip.forward -> compute_losses -> '
+             'backward -> FlatAdam.step (the reference trainer\'s sequence); onecall = vipnerf_train_step (the same kernels queued by ONE library call)',
+    'allreduce': 'allreduce_ms_per_step: HIP events on the launch stream around the one all-reduce (mean over ranks folded into the collective with RCCL) of '
+                 'the flat 4.77 MB gradient bucket, per step, rank 0; at world_size 1 (--force-dist) it is the collective\'s latency floor',
+}
+
+COMPACT_LIMIT = 4096            # bytes of the ONE stdout line (the driver reads it with a bounded parser; r04's 27 KB line was not parsed)
+
+
+def _short(x, nd=4):
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def compact_line(full: dict) -> dict:
+    """The ONE stdout line: the contract's keys, the headline `roofline` and `cpu_baseline` objects with scalar members only, and scalar
+    extras for everything else the full report (bench_full.json, stderr) holds.  Pure function of the full report (tests/test_bench_line_cpu.py)."""
+    keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data')
+    c = {k: full[k] for k in keep if k in full}
+    cf = full.get('config', {})
+    c['config'] = {k: cf[k] for k in ('workload', 'rays_per_gpu', 'global_rays', 'parallelism', 'gemm_arithmetic', 'collectives') if k in cf}
+    r = full.get('roofline') or {}
+    c['roofline'] = {k: _short(r[k]) for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms', 'launches_per_step', 'step_frac',
+                                              'sclk_mhz', 'traffic', 'traffic_ratio', 'algorithmic_bytes_per_step', 'traffic_source',
+                                              'traffic_profile_is_of_current_kernels') if k in r}
+    for g, st in (r.get('stages') or {}).items():
+        c['roofline']['ms_' + g] = st['ms_per_step']
+    cb = full.get('cpu_baseline')
+    if cb:
+        c['cpu_baseline'] = {'value': cb['value'], 'unit': cb['unit'], 'cores': cb['cores'], 'kind': cb['kind'], 'sample': cb['sample'][:160]}
+        c['gpu_over_cpu'] = round(full['value'] / cb['value'], 1) if cb['value'] else None
+    for k, v in full.items():                         # value_<arith>, ms_per_step_<arith>: scalars as they are
+        if (k.startswith('value_') or k.startswith('ms_per_step_')) and isinstance(v, (int, float)):
+            c[k] = v
+        if k.startswith('roofline_') and isinstance(v, dict):
+            c['frac_' + k[9:]] = v.get('frac')
+            c['step_frac_' + k[9:]] = v.get('step_frac')
+    if 'render' in full:
+        for prec, rd in full['render'].items():
+            c['render_ms_per_frame' + ('' if prec == full.get('config', {}).get('gemm_arithmetic') else '_' + prec)] = rd['ms_per_frame']
+    elif 'render_ms_per_frame' in full:
+        c['render_ms_per_frame'] = full['render_ms_per_frame']
+    for blk, tag in (('configs2_realestate', 'configs2'), ('configs4_dtu', 'configs4')):
+        for prec, b in (full.get(blk) or {}).items():
+            if isinstance(b, dict) and 'ms_per_step' in b:
+                c['%s_%s_ms' % (tag, prec)] = b['ms_per_step']
+                c['%s_%s_frac' % (tag, prec)] = (b.get('roofline') or {}).get('frac')
+    for label, b in (full.get('sizes') or {}).items():
+        if not isinstance(b, dict):
+            continue
+        tag = 'sizes_%d' % b.get('rows', 0)
+        for prec in ('fp32', 'bf16'):
+            for api, e in (b.get(prec) or {}).items():
+                c['%s_%s_%s_ms' % (tag, prec, api)] = e['ms_per_step']
+    for k in ('ranks_reduced', 'step_api', 'allreduce_ms_per_step', 'allreduce_calls_per_step', 'rank_ms_per_step_min', 'rank_ms_per_step_max',
+              'build_info_sha16', 'csrc_sha16', 'full_report'):
+        if k in full:
+            c[k] = full[k]
+    line = json.dumps(c, separators=(',', ':'))
+    if len(line) > COMPACT_LIMIT:                     # never print an unparseable line: shed the extras, keep the contract
+        must = set(keep) | {'config', 'roofline', 'cpu_baseline', 'ranks_reduced', 'allreduce_ms_per_step', 'ms_per_step_bf16', 'value_bf16', 'render_ms_per_frame'}
+        for k in [k for k in c if k not in must]:
+            c.pop(k)
+        c['truncated'] = True
+    return c
 
 
 def respawn_cmd(gpus, environ, argv):
@@ -343,7 +413,7 @@ def main():
     ap.add_argument('--workload', default='fern', choices=list(SCENES), help='scene geometry of `value` (BASELINE configs[1] / [3]: fern; '
                     'configs[2]: realestate; configs[4]: dtu)')
     ap.add_argument('--precision', default='fp32', choices=list(ARITH), help='arithmetic of `value` (BASELINE configs[1] says fp32)')
-    ap.add_argument('--also', default='fp16x3,fp16x3h,fp16,bf16', help='comma list of further arithmetics timed the same way ("" = none, "all")')
+    ap.add_argument('--also', default='bf16', help='comma list of further arithmetics timed the same way ("" = none, "all")')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-rays', type=int, default=4096)
     ap.add_argument('--no-render', action='store_true')
@@ -485,15 +555,23 @@ def main():
                 self.step(i)
             ops.profile_enable(profile)
             ops.profile_read()
+            vdist.timing_enable(profile and collectives)
             barrier()
             t0 = time.perf_counter()
             for i in range(args.steps):
                 self.step(args.warmup + i)
+            torch.cuda.synchronize()
+            own = time.perf_counter() - t0           # this rank's own K steps (before the closing barrier): min / max over ranks attribute a slow rank
             barrier()
             elapsed = time.perf_counter() - t0
             prof = ops.profile_read()
             ops.profile_enable(False)
+            n_ar, ar_ms = vdist.timing_read()
+            vdist.timing_enable(False)
             elapsed = max_over_ranks(elapsed)
+            self.last_extra = {'allreduce_ms_per_step': round(ar_ms / args.steps, 4) if n_ar else None, 'allreduce_calls_per_step': n_ar / args.steps,
+                               'rank_ms_per_step_min': round(-max_over_ranks(-own) / args.steps * 1e3, 3),
+                               'rank_ms_per_step_max': round(max_over_ranks(own) / args.steps * 1e3, 3)}
             if not profile:
                 return elapsed, prof, None
             # shader clock under load: EVERY rank runs the extra steps (they contain the collective); rank 0 samples
@@ -517,6 +595,7 @@ def main():
     main_wl = Workload(args.workload, rays, args.precision, step_api=args.step_api)
     model = main_wl.model
     elapsed, prof, sclk = main_wl.timed_run(args.precision)
+    main_extra = main_wl.last_extra
     # N > 1 (the driver's scaling runs): `value` plus the configs[4] arithmetic only, unless --also is given explicitly
     also_arg = args.also if (world == 1 or '--also' in sys.argv) else 'bf16'
     also = [] if args.no_other_precisions else \
@@ -655,12 +734,37 @@ def main():
         result['sizes'] = sizes
     result['ranks_reduced'] = ranks_reduced
     result['step_api'] = args.step_api
-    result['build_info'] = vlib.build_info()
+    if collectives:
+        result.update({k: v for k, v in main_extra.items() if v is not None})
+    import hashlib
+    bi = vlib.build_info()
+    result['build_info'] = bi
+    result['build_info_sha16'] = hashlib.sha256(json.dumps(bi, sort_keys=True).encode()).hexdigest()[:16]
+    try:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        from pmc_traffic import csrc_sha16
+        result['csrc_sha16'] = csrc_sha16()
+    except Exception:
+        pass
 
     if world == 1 and not args.no_cpu_baseline:
         from oracle import vipnerf_oracle as vo       # the checker, as the reported CPU baseline only
         result['cpu_baseline'] = cpu_baseline(vo, n_rays=args.cpu_rays)
-    os.write(json_fd, (json.dumps(result) + '\n').encode())
+    result['notes'] = NOTES
+    # the full report: a file next to bench.py (and under gpurun_out/ when that exists) and stderr; stdout gets ONE compact line
+    full_text = json.dumps(result, indent=1)
+    for d in (ROOT, os.path.join(ROOT, 'gpurun_out')):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, 'bench_full.json'), 'w') as f:
+                    f.write(full_text + '\n')
+                result['full_report'] = 'bench_full.json'
+        except OSError:
+            pass
+    # (stderr: indented, one member per line -- no line of it is a JSON document a line-oriented reader of merged output could mistake for THE line)
+    sys.stderr.write('bench.py full report (also in bench_full.json):\n' + json.dumps(result, indent=1) + '\n')
+    sys.stderr.flush()
+    os.write(json_fd, (json.dumps(compact_line(result), separators=(',', ':')) + '\n').encode())
     if torch.distributed.is_initialized():
         vdist.barrier()
         torch.distributed.destroy_process_group()

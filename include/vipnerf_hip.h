@@ -97,7 +97,7 @@ typedef struct vipnerf_config {
     int32_t perturb;      /* configs['model']['perturb'] && training: stratified jitter + random inverse-CDF draws */
     int32_t precision;    /* VIPNERF_PREC_*: arithmetic of the MLP GEMMs */
     int32_t bf16_layout;  /* VIPNERF_LAYOUT_*: lane layout of the split-bf16 MLP kernels; 0 = library default
-                             (environment VIPNERF_BF16_LAYOUT=wide|narrow overrides the built-in default) */
+                             (VIPNERF_LAYOUT_DEFAULT = the build's default, see vipnerf_build_info(); no environment variable changes it) */
     /* MLP topology (coarse and fine alike), configs['model']['*_mlp'][netdepth, netwidth, points_/views_positional_encoding_degree]
      * (VipNeRF01.py:458-470).  0 = the default.  The hand-written MFMA kernels are specialised on 8 / 256 / 10 / 4 -- what every
      * shipped reference config uses; any other topology (netdepth <= 8, netwidth <= 256 and a multiple of 8, degrees <= 16 / 8;
@@ -254,8 +254,11 @@ int32_t vipnerf_pack_weights(const vipnerf_mlp_params *params, void *packed, vip
  * used with that precision (cfg.precision / the _p argument) only. */
 size_t  vipnerf_packed_weights_bytes_p(int32_t precision);
 int32_t vipnerf_pack_weights_p(const vipnerf_mlp_params *params, int32_t precision, void *packed, vipnerf_stream_t stream);
-/* The same by configuration: cfg->precision for the fused topology (== the _p calls); for any other topology the flat fp32
- * parameter buffer of the generic kernels (unused slots of params may be NULL: layers >= netdepth). */
+/* The same by configuration.  Fused topology: the buffer has the size and layout of the _p call for cfg->precision, but ONLY the image
+ * that cfg's kernels read (cfg->precision, cfg->bf16_layout resolved against the build's default) is written -- the rest of the buffer is
+ * left untouched.  A buffer packed this way is valid for calls with the same precision and the same resolved layout, and NOT for the
+ * unsuffixed stage entry points (they read the wide fp32 image at the buffer's head: use vipnerf_pack_weights / _p for those).  Any
+ * other topology: the flat fp32 parameter buffer of the generic kernels (unused slots of params may be NULL: layers >= netdepth). */
 size_t  vipnerf_packed_weights_bytes_c(const vipnerf_config *cfg);
 int32_t vipnerf_pack_weights_c(const vipnerf_config *cfg, const vipnerf_mlp_params *params, void *packed, vipnerf_stream_t stream);
 

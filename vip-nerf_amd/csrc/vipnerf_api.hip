@@ -105,32 +105,16 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st);
 
 // The split-bf16 kernels exist in two lane layouts: "wide" (32-point waves, one per SIMD; vipnerf_bf16.h) and
 // "narrow" (16-point waves, two per SIMD; vipnerf_bf16n.h).  The packed buffer carries both images
-// ([fp32][wide][narrow]); VIPNERF_BF16_LAYOUT=wide|narrow picks the kernels (forward and data-gradient kernels
-// must agree: the ReLU masks are stored in fragment order).
+// ([fp32][wide][narrow]); cfg->bf16_layout picks the kernels (forward and data-gradient kernels must agree: the
+// ReLU masks are stored in fragment order), VIPNERF_LAYOUT_DEFAULT = the build's default below.  Nothing in the
+// environment changes the selection: what ran is a function of (cfg, vipnerf_build_info()) alone.
 // build switch VN_BF16_NARROW_DEFAULT (default 1, vipnerf_knobs.h)
 // build switch VN_FP32_NARROW_DEFAULT (default 1, vipnerf_knobs.h)
 static bool bf16_narrow(int layout = VIPNERF_LAYOUT_DEFAULT, int precision = 0) {
     if (precision >= VIPNERF_PREC_FP16X3) return true;      // fp16 fragments exist in the narrow layout only
-    if (precision == VIPNERF_PREC_FP32) {                   // exact fp32: wide = v_mfma_f32_32x32x2_f32, one wave per SIMD;
-        if (layout == VIPNERF_LAYOUT_WIDE) return false;    // narrow = v_mfma_f32_16x16x4_f32, two waves per SIMD
-        if (layout == VIPNERF_LAYOUT_NARROW) return true;
-        static const int v32 = [] {
-            const char *e = getenv("VIPNERF_FP32_LAYOUT");
-            if (e && !strcmp(e, "narrow")) return 1;
-            if (e && !strcmp(e, "wide")) return 0;
-            return VN_FP32_NARROW_DEFAULT;
-        }();
-        return v32 != 0;
-    }
-    if (layout == VIPNERF_LAYOUT_WIDE) return false;
-    if (layout == VIPNERF_LAYOUT_NARROW) return true;
-    static const int v = [] {
-        const char *e = getenv("VIPNERF_BF16_LAYOUT");
-        if (e && !strcmp(e, "narrow")) return 1;
-        if (e && !strcmp(e, "wide")) return 0;
-        return VN_BF16_NARROW_DEFAULT;
-    }();
-    return v != 0;
+    if (layout == VIPNERF_LAYOUT_WIDE) return false;        // exact fp32: wide = v_mfma_f32_32x32x2_f32, one wave per SIMD;
+    if (layout == VIPNERF_LAYOUT_NARROW) return true;       // narrow = v_mfma_f32_16x16x4_f32, two waves per SIMD
+    return (precision == VIPNERF_PREC_FP32 ? VN_FP32_NARROW_DEFAULT : VN_BF16_NARROW_DEFAULT) != 0;
 }
 static size_t packed_floats_all(int precision) { return packed_total_floats(precision) + packed_narrow_floats(precision); }
 

@@ -148,8 +148,9 @@ class TrainerHip:
                 g['lr'] = lr
             losses = self.train_one_iter(iter_num)
             entry = {'lr': lr}
-            pending.append((losses, entry))
-            if log_every and self.rank == 0 and (iter_num + 1) % log_every == 0:
+            if losses:                                       # a skipped iteration (empty trimmed shard) logs nothing
+                pending.append((losses, entry))
+            if log_every and losses and self.rank == 0 and (iter_num + 1) % log_every == 0:
                 print(f"iter {iter_num + 1}: " + ' '.join(f'{k} {float(v):.5f}' for k, v in losses.items()) + f' lr {lr:.3e}', flush=True)
             if val_int and (iter_num + 1) % val_int == 0:
                 entry['validation_psnr'] = float(numpy.mean([v.get('psnr', float('nan')) for v in self.run_validation().values()]))

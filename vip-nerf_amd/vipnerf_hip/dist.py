@@ -98,7 +98,7 @@ class FlatGradBucket:
         return torch.empty(0, dtype=torch.float32, device=g0.device).set_(st, g0.storage_offset(), (n,))
 
     def all_reduce_mean(self):
-        """sum over ranks, then 1/world, with ONE collective.  No-op in a single process (unless FORCE)."""
+        """mean over ranks with ONE collective.  No-op in a single process (unless FORCE)."""
         if not _active():
             return
         flat = self.flat
@@ -108,15 +108,61 @@ class FlatGradBucket:
                 torch._foreach_copy_(self.views, [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params])
                 self.attach()
                 flat = self.flat
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.mul_(1.0 / dist.get_world_size())
+        all_reduce_mean_flat(flat)
+
+
+# Attribution of the collective (bench.py `allreduce_ms_per_step`): with timing on, every all_reduce_mean_flat is bracketed by a pair of
+# HIP events on the stream it is issued from (torch's process group makes its own stream wait for that stream and that stream wait for the
+# collective, so the pair spans queueing + the collective + the 1 / R scaling as the step sees them).  Off by default: no events.
+_TIMING = None
+
+
+def timing_enable(on: bool = True):
+    global _TIMING
+    _TIMING = [] if on else None
+
+
+def timing_read():
+    """-> (collectives recorded since the last read, their total milliseconds); synchronises the recorded events."""
+    global _TIMING
+    if _TIMING is None:
+        return 0, 0.0
+    n, ms = len(_TIMING), 0.0
+    for a, b in _TIMING:
+        if isinstance(a, float):
+            ms += (b - a) * 1e3
+        else:
+            b.synchronize()
+            ms += a.elapsed_time(b)
+    _TIMING = []
+    return n, ms
 
 
 def all_reduce_mean_flat(flat: torch.Tensor):
-    """sum over ranks, then 1 / world, of one flat gradient buffer in place (the FusedTrainStep hook); no-op in a single process."""
-    if _active():
+    """Mean over ranks of one flat gradient buffer in place (the FusedTrainStep hook, FlatGradBucket); no-op in a single process.  RCCL
+    (`nccl`) averages inside the collective (ReduceOp.AVG: no separate scaling launch); gloo has no AVG: sum, then x 1 / world."""
+    if not _active():
+        return
+    ev = None
+    if _TIMING is not None:
+        if flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(torch.cuda.current_stream(flat.device))
+        else:
+            import time
+            ev = [time.perf_counter(), 0.0]
+    if dist.get_backend() == 'nccl':
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+    else:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.mul_(1.0 / dist.get_world_size())
+    if ev is not None:
+        if flat.is_cuda:
+            ev[1].record(torch.cuda.current_stream(flat.device))
+        else:
+            import time
+            ev[1] = time.perf_counter()
+        _TIMING.append(tuple(ev))
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0):

@@ -175,6 +175,7 @@ def pack_weights(params: List[torch.Tensor], out: Optional[torch.Tensor] = None,
     """params: the tensors of one MLP in param_order(depth) (24 for the default topology).  With `cfg` the image is the one
     cfg's kernels consume (cfg.precision; the flat fp32 buffer of the generic kernels for a non-default topology)."""
     lib = L.load()
+    full = cfg is None          # no configuration: EVERY image of the precision is filled (vipnerf_pack_weights_p), whatever layout renders
     if cfg is None:
         cfg = make_config(True, 64, 0, 0, False, precision=precision)
     topo = topology_of(cfg)
@@ -195,7 +196,10 @@ def pack_weights(params: List[torch.Tensor], out: Optional[torch.Tensor] = None,
             L.check(-2, 'vipnerf_packed_weights_bytes_c')
         if out is None:
             out = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
-        L.check(lib.vipnerf_pack_weights_c(C.byref(cfg), C.byref(mp), _p(out), _stream(dev)), 'vipnerf_pack_weights_c')
+        if full:
+            L.check(lib.vipnerf_pack_weights_p(C.byref(mp), int(cfg.precision), _p(out), _stream(dev)), 'vipnerf_pack_weights_p')
+        else:
+            L.check(lib.vipnerf_pack_weights_c(C.byref(cfg), C.byref(mp), _p(out), _stream(dev)), 'vipnerf_pack_weights_c')
     return out
 
 

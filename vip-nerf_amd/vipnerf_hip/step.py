@@ -96,10 +96,19 @@ class _Buffers:
 
 
 class FusedTrainStep:
+    MAX_BUFFER_SETS = 2          # persistent buffer sets kept alive (most recently used batch shapes)
+
     def __init__(self, model, configs: dict, optimizer, bucket_reduce: Optional[Callable] = None):
         from .optim import FlatAdam
         if not isinstance(optimizer, FlatAdam):
             raise L.VipNerfHipError('FusedTrainStep needs vipnerf_hip.optim.FlatAdam (flat parameter / moment buffers)')
+        # the flat gradient is laid out in ABI order (coarse.ordered_params(), then fine) and handed to ONE Adam launch next to the
+        # optimizer's flat parameter buffer: the two orders must be the same tensors in the same order
+        ordered = list(model.coarse_model.ordered_params()) + (list(model.fine_model.ordered_params()) if model.fine_mlp_needed else [])
+        if len(optimizer.params) != len(ordered) or any(a is not b for a, b in zip(optimizer.params, ordered)) \
+                or optimizer.flat.numel() != sum(p.numel() for p in ordered):
+            raise L.VipNerfHipError('FusedTrainStep: the optimizer\'s parameters are not coarse.ordered_params() + fine.ordered_params() '
+                                    '(a frozen / extra parameter, or another order): use the module-contract path')
         if model.topology != ops.DEFAULT_TOPOLOGY:
             # (the generic kernels run through the same entry point; nothing here depends on the topology except the tests that pin it)
             pass
@@ -151,6 +160,8 @@ class FusedTrainStep:
         if not rays_o.is_cuda:
             raise L.VipNerfHipError('FusedTrainStep runs on the GPU only; there is no CPU fallback')
         dev, n = rays_o.device, rays_o.shape[0]
+        if n == 0:                                          # before anything is touched: Adam's step count, the buffers, the argument block
+            raise L.VipNerfHipError('FusedTrainStep: empty batch')
         ndc = model.ndc
         two = model.fine_mlp_needed
         V = 0
@@ -174,10 +185,16 @@ class FusedTrainStep:
         z_inj = model.injected_z_fine
         cfg.given_z_fine = int(z_inj is not None and two)
         key = (n, V, prec, cfg.n_coarse, cfg.n_fine, bool(ndc), dev.index)
-        B = self._bufs.get(key)
+        B = self._bufs.pop(key, None)
         if B is None:
+            # a trainer sends batches of varying size (the short last batch of an epoch, per-rank trimmed shards): only the MAX_BUFFER_SETS
+            # most recently used shapes keep their buffers (~5 MB per ray in fp32), the oldest set goes back to the allocator first
+            while len(self._bufs) >= self.MAX_BUFFER_SETS:
+                self._bufs.pop(next(iter(self._bufs)))
+            self.outputs = {}
             shapes, slots = ops.param_shapes(model.topology), ops.param_slots(model.topology)
-            B = self._bufs[key] = _Buffers(cfg, n, dev, self.opt.flat.numel(), shapes, slots)
+            B = _Buffers(cfg, n, dev, self.opt.flat.numel(), shapes, slots)
+        self._bufs[key] = B                                  # (re-inserted: dict order = recency)
         keep = []
         batch = {k: input_batch[k] for k in ('rays_o', 'rays_d', 'view_dirs') if k in input_batch}
         if 'view_dirs' not in batch:
@@ -254,18 +271,18 @@ class FusedTrainStep:
         if local_adam:
             grp = opt.param_groups[0]
             lr, (b1, b2), eps = grp['lr'], grp['betas'], grp['eps']
-            opt.t += 1
-            bc1, bc2 = 1 - b1 ** opt.t, 1 - b2 ** opt.t
+            t_next = opt.t + 1                           # committed only once the library call has succeeded (a raising step must not
+            bc1, bc2 = 1 - b1 ** t_next, 1 - b2 ** t_next    # advance Adam's bias correction / the checkpointed step count)
             A.adam_n = opt.flat.numel()
             A.adam_param, A.adam_exp_avg, A.adam_exp_avg_sq, A.adam_grad = opt.flat.data_ptr(), opt.exp_avg.data_ptr(), opt.exp_avg_sq.data_ptr(), B.flat_grad.data_ptr()
             A.lerp_w, A.beta2, A.sq_w, A.inv_sqrt_bc2 = 1 - b1, b2, 1 - b2, float(np.float32(1.0 / bc2 ** 0.5))
             A.eps, A.neg_step, A.fma_mask = eps, -(lr / bc1), -1
         else:
             A.adam_n = 0
-        if n == 0:
-            raise L.VipNerfHipError('FusedTrainStep: empty batch')
         with ops.on_device(rays_o, opt.flat, B.flat_grad) as d:
             L.check(self.lib.vipnerf_train_step(C.byref(A), ops._stream(d)), 'vipnerf_train_step')
+        if local_adam:
+            opt.t = t_next
         g0 = opt.params[0].grad
         if g0 is None or g0.data_ptr() != B.grad_views[0].data_ptr():
             for p, v in zip(opt.params, B.grad_views):       # the gradients, for whoever looks (a bucket, a test, gradient clipping)
@@ -286,13 +303,29 @@ class FusedTrainStep:
         return {'TotalLoss': B.total, 'loss_values': B.loss_values, 'loss_slots': present, 'two_levels': two}
 
 
+_NAMED_M = {}
+
+
 def named_losses(res: dict) -> Dict[str, torch.Tensor]:
-    """{loss name: value} like LossComputer.compute_losses reports them (coarse + fine per loss), from a FusedTrainStep result."""
-    v, out = res['loss_values'].clone(), {}          # (the step's buffers are overwritten by the next call: what is handed out is a copy)
-    for name, slots in res['loss_slots'].items():
-        if slots is None:
-            out[name] = v[7]
-        else:
-            out[name] = (v[slots[0]] + v[slots[1]]) if (res['two_levels'] and slots[1] != 7) else v[slots[0]]
-    out['TotalLoss'] = res['TotalLoss'][0].clone()
+    """{loss name: value} like LossComputer.compute_losses reports them (coarse + fine per loss), from a FusedTrainStep result.  Two
+    launches whatever the number of losses: one (names x 8) selection matrix times the step's loss vector (a fresh tensor -- the step's
+    own buffers are overwritten by the next call), one copy of TotalLoss; the per-name values are views of the product."""
+    lv = res['loss_values']
+    names = list(res['loss_slots'])
+    key = (tuple((n, res['loss_slots'][n]) for n in names), bool(res['two_levels']), lv.device)
+    M = _NAMED_M.get(key)
+    if M is None:
+        m = torch.zeros(max(len(names), 1), 8)
+        for i, n in enumerate(names):
+            slots = res['loss_slots'][n]
+            if slots is None:
+                m[i, 7] = 1.0
+            else:
+                m[i, slots[0]] = 1.0
+                if res['two_levels'] and slots[1] != 7:
+                    m[i, slots[1]] = 1.0
+        M = _NAMED_M[key] = m.to(lv.device)
+    v = torch.mv(M, lv)
+    out = {n: v[i] for i, n in enumerate(names)}
+    out['TotalLoss'] = res['TotalLoss'].clone()[0]
     return out

@@ -149,8 +149,14 @@ def test_bench_self_spawns_eight_ranks_strong_scaling():
     res = json.loads(lines[0])
     assert res['n_gpus'] == 8 and res['ranks_reduced'] == 8 and res['scaling'] == 'strong'
     assert res['config']['rays_per_gpu'] == 1024 and res['config']['global_rays'] == 8192 and res['value'] > 0 and res['value_bf16'] > 0
-    assert res['render']['fp32']['row_strips'] == 8 and res['render_ms_per_frame'] > 0
-    assert 'VN_EXP=unset' in res['build_info']
+    assert len(lines[0]) < 4096                                             # the ONE compact stdout line (tests/test_bench_line_cpu.py)
+    # attribution of the collective and of a slow rank: present at N > 1
+    assert res['allreduce_ms_per_step'] > 0 and res['allreduce_calls_per_step'] == 1.0
+    assert 0 < res['rank_ms_per_step_min'] <= res['rank_ms_per_step_max'] <= res['ms_per_step'] * 1.001
+    full = json.load(open(os.path.join(ROOT, 'bench_full.json')))          # the nested blocks live in the full report
+    assert full['value'] == res['value'] and full['n_gpus'] == 8
+    assert full['render']['fp32']['row_strips'] == 8 and res['render_ms_per_frame'] > 0
+    assert 'VN_EXP=unset' in full['build_info']
 
 
 def test_bench_two_ranks_on_one_gpu():
@@ -171,11 +177,14 @@ def test_bench_two_ranks_on_one_gpu():
     res = json.loads(lines[0])
     assert res['n_gpus'] == 2 and res['scaling'] == 'weak' and res['value'] > 0 and res['config']['global_rays'] == 2048
     # N > 1 lines carry the configs[4] arithmetic beside `value`, and the configs[4] block (every rank its own DTU shard)
-    assert res['value_bf16'] > 0 and res['configs4_dtu']['n_gpus'] == 2 and res['configs4_dtu']['global_rays'] == 1024
-    assert res['configs4_dtu']['bf16']['value'] > 0 and res['configs4_dtu']['bf16']['roofline']['bound'] == 'mfma'
+    full = json.load(open(os.path.join(ROOT, 'bench_full.json')))          # the nested blocks live in the full report, scalars of them in the line
+    assert res['value_bf16'] > 0 and full['configs4_dtu']['n_gpus'] == 2 and full['configs4_dtu']['global_rays'] == 1024
+    assert full['configs4_dtu']['bf16']['value'] > 0 and full['configs4_dtu']['bf16']['roofline']['bound'] == 'mfma'
+    assert res['configs4_bf16_ms'] == full['configs4_dtu']['bf16']['ms_per_step']
     assert res['dtype'] == 'f32' and res['roofline']['bound'] == 'mfma' and 0 < res['roofline']['frac'] < 1
+    assert res['allreduce_ms_per_step'] > 0 and res['rank_ms_per_step_max'] >= res['rank_ms_per_step_min'] > 0
     # the render leg at N > 1: one strip of the 756-row frame per rank, barrier-bracketed maximum over the ranks
-    assert res['render']['fp32']['row_strips'] == 2 and res['render_ms_per_frame'] > 0
+    assert full['render']['fp32']['row_strips'] == 2 and res['render_ms_per_frame'] > 0
     # strong scaling: configs[3]'s 65,536 rays would not leave room for two ranks on one GPU; the flag itself with a small total
     cmd2 = cmd[:-2] + ['--scaling', 'strong', '--global-rays', '2048']
     r = subprocess.run(cmd2, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)

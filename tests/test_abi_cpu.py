@@ -56,7 +56,7 @@ def test_argument_validation_without_gpu():
     assert a.value == 0 and b.value > 0
     cfg.save_acts = 1
     assert lib.vipnerf_query_workspace(C.byref(cfg), 4096, C.byref(a), C.byref(b)) == 0
-    assert a.value == 4 * 4096 * 256 * (9 * 256 + 8 * 8 + 2 * 128 + 64 + 2 * 32)
+    assert a.value == 4 * 4096 * 256 * (9 * 256 + 8 * 8 + 2 * 128 + 64 + 2 * 32 + 2 * 4)      # (+ 2 x 4 words: the view hidden's ReLU bits per direction)
     bad = ops.make_config(True, 60, 128, 1, False)
     assert lib.vipnerf_query_workspace(C.byref(bad), 16, C.byref(a), C.byref(b)) == -2
     buf = C.create_string_buffer(256)

@@ -104,6 +104,7 @@ struct ActLayout {
     size_t g[1 + VIPNERF_MAX_SEC];    // [P][128] view-branch hidden (post ReLU), per direction
     size_t pex;       // [P][64]  gamma(x), zero padded
     size_t ped[1 + VIPNERF_MAX_SEC];  // [P][32]  gamma(dir), zero padded, per direction
+    size_t gm[1 + VIPNERF_MAX_SEC];   // [P][4] uint32, fp32 storage only: ReLU bits of the view hidden (bit 4 t + r of lane group q's word = feature 16 t + 4 q + r > 0)
     size_t total;
 };
 __host__ __device__ inline ActLayout act_layout(size_t P, int V, bool t16 = false) {
@@ -117,6 +118,7 @@ __host__ __device__ inline ActLayout act_layout(size_t P, int V, bool t16 = fals
     for (int k = 0; k <= VIPNERF_MAX_SEC; ++k) { a.g[k] = o; if (k <= V) o += t16 ? P * (WV / 2 + 4) : P * WV; }
     a.pex = o; o += P * DPE_PAD / d;
     for (int k = 0; k <= VIPNERF_MAX_SEC; ++k) { a.ped[k] = o; if (k <= V) o += P * DVE_PAD / d; }
+    for (int k = 0; k <= VIPNERF_MAX_SEC; ++k) { a.gm[k] = o; if (k <= V && !t16) o += P * 4; }     // (T16: the bits sit behind the view hidden's tiles)
     a.total = o;
     return a;
 }

@@ -48,6 +48,7 @@ __global__ void k_seed_absmax(MlpBwdArgs a, unsigned *slot) {
 // stored as the fp16 parts of the split that is made for the next GEMM anyway: 1 = high parts only (FP16X3H), 2 = high
 // and low parts in the fp32 slot (FP16X3, store_pair_split), sent from the next GEMM's weight stages (DEFER); with high
 // parts only, dY_5 additionally in fp32 for layer 5's gamma(x) GEMM; dY_0 stays fp32.
+int launch_mlp_bwd_f32(const MlpBwdArgs &a, hipStream_t st);
 TS_DECL(g_nb_timeline);
 #define TSNB(tag) TS_AT(g_nb_timeline, tag)
 
@@ -282,7 +283,11 @@ static int launch_one_bwd_n(const MlpBwdArgs &a, unsigned grid, hipStream_t st) 
 int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
     if (a.src.P <= 0) return VIPNERF_OK;
     const unsigned grid = (unsigned)((a.src.P + MLP_PTS_PER_WG - 1) / MLP_PTS_PER_WG);
+#if VN_F32_BWD_V2
+    if (precision == 0) return launch_mlp_bwd_f32(a, st);      // the exact-fp32 kernel of vipnerf_mlp_bwd_f32.hip
+#else
     if (precision == 0) return launch_one_bwd_n<2, false, VN_F32_DEFER ? 3 : 0, true>(a, grid, st);
+#endif
     if (precision == 1) return launch_one_bwd_n<2>(a, grid, st);
     if (precision == 2) return launch_one_bwd_n<3>(a, grid, st);
     if ((precision == 5 || precision == 6) && !single_mfma_t16(precision)) {

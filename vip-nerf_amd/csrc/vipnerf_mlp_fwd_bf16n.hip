@@ -238,7 +238,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) g[t][r] = relu_lo<F16 || T16>(g[t][r] * AU, 0.f);     // (+0 | positive | NaN for the T16 ReLU bits)
+            for (int r = 0; r < 4; ++r) g[t][r] = relu_lo<F16 || T16 || (F32 && SAVE)>(g[t][r] * AU, 0.f);     // (+0 | positive | NaN for the ReLU bits)
         if (T16) {
             if (valid && !EXP_NO_EXTRAS) {
                 // view hidden as 16-bit T16 (8 tiles) + its 32 ReLU bits per lane (bit 4 t + r), which is all the data-gradient
@@ -263,6 +263,12 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             if (!EXP_NO_EXTRAS) {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) store_tile16(a.acts + a.al.g[dsel], p, WV, q, t, g[t]);
+                if (F32) {       // the view hidden's 32 ReLU bits per lane (bit 4 t + r): all k_mlp_bwd_f32 reads of it
+                    unsigned gmb = 0u;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) gmb = push_nibble(gmb, positive_nibble(g[t]));
+                    ((unsigned *)(a.acts + a.al.gm[dsel]))[(size_t)p * 4 + q] = gmb;
+                }
             }
             if (valid && !EXP_NO_PE) store_d16(a.acts + a.al.ped[dsel] + (size_t)p * DVE_PAD, q, ped);
         }

@@ -208,7 +208,11 @@ __device__ __forceinline__ AccN<NPT> mfma_split(const FR (&a)[NS], const BOp<FR,
 // global_load_lds piece costs its wave ~60 cycles of issue time among MFMAs (MI355X_MICROARCH.md), so ONE wave issuing a 64-piece stage
 // is ~3800 cycles behind the other seven at the stage barrier -- as long as the stage's own MFMA work (4096 cycles per SIMD in the
 // two-point-tile 16-bit kernels: profiles/r04_ablation_pt2.md measured stage = skeleton + MFMA, not max).
-template <int CH, int NBUF, int WAVES = 4, bool ROTATE = false, bool STAGGER = false, int ISSUERS = 1>
+// ROTW (ROTATE only; build switch VN_DMA_ROT_WAVES for the narrow kernels): the issuer rotates over waves 0 .. ROTW - 1 only.  Waves w and w + 4 share a
+// SIMD and the arbiter favours the older one (w < 4): it finishes a stage's MFMAs first and sits ~8k cycles at the stage barrier, while the
+// younger wave IS the stage's critical path -- and a 64-piece DMA burst costs its issuer ~2k cycles (profiles/r05_timeline_bwd_f32_v2.log: 19.2k
+// against 17.3k cycles for the stages a younger wave issued in).  With ROTW = 4 only the waves with slack issue.
+template <int CH, int NBUF, int WAVES = 4, bool ROTATE = false, bool STAGGER = false, int ISSUERS = 1, int ROTW = WAVES>
 struct WStreamT {
     const float *g;
     float *buf;
@@ -224,15 +228,16 @@ struct WStreamT {
     static constexpr int PER_WAVE = ROTATE ? CH / ISSUERS : CH / WAVES;
     static_assert(CH % WAVES == 0 && (NBUF == 2 || PER_WAVE * (NBUF - 2) <= 63), "vmcnt is a 6-bit counter");
     static_assert(ISSUERS >= 1 && WAVES % ISSUERS == 0 && CH % ISSUERS == 0 && (ISSUERS == 1 || ROTATE), "issuer sets tile the waves");
+    static_assert(ROTW >= ISSUERS && ROTW <= WAVES && (ROTW & (ROTW - 1)) == 0 && ROTW % ISSUERS == 0, "rotation set: a power of two, whole issuer sets");
     __device__ __forceinline__ void fetch() {
 #if defined(VN_EXP) && (VN_EXP == 5 || VN_EXP == 18)
         if (n_left < -1000)                       // timing experiment only: no weight DMA
 #endif
         if (ROTATE) {
-            const int rel = (wave - turn) & (WAVES - 1);          // (WAVES is a power of two in every ROTATE instantiation)
+            const int rel = (wave - turn) & (WAVES - 1);          // (WAVES is a power of two in every ROTATE instantiation; turn + rel < ROTW for an issuer)
             if (ISSUERS == 1) { if (wave == turn) glds_run<PER_WAVE>(g + lane * 4, buf + fill * SF); }
             else if (rel < ISSUERS) glds_run<PER_WAVE>(g + (rel * PER_WAVE) * CHUNK_F + lane * 4, buf + fill * SF + (rel * PER_WAVE) * CHUNK_F);
-            turn = (turn + ISSUERS) & (WAVES - 1);
+            turn = (turn + ISSUERS) & (ROTW - 1);
         } else {
             glds_run<PER_WAVE>(g + (wave * PER_WAVE) * CHUNK_F + lane * 4, buf + fill * SF + (wave * PER_WAVE) * CHUNK_F);
         }
@@ -286,7 +291,7 @@ struct WStreamT {
                 else if (YOUNGER_FIRST != YOUNGER && first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER_FIRST) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
             }
-            cturn = (cturn + ISSUERS) & (WAVES - 1);
+            cturn = (cturn + ISSUERS) & (ROTW - 1);
 #if !(defined(VN_EXP) && (VN_EXP == 16 || VN_EXP == 18))
             __builtin_amdgcn_s_barrier();         // (timing experiments 16 / 18 race without it)
 #endif

@@ -173,8 +173,11 @@ struct WStreamSkew {
     template <int g, int NG> __device__ __forceinline__ void prefetch_at() {}
 };
 // build switch VN_DMA_MODE (default 1, vipnerf_knobs.h): 1: one wave issues a whole stage (ROTATE); 2: every wave its share, staggered over the stage
-template <typename PL, bool SK> struct StreamOf { typedef WStreamT<PL::CH, PL::NBUF, PL::WAVES, VN_DMA_MODE == 1, VN_DMA_MODE == 2, VN_DMA_MODE == 1 ? VN_DMA_ISSUERS : 1> type; };
+// build switch VN_DMA_ROT_WAVES (default 4, vipnerf_knobs.h): the waves a stage's issuer rotates over (4: the older wave of every SIMD only; 8: all)
+template <typename PL, bool SK> struct StreamOf { typedef WStreamT<PL::CH, PL::NBUF, PL::WAVES, VN_DMA_MODE == 1, VN_DMA_MODE == 2, VN_DMA_MODE == 1 ? VN_DMA_ISSUERS : 1, VN_DMA_MODE == 1 ? VN_DMA_ROT_WAVES : PL::WAVES> type; };
 template <typename PL> struct StreamOf<PL, true> { typedef WStreamSkew<PL::CH> type; };
+// the two-point-tile 16-bit kernels: every wave takes its turn (measured neutral to slightly better there: profiles/r05_ab_rot_waves.log)
+template <typename PL> struct StreamOfAll { typedef WStreamT<PL::CH, PL::NBUF, PL::WAVES, VN_DMA_MODE == 1, VN_DMA_MODE == 2, VN_DMA_MODE == 1 ? VN_DMA_ISSUERS : 1> type; };
 // every wave issues its eighth of a stage's DMA and drains it itself (plain vmcnt(0) + barrier): measured +1.8 % for the exact-fp32
 // EVAL kernel (0.887 -> 0.903 of the fp32 peak: no stores whose latency that vmcnt(0) would sit out, and no single wave 64 pieces
 // behind at the barrier); neutral for the 16-bit eval kernels, and a loss for every training kernel (their stores)

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_bwd_pt2(MlpBwdArgs a) {
         }
     }
     const int store_phase = pt2_store_phase(wave);
-    typename StreamOf<PL, false>::type ws;
+    typename StreamOfAll<PL>::type ws;
     ws.start(a.packed + PL::PK_BWD, PL::B_STAGES, stage_buf, lane, wave);
     ws.counted = valid[0] && valid[1];       // the counted waits assume the stores of BOTH point tiles
     {

@@ -17,7 +17,7 @@
     X(VN_BF16_H16) X(VN_T16) X(VN_T16_X4) X(VN_T16_NT) X(VN_PT2_SPREAD) X(VN_PT2_SKEW) X(VN_PT2_G) X(VN_PT2_D)                  \
     X(VN_PT2_TRAIN_KEEP) X(VN_PT2_EVAL_KEEP) X(VN_PT2_FAST_PE)                                                                                              \
     /* weight gradients (vipnerf_wgrad.hip, vipnerf_wgrad16.hip) */                                                                       \
-    X(VN_WGRAD_LATE_LOAD) X(VN_WGRAD_LATE_STORE) X(VN_WGRAD_DMA) X(VN_WGRAD_W8) X(VN_WGRAD_PIPE) X(VN_WGRAD_ONE_ROUND) X(VN_WGRAD_ROUNDS) X(VN_WG16_BIG_WM) X(VN_WG16_BIG_WN)        \
+    X(VN_WGRAD_SIGMA_FUSED) X(VN_WGRAD_VIEW_FUSED) X(VN_WGRAD_LATE_LOAD) X(VN_WGRAD_LATE_STORE) X(VN_WGRAD_DMA) X(VN_WGRAD_W8) X(VN_WGRAD_PIPE) X(VN_WGRAD_ONE_ROUND) X(VN_WGRAD_ROUNDS) X(VN_WG16_BIG_WM) X(VN_WG16_BIG_WN)        \
     X(VN_WG16_BIG_NB) X(VN_WG16_HYBRID) X(VN_WG16_SIGMA_FUSED) X(VN_WG16_DMA_PIECES) X(VN_WG16_THIN_HYBRID) X(VN_WG16_BIG_SLOTS)          \
     /* optimizer (vipnerf_api.hip) */                                                                                                     \
     X(VN_ADAM_FMA_MASK)
@@ -60,6 +60,12 @@
 #endif
 #ifndef VN_F32_BWD_V2
 #define VN_F32_BWD_V2 1          // exact-fp32 data gradients: 1 = k_mlp_bwd_f32 (vipnerf_mlp_bwd_f32.hip), 0 = the k_mlp_bwd_bf16n<2,false,3,true> instantiation
+#endif
+#ifndef VN_WGRAD_SIGMA_FUSED
+#define VN_WGRAD_SIGMA_FUSED 1    // exact fp32: the sigma head's weight gradient as weighted column sums inside the feature layer's 256 x 256 GEMM (k_wgrad256_w8)
+#endif
+#ifndef VN_WGRAD_VIEW_FUSED
+#define VN_WGRAD_VIEW_FUSED 1     // exact fp32: the view layer's 128 x 256 and per-direction 128 x 32 weight-gradient GEMMs in one launch over dYv_0..V (k_wgrad_view)
 #endif
 #ifndef VN_DMA_ROT_WAVES
 #define VN_DMA_ROT_WAVES 4       // VN_DMA_MODE 1: the issuer of a stage's DMA rotates over waves 0 .. n - 1 (4: the older wave of each SIMD; 8: every wave)

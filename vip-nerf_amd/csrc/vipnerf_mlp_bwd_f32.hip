@@ -160,8 +160,9 @@ __global__ __launch_bounds__(PLF::WG) void k_mlp_bwd_f32(MlpBwdArgs a) {
             }
         }
     }
+    // (sum_a dYv_a is formed again by the view layer's weight-gradient kernel while it stages dYv_0..V: k_wgrad_view; stored only without it)
 #pragma unroll
-    for (int t = 0; t < 8; ++t) if (!EXP_NO_EXTRAS) store_tile16(a.bwd + a.bl.dyvsum, p, WV, q, t, vsum[t]);
+    for (int t = 0; t < 8; ++t) if (!EXP_NO_EXTRAS && !VN_WGRAD_VIEW_FUSED) store_tile16(a.bwd + a.bl.dyvsum, p, WV, q, t, vsum[t]);
     TSF(TS_HEAD);
 
     // ---------------------------------------------------------------- d(feature) = W_vf^T sum_a dYv_a   (K = 128: 4 k-steps, 2 stages)

@@ -150,6 +150,145 @@ __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
 }
 
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The view layer's weight gradient, exact fp32, in ONE launch: dW_view[:, 0:256] = (sum_a dYv_a)^T feature and dW_view[:, 256:283] =
+// sum_a dYv_a^T gamma(dir_a) (reference src/models/VipNeRF01.py:576-590: views_linears[0] over cat(feature, gamma(dir)), evaluated once per
+// direction a = 0..V).  Before: a 128 x 256 launch over dYvsum = sum_a dYv_a (an array the data-gradient kernel wrote for it) and one
+// 128 x 32 GEMM per direction over dYv_a -- every dYv_a streamed twice (once as part of the sum).  Here a workgroup stages each 16-point
+// block of dYv_0..dYv_V, gamma(dir_0..V) and the feature ONCE, forms the sum while staging (the thread that loads a float4 of dYv_a loads
+// the same float4 of every direction), and runs both products from the tiles: 2304 B per point instead of 2816 + the 512 the sum's store
+// cost (V = 1), one launch instead of two, the direction products summed in the accumulator instead of by the reduction.
+// 8 waves: wave (wm = wave & 3, wk = wave >> 2) owns M tile wm x K tiles 4 wk .. 4 wk + 3 of the 128 x 256 product; the waves wk == 0 also the
+// 128 x 32 tile of the direction columns.  16-point blocks, double-buffered LDS; a block's global loads are issued one block AHEAD of the
+// LDS stores that consume them (registers carry block b + 2 through iteration b + 1).
+struct WgViewArgs {
+    const float *dyv[1 + VIPNERF_MAX_SEC], *ped[1 + VIPNERF_MAX_SEC], *feat;
+    int64_t P;
+    int chunk_pts, n_chunks;
+    float *part_vf, *part_vd;                 // chunk 0 of the two partial products ([128][256] + 128 column sums; [128][32] + 128 unused)
+    size_t stride_vf, stride_vd;
+};
+// one block's worth of staged operands in registers (thread tid: float4 (row tid >> 5, columns 4 (tid & 31)) of every dYv_a, float4 tid and
+// tid + 512 of the feature block -- rows tid >> 6 and 8 + (tid >> 6) --, and, the first 128 threads, float4 (row tid >> 3, columns 4 (tid & 7)) of
+// every gamma(dir_a))
+template <int NV> struct ViewStage { float4 rv[NV], rf[2], rp[NV]; };
+template <int NV>
+__device__ __forceinline__ void view_gload(ViewStage<NV> &r, const WgViewArgs &a, int64_t pb, int64_t p1, int tid) {
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool okv = pb + (tid >> 5) < p1;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { r.rv[k] = z4; if (okv) r.rv[k] = *(const float4 *)(a.dyv[k] + (size_t)(pb + (tid >> 5)) * WV + 4 * (tid & 31)); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 6) + 8 * i;
+        r.rf[i] = z4;
+        if (pb + row < p1) r.rf[i] = *(const float4 *)(a.feat + (size_t)(pb + row) * W + 4 * (tid & 63));
+    }
+    const bool okp = tid < 128 && pb + (tid >> 3) < p1;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { r.rp[k] = z4; if (okp) r.rp[k] = *(const float4 *)(a.ped[k] + (size_t)(pb + (tid >> 3)) * DVE_PAD + 4 * (tid & 7)); }
+}
+template <int NV, int O_SUM, int O_PED, int O_FEAT>
+__device__ __forceinline__ void view_lstore(const ViewStage<NV> &r, float *t, int tid) {
+    constexpr int BP = 16;
+    float4 sum = r.rv[0];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        ((float4 *)(t + k * BP * WV))[tid] = r.rv[k];
+        if (k > 0) { sum.x += r.rv[k].x; sum.y += r.rv[k].y; sum.z += r.rv[k].z; sum.w += r.rv[k].w; }
+    }
+    if (NV > 1) ((float4 *)(t + O_SUM))[tid] = sum;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ((float4 *)(t + O_FEAT))[tid + 512 * i] = r.rf[i];
+    if (tid < 128) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) ((float4 *)(t + O_PED + k * BP * DVE_PAD))[tid] = r.rp[k];
+    }
+}
+template <int NV>
+__global__ __launch_bounds__(512) void k_wgrad_view(WgViewArgs a) {
+    constexpr int BP = 16;                                   // points per block
+    constexpr int O_SUM = NV > 1 ? NV * BP * WV : 0;         // the sum tile (NV == 1: dYv_0 itself)
+    constexpr int O_PED = O_SUM + (NV > 1 ? BP * WV : NV * BP * WV);
+    constexpr int O_FEAT = O_PED + NV * BP * DVE_PAD;
+    constexpr int TILE_F = O_FEAT + BP * W;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if ((int)blockIdx.x >= a.n_chunks) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int wm = wave & 3, wk = wave >> 2;
+    const int64_t p0 = (int64_t)blockIdx.x * a.chunk_pts;
+    const int64_t p1 = p0 + a.chunk_pts < a.P ? p0 + a.chunk_pts : a.P;
+    const int nblk = (int)((p1 - p0 + BP - 1) / BP);
+
+    floatx16 acc[4], accd = (floatx16)(0.f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (floatx16)(0.f);
+    float bsum = 0.f;
+
+    // TWO register sets (block parity): a block's loads are issued two blocks ahead of the LDS stores that consume them
+    ViewStage<NV> st0, st1;
+    if (nblk > 0) { view_gload<NV>(st0, a, p0, p1, tid); view_lstore<NV, O_SUM, O_PED, O_FEAT>(st0, lds, tid); }
+    if (nblk > 1) view_gload<NV>(st1, a, p0 + BP, p1, tid);
+    if (nblk > 2) view_gload<NV>(st0, a, p0 + 2 * BP, p1, tid);
+    __syncthreads();
+    // block blk computes from LDS buffer blk & 1; behind k-step 1 (wk = 0) / 5 (wk = 1: the two waves of a SIMD stage at different k-steps, one's
+    // LDS stores and load issue under the other's MFMAs) it stores block blk + 1 (register set (blk + 1) & 1, requested two blocks ago) into the
+    // buffer the last barrier freed and requests block blk + 3 into the same registers
+    for (int blk = 0; blk < nblk; blk += 2) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int b = blk + half;
+            if (b < nblk) {
+                const float *t = lds + half * TILE_F;        // (blk is even: buffer = half)
+#pragma unroll
+                for (int s = 0; s < BP / 2; ++s) {
+                    if (s == 1 + 4 * wk && b + 1 < nblk) {
+                        ViewStage<NV> &nx = half == 0 ? st1 : st0;
+                        view_lstore<NV, O_SUM, O_PED, O_FEAT>(nx, lds + (1 - half) * TILE_F, tid);
+                        if (b + 3 < nblk) view_gload<NV>(nx, a, p0 + (int64_t)(b + 3) * BP, p1, tid);
+                    }
+                    const int row = 2 * s + h;
+                    const float af = t[O_SUM + row * WV + 32 * wm + l31];
+                    float bf[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bf[j] = t[O_FEAT + row * W + 32 * (4 * wk + j) + l31];
+                    bsum += af;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = mfma32(af, bf[j], acc[j]);
+                    if (wk == 0) {
+#pragma unroll
+                        for (int k = 0; k < NV; ++k)
+                            accd = mfma32(t[k * BP * WV + row * WV + 32 * wm + l31], t[O_PED + k * BP * DVE_PAD + row * DVE_PAD + l31], accd);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    float *pf = a.part_vf + (size_t)blockIdx.x * a.stride_vf, *pd = a.part_vd + (size_t)blockIdx.x * a.stride_vd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pf[(size_t)o * W + 32 * (4 * wk + j) + l31] = acc[j][r];
+        if (wk == 0) pd[(size_t)o * DVE_PAD + l31] = accd[r];
+    }
+    if (wk == 0) {
+        const float b = bsum + __shfl_xor(bsum, 32, 64);
+        if (h == 0) pf[(size_t)WV * W + 32 * wm + l31] = b;
+    }
+}
+template <int NV>
+static int launch_view(const WgViewArgs &va, hipStream_t st) {
+    const size_t ldsb = (size_t)2 * 16 * ((NV > 1 ? NV + 1 : 1) * WV + NV * DVE_PAD + W) * sizeof(float);
+    VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_view<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    hipLaunchKernelGGL(k_wgrad_view<NV>, dim3(va.n_chunks), dim3(512), ldsb, st, va);
+    VN_HIP(hipGetLastError());
+    return VIPNERF_OK;
+}
+
 // The 256 x 256 fp32 GEMMs with EIGHT waves (two per SIMD): wave (wm, wk) owns 2 x 4 of the 8 x 8 tiles (128 accumulators), so a
 // second wave keeps a SIMD's MFMA pipe busy while the first one issues its vector-memory instructions.  Why it matters: a
 // global_load_dwordx4 holds a wave's issue port ~60 cycles whatever else is going on; the 4-wave kernel above issues 16 of them per
@@ -160,8 +299,10 @@ __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
 // on the 4-wave kernel above: they are not issue-bound; profiles/r04_ablation_pt2.md 8.)
 TS_DECL(g_wg_timeline);            // VN_EXP == 50: per-block time stamps of one workgroup (tools/pt2_timeline.py wg)
 #define TSW(tag) TS_AT(g_wg_timeline, tag)
-template <int WK>       // waves along K: 2 -> 8 waves (2 x 4 tiles each), 4 -> 16 waves (2 x 2 tiles each)
-__global__ __launch_bounds__(256 * WK) void k_wgrad256_w8(WgArgs a) {
+// WC: this workgroup's GEMM carries a weighted-column-sum head (WgDesc::wcol).  Compiled as a second copy of the body that only the feature
+// layer's workgroups enter: with the head's code behind a run-time flag in ONE body the other seven GEMMs' blocks measured 2 % slower.
+template <int WK, bool WC>
+__device__ __forceinline__ void wgrad256_body(const WgArgs &a) {
     constexpr int MTW = 2, KTW = 8 / WK, Mp = 256, Kp = 256, NTH = 256 * WK, NLD = 2048 / NTH;   // float4 of A and of B per thread and block
     constexpr int TILE_F = 32 * (Mp + Kp);
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -187,9 +328,23 @@ __global__ __launch_bounds__(256 * WK) void k_wgrad256_w8(WgArgs a) {
         for (int j = 0; j < KTW; ++j) acc[i][j] = (floatx16)(0.f);
     }
     float4 ra[NLD], rb[NLD];
+    // wcol (the sigma head riding in the feature layer's GEMM: WgDesc): w[p] for the rows this thread stages, the weighted column sums of its
+    // four B columns over those rows, and sum w.  A thread's float4 i of a block is row (tid >> 6) + (NTH / 64) i, columns 4 (tid & 63) .. +3.
+    constexpr bool wc = WC;
+    float wr[NLD];
+    float4 wsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float wtot = 0.f;
     const bool linA = d.lda == Mp && d.m_load == Mp, linB = d.ldb == Kp && d.k_load == Kp;
     auto gload = [&](int blk) {
         const int64_t pb = p0 + (int64_t)blk * 32;
+        if (wc) {       // (wave-uniform addresses: scalar loads -- they stay out of the vector-memory counter the operand loads are waited on with)
+            const int wrow = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int64_t pr = pb + wrow + (NTH / 64) * i;
+                wr[i] = pr < p1 ? d.wcol[(size_t)pr * d.wcol_stride] : 0.f;
+            }
+        }
         if (pb + 32 <= p1 && linA && linB) {
             const float4 *ta = (const float4 *)(d.A + (size_t)pb * Mp) + tid;
             const float4 *tb = (const float4 *)(d.B + (size_t)pb * Kp) + tid;
@@ -209,6 +364,14 @@ __global__ __launch_bounds__(256 * WK) void k_wgrad256_w8(WgArgs a) {
         float4 *la = (float4 *)(lds + buf * TILE_F), *lb = (float4 *)(lds + buf * TILE_F + 32 * Mp);
 #pragma unroll
         for (int i = 0; i < NLD; ++i) { la[tid + NTH * i] = ra[i]; lb[tid + NTH * i] = rb[i]; }
+        if (wc) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                wsum.x = fmaf(wr[i], rb[i].x, wsum.x); wsum.y = fmaf(wr[i], rb[i].y, wsum.y);
+                wsum.z = fmaf(wr[i], rb[i].z, wsum.z); wsum.w = fmaf(wr[i], rb[i].w, wsum.w);
+                wtot += wr[i];
+            }
+        }
     };
     // VN_WGRAD_DMA (round 3): when both operands are whole [P][256] arrays and the chunk is whole 32-point blocks (the render path:
     // always), a block's 32 KiB + 32 KiB are contiguous in HBM and go HBM -> LDS by DMA (global_load_lds_dwordx4; the row-major LDS
@@ -290,6 +453,31 @@ __global__ __launch_bounds__(256 * WK) void k_wgrad256_w8(WgArgs a) {
             if (h == 0) part[(size_t)Mp * Kp + 32 * ot + l31] = b;
         }
     }
+    if (wc) {      // the head's partial behind the bias sums: [256 weighted column sums][sum w]; the NTH / 64 row groups (waves) summed in order
+        static_assert(!VN_WGRAD_DMA, "wcol needs the operands in registers");
+        __syncthreads();                                     // (every wave is done with the last block's tiles)
+        float4 *ws4 = (float4 *)lds;
+        ws4[tid] = wsum;
+        if (lane == 0) lds[4 * NTH + wave] = wtot;
+        __syncthreads();
+        if (wave == 0) {
+            float4 t = ws4[lane];
+#pragma unroll
+            for (int w = 1; w < NTH / 64; ++w) { const float4 u = ws4[64 * w + lane]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+            *(float4 *)(part + (size_t)Mp * Kp + Mp + 4 * lane) = t;
+            if (lane == 0) {
+                float tt = lds[4 * NTH];
+#pragma unroll
+                for (int w = 1; w < NTH / 64; ++w) tt += lds[4 * NTH + w];
+                part[(size_t)Mp * Kp + Mp + 256] = tt;
+            }
+        }
+    }
+}
+template <int WK>       // waves along K: 2 -> 8 waves (2 x 4 tiles each), 4 -> 16 waves (2 x 2 tiles each)
+__global__ __launch_bounds__(256 * WK) void k_wgrad256_w8(WgArgs a) {
+    if (a.d[blockIdx.y].wcol != nullptr) wgrad256_body<WK, true>(a);
+    else wgrad256_body<WK, false>(a);
 }
 
 // Weight-gradient GEMMs on split-precision bf16 MFMA ("bf16x3": hi/lo parts, 3 cross terms, fp32 accumulate),
@@ -1335,6 +1523,26 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
         g.bias_off = (size_t)Mp * Kp; g.colperm = 0; g.rowperm = 0;
     };
     const float *pex = acts + al.pex;
+    // the sigma head rides in the feature layer's 256 x 256 GEMM (weighted column sums of its B operand h_8 while it is staged): no second
+    // pass over h_8 (1 KiB per point) and no launch of its own -- the split-precision kernels always, exact fp32 with k_wgrad256_w8
+    const bool fuse_sigma = precision != VIPNERF_PREC_FP32 || (VN_WGRAD_W8 && !VN_WGRAD_DMA && VN_WGRAD_SIGMA_FUSED);
+    {   // feature_linear -- FIRST in the launch (blockIdx.y = 0): its workgroups carry the sigma head (a few per cent longer) and should not be the last round's
+        const size_t o = add(c88, n88, 256, 256, bwd + bl.dyf, W, W, acts + al.h[D - 1], W, W);
+        group(n_chunks, o, 1, 256, 256, W, W, G->g[P_FW], W, 0, G->g[P_FB]);
+        if (fuse_sigma) {
+            // sigma head: dW = sum_p dsigma_raw[p] h_8[p][:], db = sum_p dsigma_raw[p] -- weighted column sums of this
+            // GEMM's B operand, taken while it is staged (no second pass over h_8, no extra launch)
+            WgDesc &d = c88.d[n88 - 1];
+            d.wcol = bwd + bl.dq[0] + 4; d.wcol_stride = 8;
+            d.part_stride += WCOL_EXTRA;
+            off += (size_t)d.n_chunks * WCOL_EXTRA;
+            group(n_chunks, o + (size_t)256 * 256 + 256, 1, 1, 256, 1, W, G->g[P_SW], W, 0, G->g[P_SB]);
+            red.g[ng - 1].part_stride = d.part_stride;
+            red.g[ng - 1].desc_stride = (size_t)n_chunks * d.part_stride;
+            red.g[ng - 2].part_stride = d.part_stride;
+            red.g[ng - 2].desc_stride = (size_t)n_chunks * d.part_stride;
+        }
+    }
     // trunk
     for (int i = 0; i < D; ++i) {
         const float *dy = bwd + bl.dy[i];
@@ -1354,28 +1562,24 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
             group(n_chunks, o, 1, 256, 256, W, W, dW, W, 0, db);
         }
     }
-    const bool fuse_sigma = precision != VIPNERF_PREC_FP32;   // the split-precision 256x256 kernel carries the sigma head
-    {   // feature_linear
-        const size_t o = add(c88, n88, 256, 256, bwd + bl.dyf, W, W, acts + al.h[D - 1], W, W);
-        group(n_chunks, o, 1, 256, 256, W, W, G->g[P_FW], W, 0, G->g[P_FB]);
-        if (fuse_sigma) {
-            // sigma head: dW = sum_p dsigma_raw[p] h_8[p][:], db = sum_p dsigma_raw[p] -- weighted column sums of this
-            // GEMM's B operand, taken while it is staged (no second pass over h_8, no extra launch)
-            WgDesc &d = c88.d[n88 - 1];
-            d.wcol = bwd + bl.dq[0] + 4; d.wcol_stride = 8;
-            d.part_stride += WCOL_EXTRA;
-            off += (size_t)d.n_chunks * WCOL_EXTRA;
-            group(n_chunks, o + (size_t)256 * 256 + 256, 1, 1, 256, 1, W, G->g[P_SW], W, 0, G->g[P_SB]);
-            red.g[ng - 1].part_stride = d.part_stride;
-            red.g[ng - 1].desc_stride = (size_t)n_chunks * d.part_stride;
-            red.g[ng - 2].part_stride = d.part_stride;
-            red.g[ng - 2].desc_stride = (size_t)n_chunks * d.part_stride;
-        }
-    }
     if (!fuse_sigma) {   // sigma head: A = column 4 of DQ[0]
         const size_t o = add(c18, n18, 32, 256, bwd + bl.dq[0] + 4, 8, 4, acts + al.h[D - 1], W, W);
         group(n_sigma, o, 1, 32, 256, 1, W, G->g[P_SW], W, 0, G->g[P_SB]);
     }
+    // the view layer: exact fp32 in ONE launch over dYv_0..V (k_wgrad_view; no dYvsum); the split-precision modes as two GEMM classes
+    const bool view_fused = precision == VIPNERF_PREC_FP32 && VN_WGRAD_VIEW_FUSED;
+    WgViewArgs va;
+    if (view_fused) {
+        for (int k = 0; k <= VIPNERF_MAX_SEC; ++k) { va.dyv[k] = bwd + bl.dyv[k <= V ? k : 0]; va.ped[k] = acts + al.ped[k <= V ? k : 0]; }
+        va.feat = acts + al.feat; va.P = (int64_t)P; va.chunk_pts = chunk_single; va.n_chunks = n_single;
+        va.stride_vf = (size_t)128 * 256 + 128; va.stride_vd = (size_t)128 * 32 + 128;
+        va.part_vf = partial + off;
+        group(n_single, off, 1, 128, 256, WV, W, G->g[P_VW], W + DVE, 0, G->g[P_VB]);
+        off += (size_t)n_single * va.stride_vf;
+        va.part_vd = partial + off;
+        group(n_single, off, 1, 128, 32, WV, DVE, G->g[P_VW], W + DVE, W, nullptr);
+        off += (size_t)n_single * va.stride_vd;
+    } else {
     {   // view layer, feature columns: A = sum over directions
         const size_t o = add(c48, n48, 128, 256, bwd + bl.dyvsum, WV, WV, acts + al.feat, W, W);
         group(n_single, o, 1, 128, 256, WV, W, G->g[P_VW], W + DVE, 0, G->g[P_VB]);
@@ -1387,6 +1591,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
             if (k == 0) first = o;
         }
         group(n_thin, first, 1 + V, 128, 32, WV, DVE, G->g[P_VW], W + DVE, W, nullptr);
+    }
     }
     {   // output head: A = DQ[k][:, 0:4], B = view hidden of direction k
         size_t first = 0;
@@ -1434,14 +1639,17 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
     }
     ProfScope ps("wgrad_small", st);
     if (precision == VIPNERF_PREC_FP32) {
-        if ((rc = launch_class<1, 8, 4>(c48, n48, n_single, st))) return rc;
+        if (view_fused) {
+            rc = V == 0 ? launch_view<1>(va, st) : (V == 1 ? launch_view<2>(va, st) : (V == 2 ? launch_view<3>(va, st) : launch_view<4>(va, st)));
+            if (rc) return rc;
+        } else if ((rc = launch_class<1, 8, 4>(c48, n48, n_single, st))) return rc;
         if ((rc = launch_class<2, 2, 4>(c82, n82, n_pe, st))) return rc;
     } else {
         if ((rc = launch_bf16x3<4, 8, 2>(c48, n48, n_single, st))) return rc;
         if ((rc = launch_bf16x3<8, 2, 1>(c82, n82, n_pe, st))) return rc;
     }
-    if ((rc = launch_class<1, 1, 4>(c41, n41, n_thin, st))) return rc;
-    if ((rc = launch_class<1, 2, 1>(c18, n18, n_sigma, st))) return rc;
+    if (n41 && (rc = launch_class<1, 1, 4>(c41, n41, n_thin, st))) return rc;
+    if (n18 && (rc = launch_class<1, 2, 1>(c18, n18, n_sigma, st))) return rc;
     if ((rc = launch_class<1, 1, 1>(c14, n14, n_thin, st))) return rc;
     return launch_wgrad_reduce(red, ng, st);
 }

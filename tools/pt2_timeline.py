@@ -60,7 +60,7 @@ if mode == 'wg':          # the exact-fp32 256 x 256 weight-gradient kernel: per
         print(f'wave {w}:', {k: (int(np.mean(v[2:])) if len(v) > 2 else None) for k, v in acc.items()}, 'blocks', len(acc['mfma loop']))
     sys.exit(0)
 narrow = os.environ.get('HIP_PRECISION', 'bf16') not in ('bf16', 'fp16')      # the 16-point kernels (exact fp32, split arithmetics): forward only
-fn = ((lib.vipnerf_exp_timeline_f32b if (os.environ.get('HIP_PRECISION') == 'fp32' and hasattr(lib, 'vipnerf_exp_timeline_f32b')) else lib.vipnerf_exp_timeline_nb) if mode == 'bwd' else lib.vipnerf_exp_timeline_n) if narrow else (lib.vipnerf_exp_timeline_bwd if mode == 'bwd' else lib.vipnerf_exp_timeline)
+fn = ((lib.vipnerf_exp_timeline_f32b if (os.environ.get('HIP_PRECISION') == 'fp32' and hasattr(lib, 'vipnerf_exp_timeline_f32b')) else lib.vipnerf_exp_timeline_nb) if mode == 'bwd' else (lib.vipnerf_exp_timeline_f32f if (os.environ.get('HIP_PRECISION') == 'fp32' and hasattr(lib, 'vipnerf_exp_timeline_f32f')) else lib.vipnerf_exp_timeline_n)) if narrow else (lib.vipnerf_exp_timeline_bwd if mode == 'bwd' else lib.vipnerf_exp_timeline)
 fn.restype = C.c_int
 buf = (C.c_ulonglong * 1024)()
 assert fn(buf, 1024) == 0

@@ -20,6 +20,7 @@ namespace vn {
 // h_1..h_8, the feature, the view hidden and its ReLU bits per direction, gamma(x) / gamma(dir) in their slot order -- written from the
 // B fragments the GEMMs consume anyway.
 // F32: exact-fp32 fragments (f32q, vipnerf_bf16.h): v_mfma_f32_16x16x4_f32, one MFMA per product, no split, no scaling.
+int launch_mlp_fwd_f32(const MlpFwdArgs &a, hipStream_t st);
 TS_DECL(g_n_timeline);
 #define TSN(tag) TS_AT(g_n_timeline, tag)
 
@@ -321,7 +322,11 @@ static int launch_one_n(const MlpFwdArgs &a, unsigned grid, hipStream_t st) {
 int launch_mlp_fwd_bf16n(const MlpFwdArgs &a, int precision, hipStream_t st) {
     if (a.src.P <= 0) return VIPNERF_OK;
     const unsigned grid = (unsigned)((a.src.P + MLP_PTS_PER_WG - 1) / MLP_PTS_PER_WG);
+#if VN_F32_FWD_V2
+    if (precision == 0) return launch_mlp_fwd_f32(a, st);      // the exact-fp32 kernels of vipnerf_mlp_fwd_f32.hip
+#else
     if (precision == 0) return a.acts ? launch_one_n<true, 2, false, VN_F32_DEFER ? 3 : 0, true>(a, grid, st) : launch_one_n<false, 2, false, 0, true>(a, grid, st);
+#endif
     if (precision == 1) return a.acts ? launch_one_n<true, 2>(a, grid, st) : launch_one_n<false, 2>(a, grid, st);
     if (precision == 2) return a.acts ? launch_one_n<true, 3>(a, grid, st) : launch_one_n<false, 3>(a, grid, st);
     if (precision == 3) return a.acts ? launch_one_n<true, 2, true, VN_F16_PRESPLIT ? 2 : 0>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);

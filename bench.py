@@ -69,8 +69,6 @@ ARITH = {
              'waves per SIMD), v_mfma_f32_32x32x2_f32 in the weight-gradient GEMMs; one MFMA per product'),
     'fp16x3': ('f32 emulated: operands split into 2 fp16 parts, 3 fp16 MFMAs per product, fp32 accumulate (22-bit operands, '
                'fp16 exponent range with power-of-two scaling; fp32-grade error on the goldens)', F16_MFMA_PEAK_TFLOPS, 3, ''),
-    'bf16x6': ('f32 emulated: operands split into 3 bf16 parts, 6 bf16 MFMAs per product, fp32 accumulate', F16_MFMA_PEAK_TFLOPS, 6, ''),
-    'bf16x3': ('f32 emulated: 2 bf16 parts, 3 bf16 MFMAs per product (~5e-6 relative error)', F16_MFMA_PEAK_TFLOPS, 3, ''),
     'fp16x3h': ('mixed: fp16x3 forward / data gradients (fp32-grade outputs and losses); every weight-gradient operand stored as fp16 tiles, '
                 'weight gradients 1 fp16 MFMA per product (gradients ~1e-4 relative)', F16_MFMA_PEAK_TFLOPS, 3, ''),
     'fp16': ('f16 operands (rounded once, power-of-two scaling), ONE fp16 MFMA per product, fp32 accumulate; trunk activations / '

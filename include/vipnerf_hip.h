@@ -32,22 +32,23 @@
 extern "C" {
 #endif
 
-#define VIPNERF_ABI_VERSION 4
+#define VIPNERF_ABI_VERSION 5
 
 #define VIPNERF_OK             0
 #define VIPNERF_E_ARG         (-1)   /* null / inconsistent argument */
 #define VIPNERF_E_UNSUPPORTED (-2)   /* configuration outside the supported topology / sizes */
 #define VIPNERF_E_HIP         (-3)   /* a HIP runtime call failed (text in vipnerf_last_error) */
 
-/* MLP GEMM arithmetic.  FP32: v_mfma_f32_32x32x2_f32, bit-equivalent to an fmaf chain (the parity default).
- * BF16X3 / BF16X6: operands split into 2 / 3 bf16 parts, 3 / 6 cross terms on v_mfma_f32_32x32x16_bf16 with fp32
- * accumulation -- ~1e-5 / fp32-grade relative error per product at 5.3x / 2.7x the fp32 MFMA rate. */
+/* MLP GEMM arithmetic.  FP32: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, exact fp32 operands, products and accumulation, bit-equivalent to
+ * an fmaf chain (the parity default; BASELINE configs[1], [2], [3]).
+ * BF16X3 / BF16X6 (operands split into 2 / 3 bf16 parts): RETIRED with ABI 5 -- the codes stay reserved and every entry point refuses them
+ * with VIPNERF_E_UNSUPPORTED (no BASELINE configuration used them; FP16X3 is the fp32-grade fast arithmetic). */
 #define VIPNERF_PREC_FP32   0
 #define VIPNERF_PREC_BF16X3 1
 #define VIPNERF_PREC_BF16X6 2
 /* FP16X3: operands split into 2 fp16 parts (11 bits each), 3 cross terms on v_mfma_f32_16x16x32_f16 with fp32
  * accumulation, power-of-two operand scaling (vip-nerf_amd/csrc/vipnerf_bf16n.h): ~2^-21 relative error per product
- * at the cost of BF16X3.  Narrow lane layout only. */
+ * at 3 MFMAs per product. */
 #define VIPNERF_PREC_FP16X3 3
 /* FP16X3H ("mixed"): FP16X3 in the forward and data-gradient GEMMs (so outputs and losses are the FP16X3 ones), but the
  * 256-wide activations and gradients that only the weight-gradient GEMMs read back are stored as fp16 (2 bytes instead
@@ -65,8 +66,8 @@ extern "C" {
 #define VIPNERF_PREC_FP16   5
 #define VIPNERF_PREC_BF16   6
 
-/* Lane layout of the BF16X3 / BF16X6 kernels (same arithmetic, same stored activations):
- * WIDE: 32-point waves on 32x32x16 MFMA, one wave per SIMD; NARROW: 16-point waves on 16x16x32, two waves per SIMD. */
+/* Lane layout.  Every kernel runs the NARROW layout (16-point waves, two per SIMD); WIDE (32-point waves, one per SIMD: the round-1 kernel
+ * generation) was RETIRED with ABI 5 and is refused with VIPNERF_E_UNSUPPORTED.  DEFAULT == NARROW. */
 #define VIPNERF_LAYOUT_DEFAULT 0
 #define VIPNERF_LAYOUT_WIDE    1
 #define VIPNERF_LAYOUT_NARROW  2
@@ -96,8 +97,7 @@ typedef struct vipnerf_config {
                              entry; importance sampling is skipped.  0 in production. */
     int32_t perturb;      /* configs['model']['perturb'] && training: stratified jitter + random inverse-CDF draws */
     int32_t precision;    /* VIPNERF_PREC_*: arithmetic of the MLP GEMMs */
-    int32_t bf16_layout;  /* VIPNERF_LAYOUT_*: lane layout of the split-bf16 MLP kernels; 0 = library default
-                             (VIPNERF_LAYOUT_DEFAULT = the build's default, see vipnerf_build_info(); no environment variable changes it) */
+    int32_t bf16_layout;  /* VIPNERF_LAYOUT_DEFAULT (0) or VIPNERF_LAYOUT_NARROW: the one lane layout left; kept for struct compatibility */
     /* MLP topology (coarse and fine alike), configs['model']['*_mlp'][netdepth, netwidth, points_/views_positional_encoding_degree]
      * (VipNeRF01.py:458-470).  0 = the default.  The hand-written MFMA kernels are specialised on 8 / 256 / 10 / 4 -- what every
      * shipped reference config uses; any other topology (netdepth <= 8, netwidth <= 256 and a multiple of 8, degrees <= 16 / 8;
@@ -242,23 +242,21 @@ int32_t vipnerf_build_is_experiment(void);
 int32_t vipnerf_last_error(char *buf, size_t n);
 
 /* ---- weights -------------------------------------------------------------------------------------------- */
-/* Bytes of the packed (MFMA fragment order) image of one MLP for precision FP32: the wide-layout image followed by the narrow-layout
- * one (== vipnerf_packed_weights_bytes_p(VIPNERF_PREC_FP32)); valid for every entry point called with precision FP32. */
+/* Bytes of the packed (MFMA fragment order) image of one MLP for precision FP32 (== vipnerf_packed_weights_bytes_p(VIPNERF_PREC_FP32));
+ * valid for every entry point called with precision FP32. */
 size_t  vipnerf_packed_weights_bytes(void);
 /* Re-lay one MLP's nn.Linear tensors into the streaming order the kernels consume (forward image, transposed
  * image for dgrad, LDS-resident heads/biases).  Replaces nothing in the reference; it is what lets
  * MLP.forward (VipNeRF01.py:509-596) run as one kernel.  Call after every optimizer step. */
 int32_t vipnerf_pack_weights(const vipnerf_mlp_params *params, void *packed, vipnerf_stream_t stream);
-/* Same for a given precision: the buffer holds the wide fp32 image followed by the image(s) of that precision's kernels
- * ([fp32 wide][wide split-bf16, BF16X3 / BF16X6 only][narrow image of the precision]).  A buffer packed for one precision must be
- * used with that precision (cfg.precision / the _p argument) only. */
+/* Same for a given precision: ONE image per precision (forward stages, transposed stages for the data gradient, LDS-resident block).  A
+ * buffer packed for one precision must be used with that precision (cfg.precision / the _p argument) only.  bytes_p returns 0 for an
+ * unknown or retired precision. */
 size_t  vipnerf_packed_weights_bytes_p(int32_t precision);
 int32_t vipnerf_pack_weights_p(const vipnerf_mlp_params *params, int32_t precision, void *packed, vipnerf_stream_t stream);
-/* The same by configuration.  Fused topology: the buffer has the size and layout of the _p call for cfg->precision, but ONLY the image
- * that cfg's kernels read (cfg->precision, cfg->bf16_layout resolved against the build's default) is written -- the rest of the buffer is
- * left untouched.  A buffer packed this way is valid for calls with the same precision and the same resolved layout, and NOT for the
- * unsuffixed stage entry points (they read the wide fp32 image at the buffer's head: use vipnerf_pack_weights / _p for those).  Any
- * other topology: the flat fp32 parameter buffer of the generic kernels (unused slots of params may be NULL: layers >= netdepth). */
+/* The same by configuration.  Fused topology: exactly the _p call for cfg->precision (the whole buffer is written; valid for every entry
+ * point called with that precision).  Any other topology: the flat fp32 parameter buffer of the generic kernels (unused slots of params
+ * may be NULL: layers >= netdepth). */
 size_t  vipnerf_packed_weights_bytes_c(const vipnerf_config *cfg);
 int32_t vipnerf_pack_weights_c(const vipnerf_config *cfg, const vipnerf_mlp_params *params, void *packed, vipnerf_stream_t stream);
 
@@ -366,7 +364,7 @@ int32_t vipnerf_sample_fine(int64_t n_rays, int32_t n_coarse, int32_t n_fine, co
 int32_t vipnerf_mlp_forward(int64_t n_points, int32_t n_sec, const float *pts, const float *view_dirs,
                             const float *view_dirs2, const float *noise, float noise_std, const void *packed,
                             float *sigma, float *rgb, float *vis, float *vis2, vipnerf_stream_t stream);
-/* vipnerf_mlp_forward with the GEMM arithmetic of `precision` (packed from vipnerf_pack_weights_p). */
+/* vipnerf_mlp_forward with the GEMM arithmetic of `precision` (packed from vipnerf_pack_weights_p); the unsuffixed call is its FP32 case. */
 int32_t vipnerf_mlp_forward_p(int64_t n_points, int32_t n_sec, const float *pts, const float *view_dirs,
                               const float *view_dirs2, const float *noise, float noise_std, int32_t precision,
                               const void *packed, float *sigma, float *rgb, float *vis, float *vis2,

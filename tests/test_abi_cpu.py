@@ -29,9 +29,11 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f'{n} declared in include/vipnerf_hip.h but not exported'
     assert set(names) == set(_lib.SYMBOLS), 'ctypes binding and header disagree'
-    assert lib.vipnerf_abi_version() == 4
-    wide = 4 * (72 * 8192 + 68 * 8192 + 7424)      # the unsuffixed pair = precision FP32: [wide image][narrow image]
-    assert lib.vipnerf_packed_weights_bytes() == lib.vipnerf_packed_weights_bytes_p(0) > wide
+    assert lib.vipnerf_abi_version() == 5
+    image = 4 * (36 * 16384 + 34 * 16384 + 7424)      # ONE image per precision (ABI 5): 36 forward + 34 data-gradient stages of 64 KiB + the resident block
+    assert lib.vipnerf_packed_weights_bytes() == lib.vipnerf_packed_weights_bytes_p(0) == image
+    assert lib.vipnerf_packed_weights_bytes_p(1) == 0 and lib.vipnerf_packed_weights_bytes_p(2) == 0      # the retired split-bf16 arithmetics
+    assert lib.vipnerf_packed_weights_bytes_p(3) > 0 and lib.vipnerf_packed_weights_bytes_p(6) > 0 and lib.vipnerf_packed_weights_bytes_p(7) == 0
 
 
 def test_struct_sizes_match_header():

@@ -16,15 +16,11 @@ sys.path.insert(0, os.path.join(ROOT, 'vip-nerf_amd', 'src'))
 from oracle import vipnerf_oracle as vo  # noqa: E402
 import test_hip_parity as tp  # noqa: E402
 
-PRECS = ['bf16x3', 'bf16x6', 'fp16x3']
-# the render-level tests run both lane layouts of the split-bf16 kernels (configs['model']['hip_bf16_layout']):
-# 'narrow' (16-point waves, the default) and 'wide' (32-point waves)
-MODES = ['bf16x3', 'bf16x6', 'fp16x3', 'fp16x3h', 'bf16x3-wide', 'bf16x6-wide', 'fp32-wide']     # fp32's default layout is narrow
-# (tests/test_hip_parity.py); 'fp32-wide' keeps the one-wave-per-SIMD v_mfma_f32_32x32x2_f32 kernels under test
-# relative-L2 tolerance on parameter gradients.  bf16x6 is fp32 grade (same bar as the fp32 path).  bf16x3 perturbs
-# activations by ~5e-6 relative, i.e. ~20x more ReLU pre-activations land on the other side of 0 than in fp32, and
-# the error is carried through 8 chained dgrad layers: measured 2-3e-3 on the deepest layer's weights.
-GRAD_TOL = {'bf16x3': 6e-3, 'bf16x6': 2e-3, 'fp16x3': 2e-3, 'fp16x3h': 2e-3, 'fp32': 2e-3}
+# (the split-bf16 arithmetics bf16x3 / bf16x6 and the 'wide' lane layout were retired with ABI 5: test_retired_modes_are_refused below)
+PRECS = ['fp16x3']
+MODES = ['fp16x3', 'fp16x3h']
+# relative-L2 tolerance on parameter gradients: fp32 grade (the same bar as the fp32 path)
+GRAD_TOL = {'fp16x3': 2e-3, 'fp16x3h': 2e-3, 'fp32': 2e-3}
 
 
 @pytest.fixture(scope='module')
@@ -48,6 +44,28 @@ def test_mlp_forward_golden(dev, prec, V):
         tp.assert_close(o['rgb'], g[f'rgb_{mode}'], what=f'{prec} rgb {mode}')
         tp.assert_close(o['visibility'], g[f'vis_{mode}'], what=f'{prec} vis {mode}')
         tp.assert_close(o['visibility2'], g[f'vis2_{mode}'], what=f'{prec} vis2 {mode}')
+
+
+def test_retired_modes_are_refused(dev):
+    """bf16x3, bf16x6 and hip_bf16_layout 'wide' fail LOUDLY (VIPNERF_E_UNSUPPORTED with the reason) in every entry point that takes a
+    precision or a configuration -- no silent fallback to another arithmetic."""
+    from vipnerf_hip._lib import VipNerfHipError
+    ops = tp.hip_ops()
+    params = vo.init_params(3, levels=('coarse',))
+    tensors = [tp.cu(params[f'coarse_model.{n}'], dev) for n in ops.PARAM_ORDER]
+    for prec in ('bf16x3', 'bf16x6'):
+        with pytest.raises(VipNerfHipError, match='retired'):
+            ops.pack_weights(tensors, precision=ops.PRECISIONS[prec])
+        b = vo.synthetic_batch(16, 5, scene='fern', nf=2)
+        model, _ = make_model(dev, True, vo.init_params(3), prec)
+        with pytest.raises(VipNerfHipError, match='retired'):
+            model(tp.ref_batch(b, dev, 0))
+    pk = ops.pack_weights(tensors)
+    with pytest.raises(VipNerfHipError, match='retired'):
+        ops.mlp_forward(pk, torch.zeros(4, 3, device=dev), torch.zeros(4, 3, device=dev), precision=ops.PRECISIONS['bf16x6'])
+    model, _ = make_model(dev, True, vo.init_params(3), 'fp32-wide')
+    with pytest.raises(VipNerfHipError, match='retired'):
+        model(tp.ref_batch(vo.synthetic_batch(16, 5, scene='fern', nf=2), dev, 0))
 
 
 def make_model(dev, ndc, params, mode, sparse=False):
@@ -172,7 +190,7 @@ def test_mlp_forward_ragged_and_empty(dev, prec):
     assert o['rgb'].shape == (0, 3)
 
 
-@pytest.mark.parametrize('prec', ['fp16x3', 'fp16x3h', 'bf16x6'])
+@pytest.mark.parametrize('prec', ['fp16x3', 'fp16x3h'])
 def test_full_size_step_properties(dev, prec):
     """BASELINE config 2 sizes (4096 rays x 64+128) in the bench arithmetics: determinism of a whole training step
     (outputs and all 48 gradients bit-identical run to run), ray independence of the eval render, finite values, and
@@ -246,7 +264,7 @@ def test_fp16x3_range(dev):
 # ------------------------------------------------------------------------------------------------ single-MFMA 16-bit modes
 # 'fp16' / 'bf16' (VIPNERF_PREC_FP16 / BF16): operands rounded ONCE to 16 bits, one MFMA per product -- BASELINE configs[4]'s
 # mixed precision, a separate accuracy class: (output rtol, output floor relative to the tensor's max, gradient rel. L2).
-# Measured on the goldens (tools/prec_diag.py, tools/grad_diag.py): fp16 rgb 3e-5 abs, sigma 3e-4 of max, gradients 1e-3
+# Measured on the goldens (round-2 diagnostics, docs/HISTORY.md): fp16 rgb 3e-5 abs, sigma 3e-4 of max, gradients 1e-3
 # median / 2.6e-2 worst tensor; bf16 2.6e-4, 2.4e-3, 1.6e-2 / 8.4e-2.
 SINGLE = {'fp16': (5e-3, 2e-3, 6e-2), 'bf16': (4e-2, 1.5e-2, 0.2)}
 

@@ -19,7 +19,7 @@ sizes = [1, 37, 256, 1000, 1024, 2048, 3000, 4096]
 batches = {(n, nf): bench.make_batch_oracle(vo, n, 7 + n + nf, dev) for n in sizes for nf in (2,)}
 for (n, nf), b in list(batches.items()):
     pass
-precs = ['fp32', 'fp16x3', 'fp16', 'bf16', 'fp16x3h', 'bf16x3']
+precs = ["fp32", "fp16x3", "fp16", "bf16", "fp16x3h"]
 mem = []
 t0 = time.time()
 for i in range(steps):

@@ -12,7 +12,7 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 dev = torch.device('cuda:0')
 batches = [bench.make_batch_oracle(vo, 1024, 5000 + (i % 8), dev) for i in range(8)]   # 8 batches of one synthetic scene, cycled
 curves = {}
-for prec in ('fp32', 'fp16x3', 'fp16x3h', 'bf16x6', 'fp16', 'bf16'):
+for prec in ('fp32', 'fp16x3', 'fp16x3h', 'fp16', 'bf16'):
     cfg = bench.model_configs(); cfg['model']['hip_precision'] = prec
     torch.manual_seed(0)
     model = get_model(cfg, None).to(dev).train()

@@ -63,6 +63,8 @@ ProfScope::~ProfScope() {
 // the device was still waking up) must not be reported as the failure of one of our launches.
 static inline void clear_stale_hip_error() { (void)hipGetLastError(); }
 
+static bool precision_retired(int precision) { return precision == VIPNERF_PREC_BF16X3 || precision == VIPNERF_PREC_BF16X6; }
+
 static int check_cfg(const vipnerf_config *cfg) {
     clear_stale_hip_error();
     if (!cfg) { set_error("cfg is NULL"); return VIPNERF_E_ARG; }
@@ -74,6 +76,12 @@ static int check_cfg(const vipnerf_config *cfg) {
         set_error("n_sec=%d unsupported (0..%d)", cfg->n_sec, VIPNERF_MAX_SEC); return VIPNERF_E_UNSUPPORTED; }
     if (cfg->precision < 0 || cfg->precision > VIPNERF_PREC_BF16) {
         set_error("precision=%d unsupported", cfg->precision); return VIPNERF_E_UNSUPPORTED; }
+    if (precision_retired(cfg->precision)) {
+        set_error("precision=%d (split bf16: bf16x3 / bf16x6) was retired with ABI 5 -- no BASELINE configuration uses it; fp16x3 is the fp32-grade "
+                  "fast arithmetic, bf16 / fp16 the mixed-precision ones", cfg->precision); return VIPNERF_E_UNSUPPORTED; }
+    if (cfg->bf16_layout == VIPNERF_LAYOUT_WIDE) {
+        set_error("bf16_layout = VIPNERF_LAYOUT_WIDE (32-point waves, one per SIMD) was retired with ABI 5: every kernel runs the narrow layout");
+        return VIPNERF_E_UNSUPPORTED; }
     if (cfg->bf16_layout < VIPNERF_LAYOUT_DEFAULT || cfg->bf16_layout > VIPNERF_LAYOUT_NARROW) {
         set_error("bf16_layout=%d unsupported", cfg->bf16_layout); return VIPNERF_E_UNSUPPORTED; }
     const int dpt = cfg->netdepth ? cfg->netdepth : D, wid = cfg->netwidth ? cfg->netwidth : W;
@@ -98,38 +106,21 @@ static GenTopo cfg_topo(const vipnerf_config *cfg) {
 }
 static bool cfg_generic(const vipnerf_config *cfg) { return !gen_is_fused_topology(cfg_topo(cfg)); }
 
-int launch_mlp_fwd_bf16(const MlpFwdArgs &a, int precision, hipStream_t st);
-int launch_mlp_bwd_bf16(const MlpBwdArgs &a, int precision, hipStream_t st);
 int launch_mlp_fwd_bf16n(const MlpFwdArgs &a, int precision, hipStream_t st);
 int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st);
 
-// The split-bf16 kernels exist in two lane layouts: "wide" (32-point waves, one per SIMD; vipnerf_bf16.h) and
-// "narrow" (16-point waves, two per SIMD; vipnerf_bf16n.h).  The packed buffer carries both images
-// ([fp32][wide][narrow]); cfg->bf16_layout picks the kernels (forward and data-gradient kernels must agree: the
-// ReLU masks are stored in fragment order), VIPNERF_LAYOUT_DEFAULT = the build's default below.  Nothing in the
-// environment changes the selection: what ran is a function of (cfg, vipnerf_build_info()) alone.
-// build switch VN_BF16_NARROW_DEFAULT (default 1, vipnerf_knobs.h)
-// build switch VN_FP32_NARROW_DEFAULT (default 1, vipnerf_knobs.h)
-static bool bf16_narrow(int layout = VIPNERF_LAYOUT_DEFAULT, int precision = 0) {
-    if (precision >= VIPNERF_PREC_FP16X3) return true;      // fp16 fragments exist in the narrow layout only
-    if (layout == VIPNERF_LAYOUT_WIDE) return false;        // exact fp32: wide = v_mfma_f32_32x32x2_f32, one wave per SIMD;
-    if (layout == VIPNERF_LAYOUT_NARROW) return true;       // narrow = v_mfma_f32_16x16x4_f32, two waves per SIMD
-    return (precision == VIPNERF_PREC_FP32 ? VN_FP32_NARROW_DEFAULT : VN_BF16_NARROW_DEFAULT) != 0;
-}
-static size_t packed_floats_all(int precision) { return packed_total_floats(precision) + packed_narrow_floats(precision); }
+// ONE lane layout (the "narrow" one: 16-point waves, two per SIMD; vipnerf_bf16n.h) and one packed image per precision.  The round-1
+// "wide" generation (32-point waves, one per SIMD: k_mlp_fwd / k_mlp_bwd / k_mlp_*_bf16) and the split-bf16 arithmetics (bf16x3, bf16x6)
+// were retired with ABI 5 (docs/HISTORY.md 4.1, 4.1b hold their measurements).
+static size_t packed_floats_all(int precision) { return packed_narrow_floats(precision); }
 
-static int launch_mlp_fwd_any(MlpFwdArgs &a, int precision, hipStream_t st, int layout = VIPNERF_LAYOUT_DEFAULT) {
-    if (precision == VIPNERF_PREC_FP32 && !bf16_narrow(layout, precision)) return launch_mlp_fwd(a, st);
-    if (bf16_narrow(layout, precision)) {
-        a.packed += packed_total_floats(precision);   // [fp32][wide] precede the narrow image
-        if (precision == VIPNERF_PREC_FP16 || precision == VIPNERF_PREC_BF16) {                       // single-MFMA modes: two point tiles per wave
-            if (!single_mfma_t16(precision)) { set_error("this library was built without T16 storage (VN_T16 / VN_BF16_H16 = 0): no single-MFMA 16-bit kernels"); return VIPNERF_E_UNSUPPORTED; }
-            return launch_mlp_fwd_pt2(a, precision, st);
-        }
-        return launch_mlp_fwd_bf16n(a, precision, st);
+static int launch_mlp_fwd_any(MlpFwdArgs &a, int precision, hipStream_t st) {
+    if (precision_retired(precision)) { set_error("precision=%d (split bf16) was retired with ABI 5", precision); return VIPNERF_E_UNSUPPORTED; }
+    if (precision == VIPNERF_PREC_FP16 || precision == VIPNERF_PREC_BF16) {                       // single-MFMA modes: two point tiles per wave
+        if (!single_mfma_t16(precision)) { set_error("this library was built without T16 storage (VN_T16 / VN_BF16_H16 = 0): no single-MFMA 16-bit kernels"); return VIPNERF_E_UNSUPPORTED; }
+        return launch_mlp_fwd_pt2(a, precision, st);
     }
-    a.packed += PK_TOTAL_F;                       // the wide split-bf16 image follows the fp32 image
-    return launch_mlp_fwd_bf16(a, precision, st);
+    return launch_mlp_fwd_bf16n(a, precision, st);
 }
 
 static int check_rays(const vipnerf_config *cfg, const vipnerf_rays *r) {
@@ -187,18 +178,19 @@ int32_t vipnerf_last_error(char *buf, size_t n) {
     return VIPNERF_OK;
 }
 
-static int pack_wide_fp32(const vipnerf_mlp_params *params, void *packed, vipnerf_stream_t stream) {
+static int check_pack_args(const vipnerf_mlp_params *params, void *packed) {
     clear_stale_hip_error();
     if (!params || !packed) { set_error("pack_weights: NULL argument"); return VIPNERF_E_ARG; }
     for (int i = 0; i < VIPNERF_N_PARAMS; ++i)
         if (!params->p[i]) { set_error("pack_weights: parameter %d is NULL", i); return VIPNERF_E_ARG; }
-    return launch_pack(params, packed, (hipStream_t)stream);
+    return VIPNERF_OK;
 }
 
-size_t vipnerf_packed_weights_bytes_p(int32_t precision) { return packed_floats_all(precision) * sizeof(float); }
+size_t vipnerf_packed_weights_bytes_p(int32_t precision) {
+    return (precision < 0 || precision > VIPNERF_PREC_BF16 || precision_retired(precision)) ? 0 : packed_floats_all(precision) * sizeof(float);
+}
 
-// The unsuffixed pair is the FP32 case of the _p pair: [wide fp32 image][narrow fp32 image] -- every entry point that takes a packed
-// buffer (the render calls default to the narrow exact-fp32 kernels) accepts what it produces.
+// The unsuffixed pair is the FP32 case of the _p pair.
 size_t vipnerf_packed_weights_bytes(void) { return vipnerf_packed_weights_bytes_p(VIPNERF_PREC_FP32); }
 
 int32_t vipnerf_pack_weights(const vipnerf_mlp_params *params, void *packed, vipnerf_stream_t stream) {
@@ -207,11 +199,10 @@ int32_t vipnerf_pack_weights(const vipnerf_mlp_params *params, void *packed, vip
 
 int32_t vipnerf_pack_weights_p(const vipnerf_mlp_params *params, int32_t precision, void *packed, vipnerf_stream_t stream) {
     if (precision < 0 || precision > VIPNERF_PREC_BF16) { set_error("pack_weights: precision=%d unsupported", precision); return VIPNERF_E_UNSUPPORTED; }
-    int rc = pack_wide_fp32(params, packed, stream);
+    if (precision_retired(precision)) { set_error("pack_weights: precision=%d (split bf16) was retired with ABI 5", precision); return VIPNERF_E_UNSUPPORTED; }
+    int rc = check_pack_args(params, packed);
     if (rc) return rc;
-    if (precision != VIPNERF_PREC_FP32 && precision < VIPNERF_PREC_FP16X3 &&
-        (rc = launch_pack_bf16(params, precision, (float *)packed + PK_TOTAL_F, (hipStream_t)stream))) return rc;
-    return launch_pack_bf16n(params, precision, (float *)packed + packed_total_floats(precision), (hipStream_t)stream);
+    return launch_pack_bf16n(params, precision, (float *)packed, (hipStream_t)stream);
 }
 
 size_t vipnerf_packed_weights_bytes_c(const vipnerf_config *cfg) {
@@ -222,18 +213,7 @@ size_t vipnerf_packed_weights_bytes_c(const vipnerf_config *cfg) {
 int32_t vipnerf_pack_weights_c(const vipnerf_config *cfg, const vipnerf_mlp_params *params, void *packed, vipnerf_stream_t stream) {
     int rc = check_cfg(cfg);
     if (rc) return rc;
-    if (!cfg_generic(cfg)) {
-        // the images cfg's kernels read, and only those: the wide fp32 image at the buffer's head serves the wide exact-fp32 kernels and the
-        // unsuffixed stage API alone (vipnerf_pack_weights / _p fill it always) -- two launches per training step that nothing would read
-        const int prec = cfg->precision;
-        if (prec == VIPNERF_PREC_FP32 && !bf16_narrow(cfg->bf16_layout, prec)) return pack_wide_fp32(params, packed, stream);
-        if (!params || !packed) { set_error("pack_weights: NULL argument"); return VIPNERF_E_ARG; }
-        for (int i = 0; i < VIPNERF_N_PARAMS; ++i)
-            if (!params->p[i]) { set_error("pack_weights: parameter %d is NULL", i); return VIPNERF_E_ARG; }
-        if (prec != VIPNERF_PREC_FP32 && prec < VIPNERF_PREC_FP16X3 && !bf16_narrow(cfg->bf16_layout, prec))
-            return launch_pack_bf16(params, prec, (float *)packed + PK_TOTAL_F, (hipStream_t)stream);
-        return launch_pack_bf16n(params, prec, (float *)packed + packed_total_floats(prec), (hipStream_t)stream);
-    }
+    if (!cfg_generic(cfg)) return vipnerf_pack_weights_p(params, cfg->precision, packed, stream);
     if (!params || !packed) { set_error("pack_weights: NULL argument"); return VIPNERF_E_ARG; }
     return launch_gen_pack(cfg_topo(cfg), params, (float *)packed, (hipStream_t)stream);
 }
@@ -288,20 +268,8 @@ int32_t vipnerf_sample_fine(int64_t n_rays, int32_t n_coarse, int32_t n_fine, co
 int32_t vipnerf_mlp_forward(int64_t n_points, int32_t n_sec, const float *pts, const float *view_dirs,
                             const float *view_dirs2, const float *noise, float noise_std, const void *packed,
                             float *sigma, float *rgb, float *vis, float *vis2, vipnerf_stream_t stream) {
-    // `packed` comes from vipnerf_pack_weights: the wide fp32 image only
-    clear_stale_hip_error();
-    if (n_points == 0) return VIPNERF_OK;
-    if (!pts || !view_dirs || !packed || !sigma || !rgb || !vis || (n_sec > 0 && (!view_dirs2 || !vis2))) {
-        set_error("mlp_forward: NULL argument"); return VIPNERF_E_ARG; }
-    if (n_sec < 0 || n_sec > VIPNERF_MAX_SEC) { set_error("mlp_forward: n_sec=%d unsupported", n_sec); return VIPNERF_E_UNSUPPORTED; }
-    MlpFwdArgs a;
-    memset(&a, 0, sizeof(a));
-    a.src.P = n_points; a.src.S = 1; a.src.V = n_sec; a.src.rays_mode = 0;
-    a.src.pts = pts; a.src.dirs = view_dirs; a.src.dirs2 = view_dirs2;
-    a.ns.noise = noise; a.ns.std = noise_std;
-    a.packed = (const float *)packed;
-    a.sigma = sigma; a.rgb = rgb; a.vis = vis; a.vis2 = vis2;
-    return launch_mlp_fwd(a, (hipStream_t)stream);
+    // the FP32 case of vipnerf_mlp_forward_p (`packed` from vipnerf_pack_weights)
+    return vipnerf_mlp_forward_p(n_points, n_sec, pts, view_dirs, view_dirs2, noise, noise_std, VIPNERF_PREC_FP32, packed, sigma, rgb, vis, vis2, stream);
 }
 
 int32_t vipnerf_mlp_forward_p(int64_t n_points, int32_t n_sec, const float *pts, const float *view_dirs,
@@ -405,7 +373,7 @@ int32_t vipnerf_render_forward(const vipnerf_config *cfg, const vipnerf_rays *ra
             if ((rc = launch_gen_fwd(t, ma.src, ma.ns, ma.packed, ma.sigma, ma.rgb, ma.vis, ma.vis2, ga, st))) return rc;
         } else {
             ProfScope ps(lv ? "mlp_fwd_fine" : "mlp_fwd_coarse", st);
-            if ((rc = launch_mlp_fwd_any(ma, cfg->precision, st, cfg->bf16_layout))) return rc;
+            if ((rc = launch_mlp_fwd_any(ma, cfg->precision, st))) return rc;
         }
         // 3./6. compositing
         CompositeArgs ca;
@@ -485,10 +453,7 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
         mb.bwd = bw; mb.bl = bl;
         {
             ProfScope ps(lv ? "mlp_dgrad_fine" : "mlp_dgrad_coarse", st);
-            if (cfg->precision == VIPNERF_PREC_FP32 && !bf16_narrow(cfg->bf16_layout, cfg->precision)) rc = launch_mlp_bwd(mb, st);
-            else if (bf16_narrow(cfg->bf16_layout, cfg->precision)) { mb.packed += packed_total_floats(cfg->precision); rc = launch_mlp_bwd_bf16n(mb, cfg->precision, st); }
-            else { mb.packed += PK_TOTAL_F; rc = launch_mlp_bwd_bf16(mb, cfg->precision, st); }
-            if (rc) return rc;
+            if ((rc = launch_mlp_bwd_bf16n(mb, cfg->precision, st))) return rc;
         }
         // 3. weight gradients: dW = dY^T H as MFMA GEMMs over the point axis
 #if defined(VN_EXP)

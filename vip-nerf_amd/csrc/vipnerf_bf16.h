@@ -15,54 +15,6 @@ namespace vn {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int NS>
-struct BfPlan {
-    static constexpr int KSB = NS == 2 ? 4 : 2;              // k-steps (of 16) per stage for an 8-tile layer
-    static constexpr int CH = KSB * 8 * NS;                  // chunks (1 KiB) per stage: 64 (NS=2) / 48 (NS=3)
-    // LDS stage ring; the DMA runs NBUF-1 stages ahead.  Measured: a deeper ring of smaller stages (4 x 32 KiB /
-    // 5 x 24 KiB) is SLOWER than 2 x 64 / 2 x 48 KiB -- the stream's cost is the issue time of its
-    // global_load_lds instructions (~60 cycles per 1 KiB piece with no second wave to feed the MFMA pipe), not its
-    // latency or fill rate, and the extra barriers cost more than the smoothing gains (docs/HISTORY.md 4.1b).
-    static constexpr int NBUF = 2;
-    static constexpr int STAGE_F = CH * CHUNK_F;             // in float units
-    static constexpr int ST_256 = 16 / KSB;                  // stages of a 256-deep contraction over 8 tiles
-    static constexpr int ST_PE = 4 / KSB;                    // gamma(x): K = 64 -> 4 k-steps
-    static constexpr int KSV = 2 * KSB;                      // k-steps per stage when a stage spans 4 tiles
-    static constexpr int ST_VIEW_F = 16 / KSV;               // view layer forward: 4 tiles x 16 k-steps
-    static constexpr int ST_VIEW_B = 8 / KSB;                // view layer dgrad: 8 tiles x 8 k-steps (K = 128)
-    static constexpr int FS_L0PE = 0;
-    static constexpr int FS_L1 = FS_L0PE + ST_PE;
-    static constexpr int FS_L5PE = FS_L1 + 4 * ST_256;
-    static constexpr int FS_L5 = FS_L5PE + ST_PE;
-    static constexpr int FS_L6 = FS_L5 + ST_256;
-    static constexpr int FS_L7 = FS_L6 + ST_256;
-    static constexpr int FS_FEAT = FS_L7 + ST_256;
-    static constexpr int FS_VIEW = FS_FEAT + ST_256;
-    static constexpr int F_STAGES = FS_VIEW + ST_VIEW_F;
-    static constexpr int BS_VIEW = 0;
-    static constexpr int BS_FEAT = BS_VIEW + ST_VIEW_B;
-    static constexpr int BS_L7 = BS_FEAT + ST_256;
-    static constexpr int B_STAGES = BS_L7 + 7 * ST_256;
-    // LDS-resident block: direction columns of the view layer as bf16 fragments (2 k-steps x 4 tiles x NS chunks),
-    // then the fp32 biases / heads exactly as in the fp32 image (R_BIAS .. R_TOTAL)
-    static constexpr int R_DIRW = 0;
-    static constexpr int R_DIRW_F = 2 * 4 * NS * CHUNK_F;
-    static constexpr int R_F32 = R_DIRW_F;                   // + (R_x - R_BIAS) for the fp32 entries
-    static constexpr int R_TOTAL = R_F32 + (vn::R_TOTAL - vn::R_BIAS);
-    static constexpr int R_TOTAL_PAD = (R_TOTAL + 255) / 256 * 256;
-    static constexpr size_t PK_FWD = 0;
-    static constexpr size_t PK_BWD = PK_FWD + (size_t)F_STAGES * STAGE_F;
-    static constexpr size_t PK_RES = PK_BWD + (size_t)B_STAGES * STAGE_F;
-    static constexpr size_t PK_TOTAL_F = PK_RES + R_TOTAL_PAD;
-    static constexpr int LDS_F = R_TOTAL_PAD + NBUF * STAGE_F;
-    static_assert(LDS_F * 4 <= 160 * 1024, "LDS budget");
-};
-
-// float offsets inside the packed buffer: [fp32 image][bf16x3 image] or [fp32 image][bf16x6 image]
-__host__ __device__ inline size_t packed_total_floats(int precision) {
-    return PK_TOTAL_F + (precision == 1 ? BfPlan<2>::PK_TOTAL_F : (precision == 2 ? BfPlan<3>::PK_TOTAL_F : 0));
-}
-
 #if defined(__HIPCC__)
 // part i of the split of x (i = 0: bf16(x); 1: bf16(x - x0); 2: bf16(x - x0 - x1)), round-to-nearest-even
 __device__ __forceinline__ __bf16 split_part(float x, int i) {
@@ -124,9 +76,6 @@ __device__ __forceinline__ void split8(const float (&x)[8], half8 (&out)[NS]) {
 }
 __device__ __forceinline__ floatx4 mfma_bf(half8 a, half8 b, floatx4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ floatx16 mfma_bf(bf16x8 a, bf16x8 b, floatx16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 // 16x16x32: lane l supplies A[i = l&15][k = 8*(l>>4) + e] and B[k = 8*(l>>4) + e][j = l&15]; D[i = 4*(l>>4) + r][j = l&15]
 __device__ __forceinline__ floatx4 mfma_bf(bf16x8 a, bf16x8 b, floatx4 c) {
@@ -422,6 +371,5 @@ __device__ __forceinline__ void gemm_stage_bf(const float *stage, int lane, ACC 
 }
 #endif
 
-int launch_pack_bf16(const vipnerf_mlp_params *p, int precision, void *packed_bf, hipStream_t st);
 
 }  // namespace vn

@@ -33,61 +33,10 @@ constexpr int SKIP_LAYER = 5;   // layer whose input is [gamma(x), h]
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-// ----------------------------------------------------------------------------------------------- fragments
-// v_mfma_f32_32x32x2_f32: D[i][j] += sum_{kk<2} A[i][kk] B[kk][j];  lane l supplies A[i = l&31][kk = l>>5] and
-// B[kk = l>>5][j = l&31]; D register r of lane l is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
-// With 8 row tiles, "register index" r in [0,128) = 16*tile + reg.  feat(r, h) is the feature (row) that
-// register r of a lane in half h holds.
-__host__ __device__ inline int feat_of(int r, int h) {
-    const int t = r >> 4, rr = r & 15;
-    return 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * h;
-}
-
 // ----------------------------------------------------------------------------------------------- packed image
-// One chunk = the A operands of 4 consecutive k-steps for one 32-row tile: 64 lanes x float4 = 1 KiB.
+// One chunk = the A operands one ds_read_b128 per lane fetches for one 16-feature tile: 64 lanes x float4 = 1 KiB (vipnerf_bf16n.h: BnPlan
+// lays the stages of an MLP's packed image out of them).
 constexpr int CHUNK_F = 256;                    // floats per chunk
-// build switch VN_STAGE_CHUNKS (default 64, vipnerf_knobs.h)
-constexpr int STAGE_CHUNKS = VN_STAGE_CHUNKS;   // 64 KiB stages: half the workgroup barriers of 32 KiB ones
-constexpr int STAGE_F = CHUNK_F * STAGE_CHUNKS;
-constexpr int KGS8 = STAGE_CHUNKS / 8;          // kgroups per stage when a stage spans 8 row tiles
-constexpr int KGS4 = STAGE_CHUNKS / 4;          // ... 4 row tiles (view layer forward)
-constexpr int ST_256 = 32 / KGS8;               // stages of a 256-wide contraction over 8 tiles
-constexpr int ST_PE = 8 / KGS8;                 // gamma(x): K = 64 -> 8 kgroups
-constexpr int ST_VIEW_F = 32 / KGS4;            // view layer forward: 4 tiles x 32 kgroups
-constexpr int ST_VIEW_B = 16 / KGS8;            // view layer dgrad: 8 tiles x 16 kgroups
-
-// forward stream, in consumption order (stage indices)
-constexpr int FS_L0PE = 0;                      // 8 tiles x 8 kgroups (K = 64: gamma(x))
-constexpr int FS_L1 = FS_L0PE + ST_PE;          // L1..L4
-constexpr int FS_L5PE = FS_L1 + 4 * ST_256;
-constexpr int FS_L5 = FS_L5PE + ST_PE;
-constexpr int FS_L6 = FS_L5 + ST_256;
-constexpr int FS_L7 = FS_L6 + ST_256;
-constexpr int FS_FEAT = FS_L7 + ST_256;         // feature_linear
-constexpr int FS_VIEW = FS_FEAT + ST_256;       // views_linears[0][:, 0:256]
-constexpr int F_STAGES = FS_VIEW + ST_VIEW_F;
-
-// backward (dgrad) stream: A = W^T
-constexpr int BS_VIEW = 0;                      // 8 tiles(k) x 16 kgroups(o in 128)
-constexpr int BS_FEAT = BS_VIEW + ST_VIEW_B;
-constexpr int BS_L7 = BS_FEAT + ST_256;         // then L6, L5 (h part), L4, L3, L2, L1
-constexpr int B_STAGES = BS_L7 + 7 * ST_256;
-
-// LDS-resident block (floats)
-constexpr int R_DIRW = 0;                       // 4 kgroups x 4 tiles chunks: views_linears[0][:, 256:283]
-constexpr int R_BIAS = R_DIRW + 16 * CHUNK_F;   // [8 layers][8 tiles][2 halves][16]
-constexpr int R_BFEAT = R_BIAS + D * W;         // [8][2][16]
-constexpr int R_BVIEW = R_BFEAT + W;            // [4][2][16]
-constexpr int R_WSIG = R_BVIEW + WV;            // [2][128]  w_sigma[feat(r,h)]
-constexpr int R_WOUT = R_WSIG + W;              // [2][4][64] W_o[c][feat(r,h)]
-constexpr int R_BHEAD = R_WOUT + 4 * WV;        // b_sigma, b_o[0..3], pad
-constexpr int R_TOTAL = R_BHEAD + 8;            // 7304 floats
-constexpr int R_TOTAL_PAD = 7424;               // multiple of 256
-
-constexpr size_t PK_FWD = 0;
-constexpr size_t PK_BWD = PK_FWD + (size_t)F_STAGES * STAGE_F;
-constexpr size_t PK_RES = PK_BWD + (size_t)B_STAGES * STAGE_F;
-constexpr size_t PK_TOTAL_F = PK_RES + R_TOTAL_PAD;
 
 // parameter slots (vipnerf_mlp_params::p)
 constexpr int P_LW0 = 0;      // pts_linears[i].weight = 2*i, bias = 2*i+1

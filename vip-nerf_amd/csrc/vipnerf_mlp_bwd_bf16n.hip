@@ -288,8 +288,7 @@ int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
 #else
     if (precision == 0) return launch_one_bwd_n<2, false, VN_F32_DEFER ? 3 : 0, true>(a, grid, st);
 #endif
-    if (precision == 1) return launch_one_bwd_n<2>(a, grid, st);
-    if (precision == 2) return launch_one_bwd_n<3>(a, grid, st);
+    // (precisions 1 / 2, the split-bf16 arithmetics bf16x3 / bf16x6, were retired with ABI 5)
     if ((precision == 5 || precision == 6) && !single_mfma_t16(precision)) {
         set_error("this library was built without T16 storage (VN_T16 / VN_BF16_H16 = 0): no single-MFMA 16-bit kernels"); return VIPNERF_E_UNSUPPORTED; }
     if (precision == 6) return launch_mlp_bwd_pt2(a, precision, st);     // two point tiles per wave (the 16-point NS = 1 form is retired)

@@ -327,8 +327,7 @@ int launch_mlp_fwd_bf16n(const MlpFwdArgs &a, int precision, hipStream_t st) {
 #else
     if (precision == 0) return a.acts ? launch_one_n<true, 2, false, VN_F32_DEFER ? 3 : 0, true>(a, grid, st) : launch_one_n<false, 2, false, 0, true>(a, grid, st);
 #endif
-    if (precision == 1) return a.acts ? launch_one_n<true, 2>(a, grid, st) : launch_one_n<false, 2>(a, grid, st);
-    if (precision == 2) return a.acts ? launch_one_n<true, 3>(a, grid, st) : launch_one_n<false, 3>(a, grid, st);
+    // (precisions 1 / 2, the split-bf16 arithmetics bf16x3 / bf16x6, were retired with ABI 5)
     if (precision == 3) return a.acts ? launch_one_n<true, 2, true, VN_F16_PRESPLIT ? 2 : 0>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);
     if (precision == 4) return a.acts ? launch_one_n<true, 2, true, VN_T16 ? 4 : 1>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);
     // (VIPNERF_PREC_FP16 / BF16: the two-point-tile kernels of vipnerf_mlp_fwd_pt2.hip; their 16-point NS = 1 forms are retired)

@@ -129,10 +129,6 @@ int launch_pack_bf16n(const vipnerf_mlp_params *p, int precision, void *packed_b
     const int bs = 256;
     if (precision == 0) {
         hipLaunchKernelGGL((k_pack_bf16n<2, false, true>), dim3((unsigned)((BnPlan<2>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);
-    } else if (precision == 1) {
-        hipLaunchKernelGGL((k_pack_bf16n<2, false>), dim3((unsigned)((BnPlan<2>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);
-    } else if (precision == 2) {
-        hipLaunchKernelGGL((k_pack_bf16n<3, false>), dim3((unsigned)((BnPlan<3>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);
     } else if (precision == 3 || precision == 4) {
         hipLaunchKernelGGL((k_pack_bf16n<2, true>), dim3((unsigned)((BnPlan<2>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);
     } else if (precision == 5) {

@@ -659,169 +659,6 @@ static int launch_bf16x3(const WgArgs &args, int n_desc, int n_chunks, hipStream
     return VIPNERF_OK;
 }
 
-// The 256x256 class (8 of the 14 GEMMs, 95 % of the work), hand-specialised: compile-time strides, linear tile loads.
-// The 256x256 class on split-precision bf16 MFMA ("bf16x3": hi/lo parts, 3 cross terms, fp32 accumulate).  The fp32
-// rows of A and B are split while they are staged: a thread holds 4 features x 8 points of each operand (its linear
-// 16 B/lane tile loads), converts them to two bf16 planes and writes, per feature and plane, the 8 points as ONE
-// 16-byte LDS store -- the transposition the fragment needs (lane = feature, 8 consecutive k = points) happens in
-// that write.  LDS plane layout: [feature][4 slots of 8 points], slot XOR-swizzled by (feature >> 2) & 3 so that
-// the 16-lane groups of ds_read_b128 hit 16 distinct slots.  The order of the 32 points inside a block is a fixed
-// permutation (slot = loading wave), identical for A and B, which a contraction index may be.
-template <bool HAS_W>
-__device__ __forceinline__ void wgrad_bf16x3_256_body(const WgArgs &a) {
-    constexpr int MTW = 2, KTW = 8, Mp = 256, Kp = 256;
-    constexpr int PLANE = 256 * 64;                       // bytes: one operand, one part, 256 features x 32 points
-    constexpr int BUF = 4 * PLANE;                        // A hi, A lo, B hi, B lo
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    char *lb = (char *)lds;
-    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-    const WgDesc &d = a.d[blockIdx.y];
-    if ((int)blockIdx.x >= d.n_chunks) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = lane >> 5, l31 = lane & 31;
-    const int64_t p0 = (int64_t)blockIdx.x * a.chunk_pts;
-    const int64_t p1 = p0 + a.chunk_pts < a.P ? p0 + a.chunk_pts : a.P;
-    const int nblk = (int)((p1 - p0 + 31) / 32);
-
-    floatx16 acc[MTW][KTW];
-#pragma unroll
-    for (int i = 0; i < MTW; ++i)
-#pragma unroll
-        for (int j = 0; j < KTW; ++j) acc[i][j] = (floatx16)(0.f);
-    float bs[4] = {0.f, 0.f, 0.f, 0.f};                   // column sums of A for this thread's 4 features (its 8 points per block)
-    float ws[4] = {0.f, 0.f, 0.f, 0.f}, wsum = 0.f;       // wcol: weighted column sums of B, sum of the weights
-    float wv[8];
-    constexpr bool has_w = HAS_W;
-
-    float4 ra[8], rb[8];                                  // rows wave + 4 i, features 4 (tid & 63) .. + 3
-    auto gload = [&](int blk) {
-        const int64_t pb = p0 + (int64_t)blk * 32;
-        if (has_w) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int64_t row = pb + wave + 4 * i;
-                wv[i] = row < p1 ? d.wcol[(size_t)row * d.wcol_stride] : 0.f;
-            }
-        }
-        if (pb + 32 <= p1) {
-            const float4 *ta = (const float4 *)(d.A + (size_t)pb * Mp) + tid;
-            const float4 *tb = (const float4 *)(d.B + (size_t)pb * Kp) + tid;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { ra[i] = ta[256 * i]; rb[i] = tb[256 * i]; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int64_t row = pb + wave + 4 * i;
-                const bool ok = row < p1;
-                ra[i] = ok ? *((const float4 *)(d.A + (size_t)row * Mp) + lane) : make_float4(0.f, 0.f, 0.f, 0.f);
-                rb[i] = ok ? *((const float4 *)(d.B + (size_t)row * Kp) + lane) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    };
-    auto put = [&](char *plane, int f, const float (&x)[8]) {   // 8 points of feature f -> hi / lo planes
-        bf16x8 hi, lo;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { hi[e] = (__bf16)x[e]; lo[e] = (__bf16)(x[e] - (float)hi[e]); }
-        const int off = wg_off<256>(f, wave);
-        *(bf16x8 *)(plane + off) = hi;
-        *(bf16x8 *)(plane + PLANE + off) = lo;
-    };
-    auto lstore = [&](int buf) {
-        char *base = lb + buf * BUF;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float xa[8], xb[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                xa[i] = c == 0 ? ra[i].x : (c == 1 ? ra[i].y : (c == 2 ? ra[i].z : ra[i].w));
-                xb[i] = c == 0 ? rb[i].x : (c == 1 ? rb[i].y : (c == 2 ? rb[i].z : rb[i].w));
-                bs[c] += xa[i];
-                if (has_w) ws[c] = fmaf(wv[i], xb[i], ws[c]);
-            }
-            put(base, 4 * lane + c, xa);
-            put(base + 2 * PLANE, 4 * lane + c, xb);
-        }
-        if (has_w) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) wsum += wv[i];
-        }
-    };
-
-    if (nblk > 0) { gload(0); lstore(0); }
-    __syncthreads();
-    int cur = 0;
-    for (int blk = 0; blk < nblk; ++blk) {
-        if (blk + 1 < nblk) gload(blk + 1);
-        const char *base = lb + cur * BUF;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int slot = 2 * ks + h;
-            bf16x8 af[MTW][2], bf[KTW][2];
-#pragma unroll
-            for (int i = 0; i < MTW; ++i) {
-                const int f = 32 * (wave * MTW + i) + l31;
-                const int off = wg_off<256>(f, slot);
-                af[i][0] = *(const bf16x8 *)(base + off);
-                af[i][1] = *(const bf16x8 *)(base + PLANE + off);
-            }
-#pragma unroll
-            for (int j = 0; j < KTW; ++j) {
-                const int f = 32 * j + l31;
-                const int off = wg_off<256>(f, slot);
-                bf[j][0] = *(const bf16x8 *)(base + 2 * PLANE + off);
-                bf[j][1] = *(const bf16x8 *)(base + 3 * PLANE + off);
-            }
-#pragma unroll
-            for (int i = 0; i < MTW; ++i)
-#pragma unroll
-                for (int j = 0; j < KTW; ++j) {
-                    floatx16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
-                    acc[i][j] = c;
-                }
-        }
-        if (blk + 1 < nblk) lstore(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-    }
-
-    float *part = a.partial + d.part_off + (size_t)blockIdx.x * d.part_stride;
-#pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-        const int ot = wave * MTW + i;
-#pragma unroll
-        for (int j = 0; j < KTW; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * h;
-                part[(size_t)o * Kp + 32 * j + l31] = acc[i][j][r];
-            }
-    }
-    // bias column sums: every wave holds the sums of ITS points for all 256 features -> fold the 4 waves through LDS
-    float *red = (float *)lb;                              // all fragment reads are behind the loop's last barrier
-#pragma unroll
-    for (int c = 0; c < 4; ++c) red[wave * 256 + 4 * lane + c] = bs[c];
-    __syncthreads();
-    part[(size_t)Mp * Kp + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
-    if (has_w) {                                           // weighted column sums of B and the weight sum, same folding
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < 4; ++c) red[wave * 256 + 4 * lane + c] = ws[c];
-        if (lane == 0) red[1024 + wave] = wsum;            // every lane of a wave saw the same 8 rows per block
-        __syncthreads();
-        part[(size_t)Mp * Kp + Mp + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
-        if (tid == 0) part[(size_t)Mp * Kp + Mp + 256] = (red[1024] + red[1025]) + (red[1026] + red[1027]);
-    }
-}
-// one launch for the eight 256x256 GEMMs; the one that carries a weight column (sigma head) takes the second body, so the
-// other seven run exactly the plain code
-__global__ __launch_bounds__(256) void k_wgrad_bf16x3_256(WgArgs a) {
-    if (a.d[blockIdx.y].wcol) wgrad_bf16x3_256_body<true>(a);
-    else wgrad_bf16x3_256_body<false>(a);
-}
 
 // The 256x256 class when both operands were STORED as fp16 ([P][256] halves: the trunk activations h_1..h_8 and the
 // gradients dY_1..dY_7, dY_feature).  PARTS = 1 (FP16X3H): high parts only, ONE v_mfma_f32_32x32x16_f16 per product --
@@ -1630,11 +1467,9 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
             VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_split16_256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
             hipLaunchKernelGGL(k_wgrad_split16_256, dim3(n_chunks, n88), dim3(256), ldsb, st, c88);
             VN_HIP(hipGetLastError());
-        } else {                                   // bf16x3 and bf16x6 both use the hi/lo kernel for the weight gradients
-            const size_t ldsb = (size_t)2 * 4 * 256 * 64;
-            VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_bf16x3_256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-            hipLaunchKernelGGL(k_wgrad_bf16x3_256, dim3(n_chunks, n88), dim3(256), ldsb, st, c88);
-            VN_HIP(hipGetLastError());
+        } else {
+            set_error("wgrad: precision %d has no 256 x 256 weight-gradient kernel (the split-bf16 arithmetics were retired with ABI 5)", precision);
+            return VIPNERF_E_UNSUPPORTED;
         }
     }
     ProfScope ps("wgrad_small", st);

@@ -8,7 +8,7 @@ import os
 
 VIPNERF_MAX_SEC = 3
 VIPNERF_N_PARAMS = 24
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VIPNERF_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libvipnerf_hip.so')

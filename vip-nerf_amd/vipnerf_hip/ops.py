@@ -125,7 +125,7 @@ def _p(t: Optional[torch.Tensor], dtype=torch.float32, name='tensor'):
 
 def f32c(t: torch.Tensor) -> torch.Tensor:
     # (the common case costs one attribute test instead of three tensor calls: ~70 calls per training step, and at the reference's 1024
-    # rays per iteration the 16-bit step is bound by the host's enqueue time, tools/cpu_enqueue_time.py)
+    # rays per iteration the 16-bit step is bound by the host's enqueue time, docs/HISTORY.md)
     if t.dtype is torch.float32 and t.is_contiguous():
         return t.detach() if t.requires_grad else t
     return t.detach().to(torch.float32).contiguous()
@@ -155,6 +155,8 @@ def make_config(ndc, n_coarse, n_fine, n_sec, train, noise_std=0.0, lindisp=Fals
     return c
 
 
+# ('bf16x3', 'bf16x6' and the 'wide' layout were retired with ABI 5: the library refuses them with the reason -- the names stay so that an old
+# configuration fails loudly there instead of with a KeyError here)
 PRECISIONS = {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2, 'fp16x3': 3, 'fp16x3h': 4, 'fp16': 5, 'bf16': 6}
 LAYOUTS = {'default': 0, 'wide': 1, 'narrow': 2}
 
@@ -175,7 +177,6 @@ def pack_weights(params: List[torch.Tensor], out: Optional[torch.Tensor] = None,
     """params: the tensors of one MLP in param_order(depth) (24 for the default topology).  With `cfg` the image is the one
     cfg's kernels consume (cfg.precision; the flat fp32 buffer of the generic kernels for a non-default topology)."""
     lib = L.load()
-    full = cfg is None          # no configuration: EVERY image of the precision is filled (vipnerf_pack_weights_p), whatever layout renders
     if cfg is None:
         cfg = make_config(True, 64, 0, 0, False, precision=precision)
     topo = topology_of(cfg)
@@ -196,10 +197,7 @@ def pack_weights(params: List[torch.Tensor], out: Optional[torch.Tensor] = None,
             L.check(-2, 'vipnerf_packed_weights_bytes_c')
         if out is None:
             out = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
-        if full:
-            L.check(lib.vipnerf_pack_weights_p(C.byref(mp), int(cfg.precision), _p(out), _stream(dev)), 'vipnerf_pack_weights_p')
-        else:
-            L.check(lib.vipnerf_pack_weights_c(C.byref(cfg), C.byref(mp), _p(out), _stream(dev)), 'vipnerf_pack_weights_c')
+        L.check(lib.vipnerf_pack_weights_c(C.byref(cfg), C.byref(mp), _p(out), _stream(dev)), 'vipnerf_pack_weights_c')
     return out
 
 

@@ -1,6 +1,6 @@
-"""profiles/r04_pmc_traffic_<prec>.json from the per-counter summaries tools/profile_round.sh leaves (tools/pmc_summary.py
+"""profiles/r05_pmc_traffic_<prec>.json from the per-counter summaries tools/profile_round.sh leaves (tools/pmc_summary.py
 tables): HBM bytes per training step and stage, MFMA-pipe busy fraction and shader clock per kernel.
-    python tools/pmc_traffic.py gpurun_out/round fp32 profiles/r04_pmc_traffic_fp32.json"""
+    python tools/pmc_traffic.py gpurun_out/round fp32 profiles/r05_pmc_traffic_fp32.json"""
 import datetime
 import json
 import subprocess
@@ -53,7 +53,7 @@ def main(d, prec, out):
         'date': datetime.date.today().isoformat(),
         'csrc_sha16': csrc_sha16(),
         'source': 'rocprofv3 --kernel-trace --pmc <COUNTER> (one counter per pass, tools/profile_round.sh) of `python bench.py --steps 3 '
-                  '--warmup 1 --precision %s`; profiles/r04_pmc_<COUNTER>_%s.txt' % (prec, prec),
+                  '--warmup 1 --precision %s`; profiles/r05_pmc_<COUNTER>_%s.txt' % (prec, prec),
         'corrections': 'FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md '
                        'HBM section); WRITE_SIZE taken as is (k_pack_bf16n, whose output size is known, reads 1.00x)',
         'bytes_per_step': per,

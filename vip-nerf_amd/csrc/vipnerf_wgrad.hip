@@ -335,21 +335,24 @@ __device__ __forceinline__ void wgrad256_body(const WgArgs &a) {
     float4 wsum = make_float4(0.f, 0.f, 0.f, 0.f);
     float wtot = 0.f;
     const bool linA = d.lda == Mp && d.m_load == Mp, linB = d.ldb == Kp && d.k_load == Kp;
+    // the head's weights of a block: lane i < NLD of every wave loads w[row (tid >> 6) + (NTH / 64) i] with ONE vector load BEHIND the operand
+    // loads (so that the counted waits on those are what they were); lstore broadcasts the NLD values with v_readlane.  (As NLD loads ahead
+    // of the operands, vector or scalar, the feature layer's workgroups ran ~15 % longer: profiles/r05_ab_thin_wgrad.log.)
+    float wv = 0.f;
+    auto wload = [&](int64_t pb) {
+        if (wc) {
+            const int64_t pr = pb + (tid >> 6) + (NTH / 64) * (lane < NLD ? lane : 0);
+            wv = (lane < NLD && pr < p1) ? d.wcol[(size_t)pr * d.wcol_stride] : 0.f;
+        }
+    };
     auto gload = [&](int blk) {
         const int64_t pb = p0 + (int64_t)blk * 32;
-        if (wc) {       // (wave-uniform addresses: scalar loads -- they stay out of the vector-memory counter the operand loads are waited on with)
-            const int wrow = __builtin_amdgcn_readfirstlane(tid >> 6);
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const int64_t pr = pb + wrow + (NTH / 64) * i;
-                wr[i] = pr < p1 ? d.wcol[(size_t)pr * d.wcol_stride] : 0.f;
-            }
-        }
         if (pb + 32 <= p1 && linA && linB) {
             const float4 *ta = (const float4 *)(d.A + (size_t)pb * Mp) + tid;
             const float4 *tb = (const float4 *)(d.B + (size_t)pb * Kp) + tid;
 #pragma unroll
             for (int i = 0; i < NLD; ++i) { ra[i] = ta[NTH * i]; rb[i] = tb[NTH * i]; }
+            wload(pb);
             return;
         }
 #pragma unroll
@@ -359,12 +362,15 @@ __device__ __forceinline__ void wgrad256_body(const WgArgs &a) {
             ra[i] = oka ? *(const float4 *)(d.A + (size_t)(pb + row) * d.lda + col) : make_float4(0.f, 0.f, 0.f, 0.f);
             rb[i] = okb ? *(const float4 *)(d.B + (size_t)(pb + row) * d.ldb + col) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        wload(pb);
     };
     auto lstore = [&](int buf) {
         float4 *la = (float4 *)(lds + buf * TILE_F), *lb = (float4 *)(lds + buf * TILE_F + 32 * Mp);
 #pragma unroll
         for (int i = 0; i < NLD; ++i) { la[tid + NTH * i] = ra[i]; lb[tid + NTH * i] = rb[i]; }
         if (wc) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) wr[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv), i));
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 wsum.x = fmaf(wr[i], rb[i].x, wsum.x); wsum.y = fmaf(wr[i], rb[i].y, wsum.y);

@@ -171,6 +171,8 @@ struct WStreamT {
     int lane, wave;
     int turn;              // ROTATE: the wave that issues the next stage's DMA
     int cturn;             // ROTATE: the wave that issued the stage about to be consumed
+    const float *g0;       // PERIODIC streams (persistent kernels: the same n-stage image once per tile): the image's first stage ...
+    int period, pos;       // ... its length in stages, and the position of the next stage to request in it (period 0: not periodic)
     bool counted;          // false: this wave's YOUNGER bounds do not hold (a wave whose points are out of range skips its predicated
                            // stores): it drains with vmcnt(0) instead
     static constexpr int SF = CH * CHUNK_F;
@@ -191,12 +193,16 @@ struct WStreamT {
             glds_run<PER_WAVE>(g + (wave * PER_WAVE) * CHUNK_F + lane * 4, buf + fill * SF + (wave * PER_WAVE) * CHUNK_F);
         }
         g += SF;
+        if (period && ++pos == period) { pos = 0; g = g0; }
         --n_left;
         ++in_flight;
         fill = fill + 1 == NBUF ? 0 : fill + 1;
     }
-    __device__ __forceinline__ void start(const float *stream, int n_stages, float *lds_buf, int lane_, int wave_) {
-        g = stream; buf = lds_buf; n_left = n_stages; in_flight = 0; cur = 0; fill = 0; lane = lane_; wave = wave_; turn = 0; cturn = 0; counted = true;
+    // repeat = r > 1: the n_stages image is streamed r times back to back (a persistent workgroup's r tiles: the first stages of the next
+    // tile are requested during the last stages of the current one)
+    __device__ __forceinline__ void start(const float *stream, int n_stages, float *lds_buf, int lane_, int wave_, int repeat = 1) {
+        g = stream; buf = lds_buf; n_left = n_stages * repeat; in_flight = 0; cur = 0; fill = 0; lane = lane_; wave = wave_; turn = 0; cturn = 0; counted = true;
+        g0 = stream; period = repeat > 1 ? n_stages : 0; pos = 0;
 #pragma unroll
         for (int i = 0; i < NBUF - 1; ++i)
             if (n_left > 0) fetch();

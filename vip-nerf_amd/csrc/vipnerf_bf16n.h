@@ -473,6 +473,8 @@ template <> struct FragOf<true, false> { typedef half8 type; };
 template <> struct FragOf<false, true> { typedef f32q type; };
 #endif
 
+// workgroups of a persistent launch of the 160 KB-of-LDS MLP kernels: one per CU of the current device (queried once)
+int persistent_grid();
 int launch_pack_bf16n(const vipnerf_mlp_params *p, int precision, void *packed_bn, hipStream_t st);   // precision 0 (fp32 narrow) .. 4
 
 }  // namespace vn

@@ -12,7 +12,7 @@
     X(VN_BF16_NARROW_DEFAULT) X(VN_FP32_NARROW_DEFAULT)                                                                                   \
     /* fp32 / split-precision MLP kernels (vipnerf_common.h, vipnerf_bf16.h, vipnerf_bf16n.h, vipnerf_mlp_*_bf16n.hip) */                 \
     X(VN_STAGE_CHUNKS) X(VN_SPLIT_FMA_MIX) X(VN_INTERLEAVE) X(VN_SKEW) X(VN_DMA_MODE) X(VN_DMA_ISSUERS) X(VN_F16_PRESPLIT) X(VN_DEFER_STORES)             \
-    X(VN_STORE_GROUP_A) X(VN_STORE_GROUP_B) X(VN_F32_DEFER) X(VN_F32_FWD_V2) X(VN_F32_EVAL_ROTATE) X(VN_F32_BWD_V2) X(VN_F32B_CONV_GROUP) X(VN_DMA_ROT_WAVES)                                                              \
+    X(VN_STORE_GROUP_A) X(VN_STORE_GROUP_B) X(VN_F32_DEFER) X(VN_F32_PERSISTENT) X(VN_F32_FWD_V2) X(VN_F32_EVAL_ROTATE) X(VN_F32_BWD_V2) X(VN_F32B_CONV_GROUP) X(VN_DMA_ROT_WAVES)                                                              \
     /* single-MFMA 16-bit modes: storage and the two-point-tile kernels (vipnerf_bf16n.h, vipnerf_mlp_pt2.h, vipnerf_mlp_*_pt2.hip) */    \
     X(VN_BF16_H16) X(VN_T16) X(VN_T16_X4) X(VN_T16_NT) X(VN_PT2_SPREAD) X(VN_PT2_SKEW) X(VN_PT2_G) X(VN_PT2_D)                  \
     X(VN_PT2_TRAIN_KEEP) X(VN_PT2_EVAL_KEEP) X(VN_PT2_FAST_PE)                                                                                              \
@@ -57,6 +57,9 @@
 #endif
 #ifndef VN_STORE_GROUP_B
 #define VN_STORE_GROUP_B 12
+#endif
+#ifndef VN_F32_PERSISTENT
+#define VN_F32_PERSISTENT 1       // exact-fp32 data-gradient kernel: persistent workgroups (one per CU, tiles round robin, the weight stream continuous across tiles)
 #endif
 #ifndef VN_F32_FWD_V2
 #define VN_F32_FWD_V2 1          // exact-fp32 forward: 1 = k_mlp_fwd_f32 (vipnerf_mlp_fwd_f32.hip), 0 = the k_mlp_fwd_bf16n<., 2, false, ., true> instantiations

@@ -82,15 +82,27 @@ __global__ __launch_bounds__(PLF::WG) void k_mlp_bwd_f32(MlpBwdArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, j = lane & 15;
-    const int64_t p_raw = (int64_t)blockIdx.x * MLP_PTS_PER_WG + wave * 16 + j;
-    const bool valid = p_raw < a.src.P;
-    const int64_t p = valid ? p_raw : a.src.P - 1;       // a lane beyond P works on point P - 1 and writes the bytes its owner writes (vipnerf_bf16n.h)
     const int V = a.src.V;
+    // PERSISTENT workgroups: the grid is one workgroup per CU (or fewer), workgroup b takes the 128-point tiles b, b + grid, b + 2 grid, ...: the
+    // LDS-resident block is copied once, and the weight stream runs on across tiles -- the next tile's first stages are requested during the
+    // current tile's last ones instead of behind a kernel-start latency
+    const int64_t n_tiles = (a.src.P + MLP_PTS_PER_WG - 1) / MLP_PTS_PER_WG;
+    const int my_tiles = (int)((n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
 
     TS_INIT();
     TSF(TS_ENTRY);
     typename StreamOf<PL, false>::type ws;
-    ws.start(a.packed + PL::PK_BWD, PL::B_STAGES, stage_buf, lane, wave);
+    ws.start(a.packed + PL::PK_BWD, PL::B_STAGES, stage_buf, lane, wave, my_tiles);
+    {
+        const float4 *g4 = (const float4 *)(a.packed + PL::PK_RES);
+        float4 *l4 = (float4 *)res;
+        for (int i = tid; i < PL::R_TOTAL_PAD / 4; i += PL::WG) l4[i] = g4[i];
+    }
+#pragma unroll 1
+    for (int tile_k = 0; tile_k < my_tiles; ++tile_k) {
+    const int64_t p_raw = ((int64_t)blockIdx.x + (int64_t)tile_k * gridDim.x) * MLP_PTS_PER_WG + wave * 16 + j;
+    const bool valid = p_raw < a.src.P;
+    const int64_t p = valid ? p_raw : a.src.P - 1;       // a lane beyond P works on point P - 1 and writes the bytes its owner writes (vipnerf_bf16n.h)
 
     // ---------------------------------------------------------------- every global input of the head, requested at once
     const float *gb = a.bwd;
@@ -110,17 +122,12 @@ __global__ __launch_bounds__(PLF::WG) void k_mlp_bwd_f32(MlpBwdArgs a) {
         gm[d] = 0u;
         if (d <= V) gm[d] = ((const unsigned *)(a.acts + a.al.gm[d]))[(size_t)p * 4 + q];
     }
-    {
-        const float4 *g4 = (const float4 *)(a.packed + PL::PK_RES);
-        float4 *l4 = (float4 *)res;
-        for (int i = tid; i < PL::R_TOTAL_PAD / 4; i += PL::WG) l4[i] = g4[i];
-    }
     float dq0[4];
 #pragma unroll
     for (int c = 0; c < 3; ++c) dq0[c] = g_rgb[c] * ((1.f - y_rgb[c]) * y_rgb[c]);
     dq0[3] = g_vis * ((1.f - y_vis) * y_vis);
     const float dsig_raw = sig > 0.f ? g_sig : 0.f;
-    __syncthreads();
+    if (tile_k == 0) __syncthreads();                   // (the resident block; later tiles: the stage barriers order everything)
     TSF(TS_RESIDENT);
 
     // ---------------------------------------------------------------- view branch, per direction: dYv_a = (W_o^T dq_a) . relu'(view hidden_a)
@@ -224,8 +231,6 @@ __global__ __launch_bounds__(PLF::WG) void k_mlp_bwd_f32(MlpBwdArgs a) {
         mi0 = mk.x; mi1 = mk.y;
         dst_in = a.bwd + a.bl.dy[layer];
     }
-    stream_end(ws);
-
     // ---------------------------------------------------------------- dY_0: layer 0's ReLU bits, stored from here (no GEMM consumes it)
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
@@ -236,6 +241,8 @@ __global__ __launch_bounds__(PLF::WG) void k_mlp_bwd_f32(MlpBwdArgs a) {
         }
     }
     TSF(TS_LAST);
+    }   // tiles
+    stream_end(ws);
 }
 
 #if defined(VN_EXP) && VN_EXP == 50
@@ -246,7 +253,8 @@ extern "C" int vipnerf_exp_timeline_f32b(unsigned long long *out, int n) {
 
 int launch_mlp_bwd_f32(const MlpBwdArgs &a, hipStream_t st) {
     if (a.src.P <= 0) return VIPNERF_OK;
-    const unsigned grid = (unsigned)((a.src.P + MLP_PTS_PER_WG - 1) / MLP_PTS_PER_WG);
+    const int64_t tiles = (a.src.P + MLP_PTS_PER_WG - 1) / MLP_PTS_PER_WG;
+    const unsigned grid = (unsigned)(VN_F32_PERSISTENT && tiles > persistent_grid() ? persistent_grid() : tiles);   // one workgroup per CU (160 KB of LDS each)
     const size_t lds = (size_t)PLF::LDS_F * sizeof(float);
     VN_HIP(hipFuncSetAttribute((const void *)k_mlp_bwd_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_mlp_bwd_f32, dim3(grid), dim3(PLF::WG), lds, st, a);

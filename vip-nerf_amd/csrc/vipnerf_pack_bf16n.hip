@@ -122,6 +122,15 @@ __global__ void k_pack_bf16n(PackBnArgs a) {
     a.out[idx] = cell;
 }
 
+int persistent_grid() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return cus;
+    }();
+    return n;
+}
+
 int launch_pack_bf16n(const vipnerf_mlp_params *p, int precision, void *packed_bn, hipStream_t st) {
     PackBnArgs a;
     a.p = *p;

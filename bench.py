@@ -92,6 +92,14 @@ def stage_macs(n_sec):
     return {'mlp_fwd': per_point, 'mlp_dgrad': per_point, 'wgrad_256x256': 8 * 65536, 'wgrad_small': per_point - 8 * 65536}
 
 
+def stage_macs_executed(n_sec):
+    """MACs per point the exact-fp32 kernels EXECUTE (vipnerf_mlp_{fwd,bwd}_f32.hip): forward 36 weight stages x 256 MFMAs x 1024 MAC / 16 points
+    (gamma(x) padded to K = 64, the view layer's 256 feature columns evaluated ONCE for all directions) + one 8-tile k-step per direction; data
+    gradient 34 stages (the directions' hidden gradients are summed before the one W_v^T product).  The 3x convention prices every pass at the
+    algorithmic 630,272: these are what the MFMA pipe really does."""
+    return {'mlp_fwd': 36 * 256 * 1024 // 16 + (1 + n_sec) * 4096, 'mlp_dgrad': 34 * 256 * 1024 // 16}
+
+
 def model_configs(ndc=True, sparse_depth=False):
     mlp = lambda ns: {'num_samples': ns, 'netdepth': 8, 'netwidth': 256, 'points_positional_encoding_degree': 10,
                       'views_positional_encoding_degree': 4, 'use_view_dirs': True, 'view_dependent_rgb': True,
@@ -260,7 +268,10 @@ def roofline_block(prec, prof, steps, rays, ms_per_step, sclk_mhz, n_sec=1, work
          'frac': round(tf(dom) / peak, 4), 'mac_per_point': macs[dom], 'points_per_step': points,
          'avg_launch_ms': round(stage_ms[dom] / max(launches[dom], 1), 4), 'launches_per_step': launches[dom],
          'mfmas_issued_per_product': issued, 'frac_issued': round(min(tf(dom) * issued / peak, 9.99), 4),
-         'stages': dict({g: {'ms_per_step': round(stage_ms[g], 3), 'achieved_tflops': round(tf(g), 1), 'frac': round(tf(g) / peak, 4)}
+         'stages': dict({g: dict({'ms_per_step': round(stage_ms[g], 3), 'achieved_tflops': round(tf(g), 1), 'frac': round(tf(g) / peak, 4)},
+                                 **({'mac_per_point_executed': stage_macs_executed(n_sec)[g],
+                                     'frac_executed': round(stage_macs_executed(n_sec)[g] * 2.0 * points / (stage_ms[g] * 1e-3) / 1e12 / peak, 4)}
+                                    if prec == 'fp32' and g in ('mlp_fwd', 'mlp_dgrad') and stage_ms[g] > 0 else {}))
                          for g in stage_ms},
                         wgrad={'ms_per_step': round(wg_ms, 3), 'achieved_tflops': round(flop_pass / (wg_ms * 1e-3) / 1e12, 1) if wg_ms > 0 else 0.0,
                                'frac': round(flop_pass / (wg_ms * 1e-3) / 1e12 / peak, 4) if wg_ms > 0 else 0.0}),
@@ -341,6 +352,8 @@ def compact_line(full: dict) -> dict:
                                               'traffic_profile_is_of_current_kernels') if k in r}
     for g, st in (r.get('stages') or {}).items():
         c['roofline']['ms_' + g] = st['ms_per_step']
+        if 'frac_executed' in st:
+            c['roofline']['frac_executed_' + g] = st['frac_executed']
     cb = full.get('cpu_baseline')
     if cb:
         c['cpu_baseline'] = {'value': cb['value'], 'unit': cb['unit'], 'cores': cb['cores'], 'kind': cb['kind'], 'sample': cb['sample'][:160]}

@@ -12,7 +12,7 @@
     X(VN_BF16_NARROW_DEFAULT) X(VN_FP32_NARROW_DEFAULT)                                                                                   \
     /* fp32 / split-precision MLP kernels (vipnerf_common.h, vipnerf_bf16.h, vipnerf_bf16n.h, vipnerf_mlp_*_bf16n.hip) */                 \
     X(VN_STAGE_CHUNKS) X(VN_SPLIT_FMA_MIX) X(VN_INTERLEAVE) X(VN_SKEW) X(VN_DMA_MODE) X(VN_DMA_ISSUERS) X(VN_F16_PRESPLIT) X(VN_DEFER_STORES)             \
-    X(VN_STORE_GROUP_A) X(VN_STORE_GROUP_B) X(VN_F32_DEFER) X(VN_F32_PERSISTENT) X(VN_F32_FWD_V2) X(VN_F32_EVAL_ROTATE) X(VN_F32_BWD_V2) X(VN_F32B_CONV_GROUP) X(VN_DMA_ROT_WAVES)                                                              \
+    X(VN_STORE_GROUP_A) X(VN_STORE_GROUP_B) X(VN_F32_PERSISTENT) X(VN_F32_EVAL_ROTATE) X(VN_F32B_CONV_GROUP) X(VN_DMA_ROT_WAVES)                                                              \
     /* single-MFMA 16-bit modes: storage and the two-point-tile kernels (vipnerf_bf16n.h, vipnerf_mlp_pt2.h, vipnerf_mlp_*_pt2.hip) */    \
     X(VN_BF16_H16) X(VN_T16) X(VN_T16_X4) X(VN_T16_NT) X(VN_PT2_SPREAD) X(VN_PT2_SKEW) X(VN_PT2_G) X(VN_PT2_D)                  \
     X(VN_PT2_TRAIN_KEEP) X(VN_PT2_EVAL_KEEP) X(VN_PT2_FAST_PE)                                                                                              \
@@ -61,14 +61,8 @@
 #ifndef VN_F32_PERSISTENT
 #define VN_F32_PERSISTENT 1       // exact-fp32 data-gradient kernel: persistent workgroups (one per CU, tiles round robin, the weight stream continuous across tiles)
 #endif
-#ifndef VN_F32_FWD_V2
-#define VN_F32_FWD_V2 1          // exact-fp32 forward: 1 = k_mlp_fwd_f32 (vipnerf_mlp_fwd_f32.hip), 0 = the k_mlp_fwd_bf16n<., 2, false, ., true> instantiations
-#endif
 #ifndef VN_F32_EVAL_ROTATE
 #define VN_F32_EVAL_ROTATE 0      // exact-fp32 EVAL kernel: 1 = the training kernels' weight stream (one older wave issues a whole stage), 0 = every wave its eighth
-#endif
-#ifndef VN_F32_BWD_V2
-#define VN_F32_BWD_V2 1          // exact-fp32 data gradients: 1 = k_mlp_bwd_f32 (vipnerf_mlp_bwd_f32.hip), 0 = the k_mlp_bwd_bf16n<2,false,3,true> instantiation
 #endif
 #ifndef VN_WGRAD_SIGMA_FUSED
 #define VN_WGRAD_SIGMA_FUSED 1    // exact fp32: the sigma head's weight gradient as weighted column sums inside the feature layer's 256 x 256 GEMM (k_wgrad256_w8)
@@ -81,9 +75,6 @@
 #endif
 #ifndef VN_F32B_CONV_GROUP
 #define VN_F32B_CONV_GROUP 2     // k_mlp_bwd_f32: MFMA group of a stage behind which the next stage's operand k-steps are converted
-#endif
-#ifndef VN_F32_DEFER
-#define VN_F32_DEFER 1           // exact-fp32 narrow kernels: activation / gradient stores leave from the next GEMM's stages (H16 = 3)
 #endif
 #ifndef VN_BF16_H16
 #define VN_BF16_H16 1

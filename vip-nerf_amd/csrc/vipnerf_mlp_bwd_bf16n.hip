@@ -1,11 +1,10 @@
-// Data-gradient pass, narrow-wave layout (vipnerf_bf16n.h): vipnerf_mlp_bwd_bf16.hip with 16-point waves on
-// v_mfma_f32_16x16x32_bf16, two waves per SIMD.  A = W^T from the narrow packed image, B = the NS-part split of the
+// Data-gradient pass of the fp16x3 arithmetics, narrow-wave layout (vipnerf_bf16n.h): 16-point waves on v_mfma_f32_16x16x32_f16, two waves per
+// SIMD (the exact-fp32 arithmetic: vipnerf_mlp_bwd_f32.hip; the single-MFMA 16-bit modes: vipnerf_mlp_bwd_pt2.hip).  A = W^T from the narrow packed image, B = the NS-part split of the
 // current dY; ReLU masks are the 64 bits per lane and layer the narrow forward wrote.
 #include "vipnerf_bf16n.h"
 #include "vipnerf_mlp.h"
 #include "vipnerf_mlp_pt2.h"
 
-// build switch VN_F32_DEFER (default 1, vipnerf_knobs.h)
 
 namespace vn {
 
@@ -52,10 +51,10 @@ int launch_mlp_bwd_f32(const MlpBwdArgs &a, hipStream_t st);
 TS_DECL(g_nb_timeline);
 #define TSNB(tag) TS_AT(g_nb_timeline, tag)
 
-template <int NS, bool F16, int H16 = 0, bool F32 = false>
+template <int NS, bool F16, int H16 = 0>
 __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) {
     typedef BnPlan<NS> PL;
-    typedef typename FragOf<F16, F32>::type FR;
+    typedef typename FragOf<F16, false>::type FR;
     constexpr float AU = F16 ? 1.f / F16_WSCALE : 1.f;
     constexpr bool DEFER = H16 != 0 && VN_DEFER_STORES;    // fp16-stored gradients leave from the next GEMM's stages (vipnerf_bf16n.h)
     // H16 == 4 (VN_T16): every gradient the weight-gradient GEMMs read is stored as 16-bit T16 (store_t16) -- dY_0..dY_7, dY_feature, dYv per
@@ -271,11 +270,11 @@ extern "C" int vipnerf_exp_timeline_nb(unsigned long long *out, int n) {
 }
 #endif
 
-template <int NS, bool F16 = false, int H16 = 0, bool F32 = false>
+template <int NS, bool F16 = false, int H16 = 0>
 static int launch_one_bwd_n(const MlpBwdArgs &a, unsigned grid, hipStream_t st) {
     const size_t lds = (size_t)BnPlan<NS>::LDS_F * sizeof(float);
-    VN_HIP(hipFuncSetAttribute((const void *)k_mlp_bwd_bf16n<NS, F16, H16, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_mlp_bwd_bf16n<NS, F16, H16, F32>), dim3(grid), dim3(BnPlan<NS>::WG), lds, st, a);
+    VN_HIP(hipFuncSetAttribute((const void *)k_mlp_bwd_bf16n<NS, F16, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_mlp_bwd_bf16n<NS, F16, H16>), dim3(grid), dim3(BnPlan<NS>::WG), lds, st, a);
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;
 }
@@ -283,11 +282,7 @@ static int launch_one_bwd_n(const MlpBwdArgs &a, unsigned grid, hipStream_t st) 
 int launch_mlp_bwd_bf16n(const MlpBwdArgs &a, int precision, hipStream_t st) {
     if (a.src.P <= 0) return VIPNERF_OK;
     const unsigned grid = (unsigned)((a.src.P + MLP_PTS_PER_WG - 1) / MLP_PTS_PER_WG);
-#if VN_F32_BWD_V2
     if (precision == 0) return launch_mlp_bwd_f32(a, st);      // the exact-fp32 kernel of vipnerf_mlp_bwd_f32.hip
-#else
-    if (precision == 0) return launch_one_bwd_n<2, false, VN_F32_DEFER ? 3 : 0, true>(a, grid, st);
-#endif
     // (precisions 1 / 2, the split-bf16 arithmetics bf16x3 / bf16x6, were retired with ABI 5)
     if ((precision == 5 || precision == 6) && !single_mfma_t16(precision)) {
         set_error("this library was built without T16 storage (VN_T16 / VN_BF16_H16 = 0): no single-MFMA 16-bit kernels"); return VIPNERF_E_UNSUPPORTED; }

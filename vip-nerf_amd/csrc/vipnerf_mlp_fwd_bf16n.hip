@@ -1,13 +1,12 @@
-// MLP.forward on split-precision bf16 MFMA, narrow-wave layout (vipnerf_bf16n.h): 16 points per wave on
-// v_mfma_f32_16x16x32_bf16, 8 waves (two per SIMD) and 128 points per workgroup.  Same algorithm, stage order and
-// stored activations as vipnerf_mlp_fwd_bf16.hip; only the lane <-> (point, feature) map differs: lane (j, q) holds
-// features 16T + 4q .. +3 of tile T for point j.
+// MLP.forward of the fp16x3 arithmetics (operands split into two fp16 parts, three cross terms per product), narrow-wave layout
+// (vipnerf_bf16n.h): 16 points per wave on v_mfma_f32_16x16x32_f16, 8 waves (two per SIMD) and 128 points per workgroup; lane (j, q) holds
+// features 16T + 4q .. +3 of tile T for point j.  (The exact-fp32 arithmetic: vipnerf_mlp_fwd_f32.hip; the single-MFMA 16-bit modes:
+// vipnerf_mlp_fwd_pt2.hip.)
 #include <type_traits>
 #include "vipnerf_bf16n.h"
 #include "vipnerf_mlp.h"
 #include "vipnerf_mlp_pt2.h"
 
-// build switch VN_F32_DEFER (default 1, vipnerf_knobs.h): exact-fp32 narrow kernels: activation / gradient stores leave from the next GEMM's stages (H16 = 3)
 
 namespace vn {
 
@@ -19,16 +18,16 @@ namespace vn {
 // H16 == 4 (single-MFMA modes, VN_T16): every stored operand is 16-bit in the tile-blocked layout T16 (vipnerf_bf16n.h: store_t16) --
 // h_1..h_8, the feature, the view hidden and its ReLU bits per direction, gamma(x) / gamma(dir) in their slot order -- written from the
 // B fragments the GEMMs consume anyway.
-// F32: exact-fp32 fragments (f32q, vipnerf_bf16.h): v_mfma_f32_16x16x4_f32, one MFMA per product, no split, no scaling.
+// (The exact-fp32 arithmetic has kernels of its own: vipnerf_mlp_fwd_f32.hip.  This template serves the fp16x3 modes.)
 int launch_mlp_fwd_f32(const MlpFwdArgs &a, hipStream_t st);
 TS_DECL(g_n_timeline);
 #define TSN(tag) TS_AT(g_n_timeline, tag)
 
-template <bool SAVE, int NS, bool F16, int H16 = 0, bool F32 = false>
+template <bool SAVE, int NS, bool F16, int H16 = 0>
 __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) {
     typedef BnPlan<NS> PL;
-    typedef typename FragOf<F16, F32>::type FR;
-    static_assert(!(F16 && F32) && (!F32 || (NS == 2 && (H16 == 0 || H16 == 3))) && (F32 || H16 != 3) && (H16 != 4 || NS == 1 || (NS == 2 && F16)), "arithmetic");
+    typedef typename FragOf<F16, false>::type FR;
+    static_assert(H16 != 3 && (H16 != 4 || NS == 1 || (NS == 2 && F16)), "arithmetic");
     constexpr bool T16 = SAVE && H16 == 4;
     constexpr float XS = F16 ? F16_XSCALE : 1.f;           // B operands are split as XS * x
     constexpr float AU = F16 ? F16_ACC_UNSCALE : 1.f;
@@ -50,7 +49,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
 
     TS_INIT();
     TSN(TS_ENTRY);
-    typename std::conditional<F32 && !SAVE, typename StreamShared<PL>::type, typename StreamOf<PL, PL::SKEW>::type>::type ws;
+    typename StreamOf<PL, PL::SKEW>::type ws;
     ws.start(a.packed + PL::PK_FWD, PL::F_STAGES, stage_buf, lane, wave);
     stream_counted(ws, !T16 || valid);      // a wave beyond P skips its (predicated) T16 stores: its counted waits would not hold
     {
@@ -135,8 +134,6 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
         // Kept free of per-tile branches on `layer`: ReLU is a max with a per-layer bound (0, or -inf for the feature
         // layer), the sigma head is one block for layer 7.
         const float lo = relu_bound<F16>(layer < 8);
-        int lo_i = layer < 8 ? 0 : (int)0x80000000;            // the bound of relu_bits (exact-fp32 training: the ReLU as one integer max)
-        asm volatile("" : "+s"(lo_i));                           // one SGPR operand: the compiler otherwise emits max(x, 0) AND a select on `layer` per value
         if (layer == 7) {
             float sg[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -162,10 +159,10 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             for (int u = 0; u < 2; ++u) {
                 const int t = 2 * s + u;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) x[u][r] = (F32 && SAVE && !F16) ? relu_bits(x[u][r] * AU, lo_i) : relu_lo<F16>(x[u][r] * AU, lo);   // (+0 | positive | NaN for the bit masks)
+                for (int r = 0; r < 4; ++r) x[u][r] = relu_lo<F16>(x[u][r] * AU, lo);   // (+0 | positive | NaN for the bit masks)
                 if (SAVE) {
                     if (!(H16 && layer < 8) && !T16 && !(layer < 8 ? EXP_NO_STORES : EXP_NO_EXTRAS)) store_tile16(dst, p, W, q, t, x[u]);
-                    if (F16 || F32) {
+                    if (F16) {
                         if (t < 8) mk0 = push_nibble(mk0, positive_nibble(x[u])); else mk1 = push_nibble(mk1, positive_nibble(x[u]));
                     } else {
                         unsigned m = 0;
@@ -239,7 +236,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) g[t][r] = relu_lo<F16 || T16 || (F32 && SAVE)>(g[t][r] * AU, 0.f);     // (+0 | positive | NaN for the ReLU bits)
+            for (int r = 0; r < 4; ++r) g[t][r] = relu_lo<F16 || T16>(g[t][r] * AU, 0.f);     // (+0 | positive | NaN for the ReLU bits)
         if (T16) {
             if (valid && !EXP_NO_EXTRAS) {
                 // view hidden as 16-bit T16 (8 tiles) + its 32 ReLU bits per lane (bit 4 t + r), which is all the data-gradient
@@ -264,12 +261,6 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
             if (!EXP_NO_EXTRAS) {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) store_tile16(a.acts + a.al.g[dsel], p, WV, q, t, g[t]);
-                if (F32) {       // the view hidden's 32 ReLU bits per lane (bit 4 t + r): all k_mlp_bwd_f32 reads of it
-                    unsigned gmb = 0u;
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) gmb = push_nibble(gmb, positive_nibble(g[t]));
-                    ((unsigned *)(a.acts + a.al.gm[dsel]))[(size_t)p * 4 + q] = gmb;
-                }
             }
             if (valid && !EXP_NO_PE) store_d16(a.acts + a.al.ped[dsel] + (size_t)p * DVE_PAD, q, ped);
         }
@@ -309,11 +300,11 @@ extern "C" int vipnerf_exp_timeline_n(unsigned long long *out, int n) {
 }
 #endif
 
-template <bool SAVE, int NS, bool F16 = false, int H16 = 0, bool F32 = false>
+template <bool SAVE, int NS, bool F16 = false, int H16 = 0>
 static int launch_one_n(const MlpFwdArgs &a, unsigned grid, hipStream_t st) {
     const size_t lds = (size_t)BnPlan<NS>::LDS_F * sizeof(float);
-    VN_HIP(hipFuncSetAttribute((const void *)k_mlp_fwd_bf16n<SAVE, NS, F16, H16, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_mlp_fwd_bf16n<SAVE, NS, F16, H16, F32>), dim3(grid), dim3(BnPlan<NS>::WG), lds, st, a);
+    VN_HIP(hipFuncSetAttribute((const void *)k_mlp_fwd_bf16n<SAVE, NS, F16, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_mlp_fwd_bf16n<SAVE, NS, F16, H16>), dim3(grid), dim3(BnPlan<NS>::WG), lds, st, a);
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;
 }
@@ -322,11 +313,7 @@ static int launch_one_n(const MlpFwdArgs &a, unsigned grid, hipStream_t st) {
 int launch_mlp_fwd_bf16n(const MlpFwdArgs &a, int precision, hipStream_t st) {
     if (a.src.P <= 0) return VIPNERF_OK;
     const unsigned grid = (unsigned)((a.src.P + MLP_PTS_PER_WG - 1) / MLP_PTS_PER_WG);
-#if VN_F32_FWD_V2
     if (precision == 0) return launch_mlp_fwd_f32(a, st);      // the exact-fp32 kernels of vipnerf_mlp_fwd_f32.hip
-#else
-    if (precision == 0) return a.acts ? launch_one_n<true, 2, false, VN_F32_DEFER ? 3 : 0, true>(a, grid, st) : launch_one_n<false, 2, false, 0, true>(a, grid, st);
-#endif
     // (precisions 1 / 2, the split-bf16 arithmetics bf16x3 / bf16x6, were retired with ABI 5)
     if (precision == 3) return a.acts ? launch_one_n<true, 2, true, VN_F16_PRESPLIT ? 2 : 0>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);
     if (precision == 4) return a.acts ? launch_one_n<true, 2, true, VN_T16 ? 4 : 1>(a, grid, st) : launch_one_n<false, 2, true>(a, grid, st);

@@ -176,7 +176,13 @@ struct WStreamSkew {
 // build switch VN_DMA_ROT_WAVES (default 4, vipnerf_knobs.h): the waves a stage's issuer rotates over (4: the older wave of every SIMD only; 8: all)
 template <typename PL, bool SK> struct StreamOf { typedef WStreamT<PL::CH, PL::NBUF, PL::WAVES, VN_DMA_MODE == 1, VN_DMA_MODE == 2, VN_DMA_MODE == 1 ? VN_DMA_ISSUERS : 1, VN_DMA_MODE == 1 ? VN_DMA_ROT_WAVES : PL::WAVES> type; };
 template <typename PL> struct StreamOf<PL, true> { typedef WStreamSkew<PL::CH> type; };
-// the two-point-tile 16-bit kernels: every wave takes its turn (measured neutral to slightly better there: profiles/r05_ab_rot_waves.log)
+// the exact-fp32 kernels (vipnerf_mlp_{fwd,bwd}_f32.hip): the four OLDER waves share every stage's DMA, a quarter each (build switch VN_F32_DMA_ISSUERS,
+// default 4, vipnerf_knobs.h).  With one issuer per stage that wave's loop took 18.1k cycles against 10.4k (64 pieces x ~120 cycles of issue among its
+// MFMAs) and its SIMD was the stage's last; a quarter of the burst fits the ~7k cycles of slack every older wave has: fp32 step -0.15 ms
+// (profiles/r05_ab_dma_issuers.log)
+template <typename PL> struct StreamOlder { typedef WStreamT<PL::CH, PL::NBUF, PL::WAVES, true, false, VN_F32_DMA_ISSUERS, 4> type; };
+// the two-point-tile 16-bit kernels: every wave takes its turn (issuing from the older waves only -- one, two or four of them per stage -- measured
+// neutral there: profiles/r05_ab_rot_waves.log, r05_ab_dma_issuers.log)
 template <typename PL> struct StreamOfAll { typedef WStreamT<PL::CH, PL::NBUF, PL::WAVES, VN_DMA_MODE == 1, VN_DMA_MODE == 2, VN_DMA_MODE == 1 ? VN_DMA_ISSUERS : 1> type; };
 // every wave issues its eighth of a stage's DMA and drains it itself (plain vmcnt(0) + barrier): measured +1.8 % for the exact-fp32
 // EVAL kernel (0.887 -> 0.903 of the fp32 peak: no stores whose latency that vmcnt(0) would sit out, and no single wave 64 pieces

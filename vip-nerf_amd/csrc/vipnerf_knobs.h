@@ -12,7 +12,7 @@
     X(VN_BF16_NARROW_DEFAULT) X(VN_FP32_NARROW_DEFAULT)                                                                                   \
     /* fp32 / split-precision MLP kernels (vipnerf_common.h, vipnerf_bf16.h, vipnerf_bf16n.h, vipnerf_mlp_*_bf16n.hip) */                 \
     X(VN_STAGE_CHUNKS) X(VN_SPLIT_FMA_MIX) X(VN_INTERLEAVE) X(VN_SKEW) X(VN_DMA_MODE) X(VN_DMA_ISSUERS) X(VN_F16_PRESPLIT) X(VN_DEFER_STORES)             \
-    X(VN_STORE_GROUP_A) X(VN_STORE_GROUP_B) X(VN_F32_PERSISTENT) X(VN_F32_EVAL_ROTATE) X(VN_F32B_CONV_GROUP) X(VN_DMA_ROT_WAVES)                                                              \
+    X(VN_STORE_GROUP_A) X(VN_STORE_GROUP_B) X(VN_F32_PERSISTENT) X(VN_F32_EVAL_ROTATE) X(VN_F32B_CONV_GROUP) X(VN_DMA_ROT_WAVES) X(VN_F32_DMA_ISSUERS)                                                              \
     /* single-MFMA 16-bit modes: storage and the two-point-tile kernels (vipnerf_bf16n.h, vipnerf_mlp_pt2.h, vipnerf_mlp_*_pt2.hip) */    \
     X(VN_BF16_H16) X(VN_T16) X(VN_T16_X4) X(VN_T16_NT) X(VN_PT2_SPREAD) X(VN_PT2_SKEW) X(VN_PT2_G) X(VN_PT2_D)                  \
     X(VN_PT2_TRAIN_KEEP) X(VN_PT2_EVAL_KEEP) X(VN_PT2_FAST_PE)                                                                                              \
@@ -62,13 +62,16 @@
 #define VN_F32_PERSISTENT 1       // exact-fp32 data-gradient kernel: persistent workgroups (one per CU, tiles round robin, the weight stream continuous across tiles)
 #endif
 #ifndef VN_F32_EVAL_ROTATE
-#define VN_F32_EVAL_ROTATE 0      // exact-fp32 EVAL kernel: 1 = the training kernels' weight stream (one older wave issues a whole stage), 0 = every wave its eighth
+#define VN_F32_EVAL_ROTATE 1      // exact-fp32 EVAL kernel: 1 = the training kernels' weight stream (the four older waves issue a quarter of a stage each: 0.908 -> 0.918 of the peak), 0 = every wave its eighth
 #endif
 #ifndef VN_WGRAD_SIGMA_FUSED
 #define VN_WGRAD_SIGMA_FUSED 1    // exact fp32: the sigma head's weight gradient as weighted column sums inside the feature layer's 256 x 256 GEMM (k_wgrad256_w8)
 #endif
 #ifndef VN_WGRAD_VIEW_FUSED
 #define VN_WGRAD_VIEW_FUSED 1     // exact fp32: the view layer's 128 x 256 and per-direction 128 x 32 weight-gradient GEMMs in one launch over dYv_0..V (k_wgrad_view)
+#endif
+#ifndef VN_F32_DMA_ISSUERS
+#define VN_F32_DMA_ISSUERS 4      // exact-fp32 MLP kernels: older waves (0..3) that share a stage's DMA (1, 2 or 4)
 #endif
 #ifndef VN_DMA_ROT_WAVES
 #define VN_DMA_ROT_WAVES 4       // VN_DMA_MODE 1: the issuer of a stage's DMA rotates over waves 0 .. n - 1 (4: the older wave of each SIMD; 8: every wave)

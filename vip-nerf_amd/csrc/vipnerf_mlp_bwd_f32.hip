@@ -91,7 +91,7 @@ __global__ __launch_bounds__(PLF::WG) void k_mlp_bwd_f32(MlpBwdArgs a) {
 
     TS_INIT();
     TSF(TS_ENTRY);
-    typename StreamOf<PL, false>::type ws;
+    typename StreamOlder<PL>::type ws;
     ws.start(a.packed + PL::PK_BWD, PL::B_STAGES, stage_buf, lane, wave, my_tiles);
     {
         const float4 *g4 = (const float4 *)(a.packed + PL::PK_RES);

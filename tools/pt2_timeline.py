@@ -47,8 +47,8 @@ torch.cuda.synchronize()
 lib = L.load()
 if mode == 'wg':          # the exact-fp32 256 x 256 weight-gradient kernel: per 32-point block -- loads issued / MFMA loop / LDS stores / barrier
     fn = lib.vipnerf_exp_timeline_wg; fn.restype = C.c_int
-    buf = (C.c_ulonglong * 1024)(); assert fn(buf, 1024) == 0
-    raw = np.array(buf, dtype=np.uint64).reshape(8, 128)
+    buf = (C.c_ulonglong * 2048)(); assert fn(buf, 2048) == 0
+    raw = np.array(buf, dtype=np.uint64).reshape(8, 256)
     for w in range(8):
         ev = [(int(x >> np.uint64(56)), int(x & np.uint64((1 << 56) - 1))) for x in raw[w] if x][:-1]
         acc = {'top (next block loads issued)': [], 'mfma loop': [], 'lds stores': [], 'barrier': []}
@@ -62,9 +62,9 @@ if mode == 'wg':          # the exact-fp32 256 x 256 weight-gradient kernel: per
 narrow = os.environ.get('HIP_PRECISION', 'bf16') not in ('bf16', 'fp16')      # the 16-point kernels (exact fp32, split arithmetics): forward only
 fn = ((lib.vipnerf_exp_timeline_f32b if (os.environ.get('HIP_PRECISION') == 'fp32' and hasattr(lib, 'vipnerf_exp_timeline_f32b')) else lib.vipnerf_exp_timeline_nb) if mode == 'bwd' else (lib.vipnerf_exp_timeline_f32f if (os.environ.get('HIP_PRECISION') == 'fp32' and hasattr(lib, 'vipnerf_exp_timeline_f32f')) else lib.vipnerf_exp_timeline_n)) if narrow else (lib.vipnerf_exp_timeline_bwd if mode == 'bwd' else lib.vipnerf_exp_timeline)
 fn.restype = C.c_int
-buf = (C.c_ulonglong * 1024)()
-assert fn(buf, 1024) == 0
-raw = np.array(buf, dtype=np.uint64).reshape(8, 128)
+buf = (C.c_ulonglong * 2048)()
+assert fn(buf, 2048) == 0
+raw = np.array(buf, dtype=np.uint64).reshape(8, 256)
 ENTRY, RESIDENT, HEAD, PRE, POST, END, VIEW, LAST, EPI_A, EPI_B = range(10)
 print(f'{mode} {os.environ.get("HIP_PRECISION", "bf16")}: cycles (s_memtime ticks) of the recorded workgroup, per wave')
 rows = []
@@ -72,7 +72,7 @@ for w in range(8):
     ev = [(int(x >> np.uint64(56)), int(x & np.uint64((1 << 56) - 1))) for x in raw[w] if x]
     assert ev[0][0] == ENTRY and ev[-1][0] == LAST, [e[0] for e in ev]
     rec = {'resident': 0, 'head': 0, 'wait': 0, 'gemm': 0, 'between': 0, 'tail': 0, 'epi_operands': 0, 'epi_valu': 0}
-    stages = []
+    stages = []; fine = {}
     prev_tag, prev_t = ev[0]
     for tag, t in ev[1:]:
         d = t - prev_t
@@ -84,11 +84,13 @@ for w in range(8):
         elif tag == EPI_A: rec['epi_operands'] += d; rec['between'] += d      # (backward) the epilogue's operands ready: last accumulators, ReLU bits
         elif tag == EPI_B: rec['epi_valu'] += d; rec['between'] += d           # (backward) conversion + ReLU bits applied
         elif tag == LAST: rec['tail'] += d                  # forward: per-direction view tail; backward: the last epilogue and dY_0's stores
+        if tag >= 10: fine[tag] = fine.get(tag, 0) + d      # finer markers of an experiment build (the cycles up to each marker from the one before it)
         prev_tag, prev_t = tag, t
     rec['total'] = ev[-1][1] - ev[0][1]
     rows.append(rec)
     print(f'wave {w}: total {rec["total"]:7d} | resident load {rec["resident"]:5d}  head {rec["head"]:6d} | {len(stages)} stages: MFMA loops {rec["gemm"]:7d}  waits+barriers {rec["wait"]:6d}  '
           f'between stages {rec["between"]:6d} | tail {rec["tail"]:6d}')
+    if fine: print('        fine markers (tag: cycles before it):', fine)
     if w in (0, 4):
         print('        per stage (wait, loop):', ' '.join(f'{a}/{b}' for a, b in stages))
 m = {k: int(np.mean([r[k] for r in rows])) for k in rows[0]}

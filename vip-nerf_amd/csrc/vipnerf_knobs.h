@@ -17,7 +17,7 @@
     X(VN_BF16_H16) X(VN_T16) X(VN_T16_X4) X(VN_T16_NT) X(VN_PT2_SPREAD) X(VN_PT2_SKEW) X(VN_PT2_G) X(VN_PT2_D)                  \
     X(VN_PT2_TRAIN_KEEP) X(VN_PT2_EVAL_KEEP) X(VN_PT2_FAST_PE)                                                                                              \
     /* weight gradients (vipnerf_wgrad.hip, vipnerf_wgrad16.hip) */                                                                       \
-    X(VN_WGRAD_SIGMA_FUSED) X(VN_WGRAD_VIEW_FUSED) X(VN_WGRAD_LATE_LOAD) X(VN_WGRAD_LATE_STORE) X(VN_WGRAD_DMA) X(VN_WGRAD_W8) X(VN_WGRAD_PIPE) X(VN_WGRAD_ONE_ROUND) X(VN_WGRAD_ROUNDS) X(VN_WG16_BIG_WM) X(VN_WG16_BIG_WN)        \
+    X(VN_WGRAD_SIGMA_FUSED) X(VN_WGRAD_VIEW_FUSED) X(VN_WGRAD_LATE_LOAD) X(VN_WGRAD_LATE_STORE) X(VN_WGRAD_STORE_SKEW) X(VN_WGRAD_FAST) X(VN_WGRAD_BIAS_WK0) X(VN_WGRAD_VECFRAG) X(VN_WGRAD_PREFETCH) X(VN_WGRAD_DMA) X(VN_WGRAD_W8) X(VN_WGRAD_PIPE) X(VN_WGRAD_ONE_ROUND) X(VN_WGRAD_ROUNDS) X(VN_WG16_BIG_WM) X(VN_WG16_BIG_WN)        \
     X(VN_WG16_BIG_NB) X(VN_WG16_HYBRID) X(VN_WG16_SIGMA_FUSED) X(VN_WG16_DMA_PIECES) X(VN_WG16_THIN_HYBRID) X(VN_WG16_BIG_SLOTS)          \
     /* optimizer (vipnerf_api.hip) */                                                                                                     \
     X(VN_ADAM_FMA_MASK)
@@ -117,6 +117,21 @@
 #endif
 #ifndef VN_WGRAD_LATE_STORE
 #define VN_WGRAD_LATE_STORE 12     // ... and behind which it stores them to LDS (a SIMD's second wave: 2 steps later)
+#endif
+#ifndef VN_WGRAD_STORE_SKEW
+#define VN_WGRAD_STORE_SKEW 2      // ... the second wave's lag in k-steps for those LDS stores
+#endif
+#ifndef VN_WGRAD_FAST
+#define VN_WGRAD_FAST 1            // k_wgrad256_w8: a block loop without range logic for whole [P][256] operands and whole 32-point blocks (8.15 -> 7.90 ms per step with the operand bases pinned in SGPRs)
+#endif
+#ifndef VN_WGRAD_BIAS_WK0
+#define VN_WGRAD_BIAS_WK0 1        // k_wgrad256_w8: only the waves that store a bias sum (the older wave of every SIMD) form it, behind a scalar branch at the block's end (7.89 -> 7.85)
+#endif
+#ifndef VN_WGRAD_VECFRAG
+#define VN_WGRAD_VECFRAG 1         // k_wgrad256_w8: a wave's tiles are interleaved feature sets, its fragments one 8-byte + one 16-byte LDS read per k-step at immediate offsets (no address arithmetic among the MFMAs)
+#endif
+#ifndef VN_WGRAD_PREFETCH
+#define VN_WGRAD_PREFETCH 1        // ... and k-step s + 1's fragments are requested before k-step s's MFMAs (7.86 -> 7.79)
 #endif
 #ifndef VN_WGRAD_DMA
 #define VN_WGRAD_DMA 0           // exact-fp32 256 x 256 weight gradients: 1 = operand blocks HBM -> LDS by DMA instead of through registers -- built, correct, and measured SLOWER (9.10 vs 8.22 ms per step: docs/HISTORY.md 5); off

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
 
 #if defined(VN_EXP) && VN_EXP == 50
 extern "C" int vipnerf_exp_timeline_nb(unsigned long long *out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nb_timeline), sizeof(unsigned long long) * (n < 1024 ? n : 1024));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nb_timeline), sizeof(unsigned long long) * (n < 2048 ? n : 2048));
 }
 #endif
 

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_bwd_pt2(MlpBwdArgs a) {
 
 #if defined(VN_EXP) && VN_EXP == 50
 extern "C" int vipnerf_exp_timeline_bwd(unsigned long long *out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pt2_timeline_bwd), sizeof(unsigned long long) * (n < 1024 ? n : 1024));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pt2_timeline_bwd), sizeof(unsigned long long) * (n < 2048 ? n : 2048));
 }
 #endif
 

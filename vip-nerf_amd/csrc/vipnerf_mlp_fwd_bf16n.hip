@@ -296,7 +296,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_fwd_bf16n(MlpFwdArgs a) 
 
 #if defined(VN_EXP) && VN_EXP == 50
 extern "C" int vipnerf_exp_timeline_n(unsigned long long *out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_n_timeline), sizeof(unsigned long long) * (n < 1024 ? n : 1024));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_n_timeline), sizeof(unsigned long long) * (n < 2048 ? n : 2048));
 }
 #endif
 

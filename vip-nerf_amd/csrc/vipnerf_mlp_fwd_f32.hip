@@ -137,12 +137,14 @@ __global__ __launch_bounds__(PLFF::WG) void k_mlp_fwd_f32(MlpFwdArgs a) {
         const float *bias = rf + (layer < 8 ? PL::N_BIAS + layer * W : PL::N_BFEAT) + 4 * q;
 #pragma unroll
         for (int t = 0; t < 16; ++t) { const float4 b4 = *(const float4 *)(bias + 16 * t); acc[t][0] = b4.x; acc[t][1] = b4.y; acc[t][2] = b4.z; acc[t][3] = b4.w; }
+        TSFF(TS_EPI_A);
         const bool sig = layer == 8;                      // h_8 also feeds the sigma head
         float *hdst = SAVE ? a.acts + a.al.h[layer - 1] : nullptr;
         uint2 *mdst = SAVE ? (uint2 *)(a.acts + a.al.hm[layer - 1] + ((size_t)p * 4 + q) * 2) : nullptr;
         mk[0] = 0u; mk[1] = 0u;
         fwd_conv_kstep<SAVE>(xr, bin, 0, mk, sig, sg, wsig);
         fwd_conv_kstep<SAVE>(xr, bin, 1, mk, sig, sg, wsig);
+        TSFF(TS_EPI_B);
 #pragma unroll
         for (int jj = 0; jj < PL::ST_256; ++jj) {
             // counted wait (training): since it issued this stage's DMA (behind group 0 of the stage before) the issuing wave has executed that
@@ -168,6 +170,7 @@ __global__ __launch_bounds__(PLFF::WG) void k_mlp_fwd_f32(MlpFwdArgs a) {
         }
 #pragma unroll
         for (int t = 0; t < 16; ++t) xr[t] = acc[t];
+        TSFF(15);
     }
 
     // ---------------------------------------------------------------- sigma (from the products gathered during GEMM 8's conversions)
@@ -210,12 +213,14 @@ __global__ __launch_bounds__(PLFF::WG) void k_mlp_fwd_f32(MlpFwdArgs a) {
         TSFF(TS_VIEW);
     }
     stream_end(ws);
+    TSFF(16);
 
 #pragma unroll 1
     for (int dsel = 0; dsel <= a.src.V; ++dsel) {
         float dir[3];
         if (dsel == 0) { dir[0] = pc.dir[0]; dir[1] = pc.dir[1]; dir[2] = pc.dir[2]; }
         else secondary_dir(a.src, pc, dsel - 1, dir);
+        TSFF(10);
         float ped[1][8];
         encode_d16(dir, q, ped);
         FR bpd[1][2];
@@ -228,6 +233,7 @@ __global__ __launch_bounds__(PLFF::WG) void k_mlp_fwd_f32(MlpFwdArgs a) {
         for (int t = 0; t < 8; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) g[t][r] = relu_lo<SAVE>(g[t][r], 0.f);     // (training: +0 | positive | NaN for the ReLU bits)
+        TSFF(12);
         if (SAVE) {
             if (!EXP_NO_EXTRAS) {
 #pragma unroll
@@ -239,6 +245,7 @@ __global__ __launch_bounds__(PLFF::WG) void k_mlp_fwd_f32(MlpFwdArgs a) {
             }
             if (valid && !EXP_NO_PE) store_d16(a.acts + a.al.ped[dsel] + (size_t)p * DVE_PAD, q, ped);
         }
+        TSFF(13);
         float qv[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -265,13 +272,14 @@ __global__ __launch_bounds__(PLFF::WG) void k_mlp_fwd_f32(MlpFwdArgs a) {
                 a.vis2[p * a.src.V + (dsel - 1)] = qv[3];
             }
         }
+        TSFF(14);
     }
     TSFF(TS_LAST);
 }
 
 #if defined(VN_EXP) && VN_EXP == 50
 extern "C" int vipnerf_exp_timeline_f32f(unsigned long long *out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_f32f_timeline), sizeof(unsigned long long) * (n < 1024 ? n : 1024));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_f32f_timeline), sizeof(unsigned long long) * (n < 2048 ? n : 2048));
 }
 #endif
 

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_fwd_pt2(MlpFwdArgs a) {
 
 #if defined(VN_EXP) && VN_EXP == 50
 extern "C" int vipnerf_exp_timeline(unsigned long long *out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pt2_timeline), sizeof(unsigned long long) * (n < 1024 ? n : 1024));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pt2_timeline), sizeof(unsigned long long) * (n < 2048 ? n : 2048));
 }
 #endif
 

@@ -67,9 +67,9 @@ __device__ __forceinline__ int pt2_store_phase(int wave) {
 // TS(tag) is nothing in every other build.
 enum { TS_ENTRY = 0, TS_RESIDENT = 1, TS_HEAD = 2, TS_PRE = 3, TS_POST = 4, TS_END = 5, TS_VIEW = 6, TS_LAST = 7, TS_EPI_A = 8, TS_EPI_B = 9 };
 #if defined(VN_EXP) && VN_EXP == 50
-#define TS_DECL(buf) __device__ unsigned long long buf[8 * 128]
+#define TS_DECL(buf) __device__ unsigned long long buf[8 * 256]
 #define TS_INIT() const bool ts_rec = blockIdx.x == gridDim.x / 2 && lane == 0; int ts_n = 0
-#define TS_AT(buf, tag) do { if (ts_rec) { buf[wave * 128 + (ts_n < 127 ? ts_n : 127)] = ((unsigned long long)(tag) << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull); ++ts_n; } } while (0)
+#define TS_AT(buf, tag) do { if (ts_rec) { buf[wave * 256 + (ts_n < 255 ? ts_n : 255)] = ((unsigned long long)(tag) << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull); ++ts_n; } } while (0)
 #else
 #define TS_DECL(buf)
 #define TS_INIT() do { } while (0)

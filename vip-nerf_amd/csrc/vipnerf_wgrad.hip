@@ -70,16 +70,21 @@ __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
     float4 ra[MT], rb[KT];
     // whole-tile-contiguous operands (row stride == padded width, all columns valid) are a linear 16 B/lane copy
     const bool linA = d.lda == Mp && d.m_load == Mp, linB = d.ldb == Kp && d.k_load == Kp;
+    // the operand bases pinned in SGPRs (see wgrad256_body: re-read from the kernel arguments per block otherwise, behind an s_waitcnt lgkmcnt(0))
+    typedef float __attribute__((ext_vector_type(4))) f4v;
+    typedef const f4v __attribute__((address_space(1))) *gf4p;
+    unsigned long long uA = (unsigned long long)d.A, uB = (unsigned long long)d.B;
+    asm volatile("" : "+s"(uA), "+s"(uB));
+    const gf4p gA = (gf4p)uA, gB = (gf4p)uB;
     auto gload = [&](int blk) {
         const int64_t pb = p0 + (int64_t)blk * 32;
         const bool inrange = pb + 32 <= p1;
         if (inrange && linA && linB) {
-            const float4 *ta = (const float4 *)(d.A + (size_t)pb * Mp) + tid;
-            const float4 *tb = (const float4 *)(d.B + (size_t)pb * Kp) + tid;
+            const gf4p ta = gA + (size_t)pb * (Mp / 4) + tid, tb = gB + (size_t)pb * (Kp / 4) + tid;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) ra[i] = ta[256 * i];
+            for (int i = 0; i < MT; ++i) { const f4v v = ta[256 * i]; ra[i] = make_float4(v.x, v.y, v.z, v.w); }
 #pragma unroll
-            for (int i = 0; i < KT; ++i) rb[i] = tb[256 * i];
+            for (int i = 0; i < KT; ++i) { const f4v v = tb[256 * i]; rb[i] = make_float4(v.x, v.y, v.z, v.w); }
             return;
         }
 #pragma unroll
@@ -301,10 +306,17 @@ TS_DECL(g_wg_timeline);            // VN_EXP == 50: per-block time stamps of one
 #define TSW(tag) TS_AT(g_wg_timeline, tag)
 // WC: this workgroup's GEMM carries a weighted-column-sum head (WgDesc::wcol).  Compiled as a second copy of the body that only the feature
 // layer's workgroups enter: with the head's code behind a run-time flag in ONE body the other seven GEMMs' blocks measured 2 % slower.
-template <int WK, bool WC>
+// FAST: both operands are whole [P][256] arrays and the chunk is whole 32-point blocks (the render / training path: always) -- a block's loads are a
+// scalar base (advanced on the scalar unit) plus a per-thread 32-bit offset that never changes, with no bounds logic in the loop: as one body with
+// the general path behind run-time flags, every block carried ~50 vector instructions of 64-bit address arithmetic and range compares for loads it
+// did not take (each one an issue slot an MFMA does not get).
+template <int WK, bool WC, bool FAST>
 __device__ __forceinline__ void wgrad256_body(const WgArgs &a) {
     constexpr int MTW = 2, KTW = 8 / WK, Mp = 256, Kp = 256, NTH = 256 * WK, NLD = 2048 / NTH;   // float4 of A and of B per thread and block
     constexpr int TILE_F = 32 * (Mp + Kp);
+    constexpr bool VECFRAG = VN_WGRAD_VECFRAG && KTW == 4;
+    typedef float __attribute__((ext_vector_type(2))) f2v;
+    typedef float __attribute__((ext_vector_type(4))) f4v;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const WgDesc &d = a.d[blockIdx.y];
     if ((int)blockIdx.x >= d.n_chunks) return;
@@ -335,6 +347,15 @@ __device__ __forceinline__ void wgrad256_body(const WgArgs &a) {
     float4 wsum = make_float4(0.f, 0.f, 0.f, 0.f);
     float wtot = 0.f;
     const bool linA = d.lda == Mp && d.m_load == Mp, linB = d.ldb == Kp && d.k_load == Kp;
+    // the operand bases live in SGPRs for the whole kernel: left to the compiler they are re-read from the kernel arguments by every block's
+    // gload (s_load + s_waitcnt lgkmcnt(0) -- which also drains the wave's LDS fragment reads in flight in the middle of its MFMA loop)
+    // (as GLOBAL-address-space pointers: a pointer that went through an asm operand is generic to the compiler, and flat loads count in lgkmcnt too)
+    typedef const float __attribute__((address_space(1))) *gfp;
+    typedef const f4v __attribute__((address_space(1))) *gf4p;
+    unsigned long long uA = (unsigned long long)d.A, uB = (unsigned long long)d.B, uW = (unsigned long long)d.wcol;
+    int dwstride = d.wcol_stride;
+    asm volatile("" : "+s"(uA), "+s"(uB), "+s"(uW), "+s"(dwstride));
+    const gfp dA = (gfp)uA, dB = (gfp)uB, dwcol = (gfp)uW;
     // the head's weights of a block: lane i < NLD of every wave loads w[row (tid >> 6) + (NTH / 64) i] with ONE vector load BEHIND the operand
     // loads (so that the counted waits on those are what they were); lstore broadcasts the NLD values with v_readlane.  (As NLD loads ahead
     // of the operands, vector or scalar, the feature layer's workgroups ran ~15 % longer: profiles/r05_ab_thin_wgrad.log.)
@@ -342,16 +363,20 @@ __device__ __forceinline__ void wgrad256_body(const WgArgs &a) {
     auto wload = [&](int64_t pb) {
         if (wc) {
             const int64_t pr = pb + (tid >> 6) + (NTH / 64) * (lane < NLD ? lane : 0);
-            wv = (lane < NLD && pr < p1) ? d.wcol[(size_t)pr * d.wcol_stride] : 0.f;
+            wv = (lane < NLD && pr < p1) ? dwcol[(size_t)pr * dwstride] : 0.f;
         }
     };
+    typedef const char __attribute__((address_space(1))) *gcp;
+    const unsigned voff = (unsigned)tid * 16u;
     auto gload = [&](int blk) {
         const int64_t pb = p0 + (int64_t)blk * 32;
-        if (pb + 32 <= p1 && linA && linB) {
-            const float4 *ta = (const float4 *)(d.A + (size_t)pb * Mp) + tid;
-            const float4 *tb = (const float4 *)(d.B + (size_t)pb * Kp) + tid;
+        if (FAST || (pb + 32 <= p1 && linA && linB)) {
+            const gcp ba = (gcp)(dA + (size_t)pb * Mp), bb = (gcp)(dB + (size_t)pb * Kp);       // wave-uniform
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) { ra[i] = ta[NTH * i]; rb[i] = tb[NTH * i]; }
+            for (int i = 0; i < NLD; ++i) {
+                const f4v va = *(gf4p)(ba + (voff + (unsigned)(NTH * 16 * i))), vb = *(gf4p)(bb + (voff + (unsigned)(NTH * 16 * i)));
+                ra[i] = make_float4(va.x, va.y, va.z, va.w); rb[i] = make_float4(vb.x, vb.y, vb.z, vb.w);
+            }
             wload(pb);
             return;
         }
@@ -406,7 +431,10 @@ __device__ __forceinline__ void wgrad256_body(const WgArgs &a) {
     // a block's 19.7k cycles had no MFMA in flight on the SIMD (the block's MFMAs are 16.4k); now 18.8k per block.
     const bool late = VN_WGRAD_LATE_LOAD >= 0;
     const int second = (wave >> 2) & 1;
+    f2v a2n = {0.f, 0.f}; f4v b4n = {0.f, 0.f, 0.f, 0.f};
     int cur = 0;
+    // only the waves that store a bias sum (wk == 0: the OLDER wave of every SIMD) form it
+    const bool bias_wave = __builtin_amdgcn_readfirstlane(wave >> 2) == 0;
     for (int blk = 0; blk < nblk; ++blk) {
         if (dma) {
             glds_drain();                                    // this wave's pieces of block blk (issued one block ago)
@@ -416,21 +444,56 @@ __device__ __forceinline__ void wgrad256_body(const WgArgs &a) {
         } else if (!late && blk + 1 < nblk) gload(blk + 1);
         TSW(TS_POST);
         const float *la = lds + cur * TILE_F, *lb = la + 32 * Mp;
+        float afs[16][MTW];                                  // (VN_WGRAD_BIAS_WK0) the block's A fragments, summed behind its MFMAs by the waves that store the sums
+        if (VECFRAG && VN_WGRAD_PREFETCH) {
+            a2n = *(const f2v *)(la + h * Mp + 64 * wm + 2 * l31);
+            b4n = *(const f4v *)(lb + h * Kp + 128 * wk + 4 * l31);
+        }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             if (!dma && late && s == VN_WGRAD_LATE_LOAD + 4 * second && blk + 1 < nblk) gload(blk + 1);
             float af[MTW], bf[KTW];
+            if (VECFRAG && VN_WGRAD_PREFETCH) {
+                // the fragments of k-step s + 1 are requested BEFORE the MFMAs of k-step s (two registers sets): a wave alone on its SIMD -- the younger
+                // one at the end of every block -- otherwise sits out the LDS latency once per k-step pair
+                const f2v a2 = a2n; const f4v b4 = b4n;
+                if (s + 1 < 16) {
+                    a2n = *(const f2v *)(la + (2 * (s + 1) + h) * Mp + 64 * wm + 2 * l31);
+                    b4n = *(const f4v *)(lb + (2 * (s + 1) + h) * Kp + 128 * wk + 4 * l31);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                af[0] = a2.x; af[1] = a2.y;
+                bf[0] = b4.x; bf[1] = b4.y; bf[2] = b4.z; bf[KTW - 1] = b4.w;
+            } else if (VECFRAG) {
+                // a wave's M tile i is features 64 wm + 2 l + i, its K tile j features 128 wk + 4 l + j (l = 0..31): the lane's fragments of a k-step are
+                // ONE 8-byte and ONE 16-byte read of the row-major tile at immediate offsets from two per-block bases -- no address arithmetic among
+                // the MFMAs (32 consecutive features per tile took three ds_read2_b32 and three v_add per k-step)
+                const f2v a2 = *(const f2v *)(la + (2 * s + h) * Mp + 64 * wm + 2 * l31);
+                const f4v b4 = *(const f4v *)(lb + (2 * s + h) * Kp + 128 * wk + 4 * l31);
+                af[0] = a2.x; af[1] = a2.y;
+                bf[0] = b4.x; bf[1] = b4.y; bf[2] = b4.z; bf[KTW - 1] = b4.w;
+            } else {
 #pragma unroll
             for (int i = 0; i < MTW; ++i) af[i] = la[(2 * s + h) * Mp + 32 * (wm * MTW + i) + l31];
 #pragma unroll
             for (int j = 0; j < KTW; ++j) bf[j] = lb[(2 * s + h) * Kp + 32 * (wk * KTW + j) + l31];
+            }
 #pragma unroll
             for (int i = 0; i < MTW; ++i) {
-                bsum[i] += af[i];
+                if (!VN_WGRAD_BIAS_WK0) bsum[i] += af[i];
+                if (VN_WGRAD_BIAS_WK0) afs[s][i] = af[i];
 #pragma unroll
                 for (int j = 0; j < KTW; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
             }
-            if (!dma && late && s == VN_WGRAD_LATE_STORE + 2 * second && blk + 1 < nblk) lstore(cur ^ 1);
+            if (VECFRAG && VN_WGRAD_PREFETCH) __builtin_amdgcn_sched_barrier(0);
+            if (!dma && late && s == VN_WGRAD_LATE_STORE + VN_WGRAD_STORE_SKEW * second && blk + 1 < nblk) lstore(cur ^ 1);
+        }
+        if (VN_WGRAD_BIAS_WK0 && bias_wave) {
+            asm volatile("" ::);                             // (a real scalar branch: as a select the other waves would form the sums too)
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int i = 0; i < MTW; ++i) bsum[i] += afs[s][i];
         }
         TSW(TS_END);
         if (!dma) {
@@ -442,6 +505,20 @@ __device__ __forceinline__ void wgrad256_body(const WgArgs &a) {
         cur ^= 1;
     }
     float *part = a.partial + d.part_off + (size_t)blockIdx.x * d.part_stride;
+    if (VECFRAG) {
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = 64 * wm + 2 * ((r & 3) + 8 * (r >> 2) + 4 * h) + i;
+                *(float4 *)(part + (size_t)o * Kp + 128 * wk + 4 * l31) = make_float4(acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][KTW - 1][r]);
+            }
+            if (wk == 0) {
+                const float b = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+                if (h == 0) part[(size_t)Mp * Kp + 64 * wm + 2 * l31 + i] = b;
+            }
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
         const int ot = wm * MTW + i;
@@ -482,8 +559,12 @@ __device__ __forceinline__ void wgrad256_body(const WgArgs &a) {
 }
 template <int WK>       // waves along K: 2 -> 8 waves (2 x 4 tiles each), 4 -> 16 waves (2 x 2 tiles each)
 __global__ __launch_bounds__(256 * WK) void k_wgrad256_w8(WgArgs a) {
-    if (a.d[blockIdx.y].wcol != nullptr) wgrad256_body<WK, true>(a);
-    else wgrad256_body<WK, false>(a);
+    const WgDesc &d = a.d[blockIdx.y];
+    const int64_t p0 = (int64_t)blockIdx.x * a.chunk_pts;
+    const int64_t p1 = p0 + a.chunk_pts < a.P ? p0 + a.chunk_pts : a.P;
+    const bool fast = d.lda == 256 && d.m_load == 256 && d.ldb == 256 && d.k_load == 256 && (p1 - p0) % 32 == 0 && !VN_WGRAD_DMA && VN_WGRAD_FAST;
+    if (d.wcol != nullptr) { if (fast) wgrad256_body<WK, true, true>(a); else wgrad256_body<WK, true, false>(a); }
+    else { if (fast) wgrad256_body<WK, false, true>(a); else wgrad256_body<WK, false, false>(a); }
 }
 
 // Weight-gradient GEMMs on split-precision bf16 MFMA ("bf16x3": hi/lo parts, 3 cross terms, fp32 accumulate),
@@ -1497,7 +1578,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
 
 #if defined(VN_EXP) && VN_EXP == 50
 extern "C" int vipnerf_exp_timeline_wg(unsigned long long *out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_timeline), sizeof(unsigned long long) * (n < 1024 ? n : 1024));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_timeline), sizeof(unsigned long long) * (n < 2048 ? n : 2048));
 }
 #endif
 

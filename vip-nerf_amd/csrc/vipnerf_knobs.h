@@ -17,7 +17,7 @@
     X(VN_BF16_H16) X(VN_T16) X(VN_T16_X4) X(VN_T16_NT) X(VN_PT2_SPREAD) X(VN_PT2_SKEW) X(VN_PT2_G) X(VN_PT2_D)                  \
     X(VN_PT2_TRAIN_KEEP) X(VN_PT2_EVAL_KEEP) X(VN_PT2_FAST_PE)                                                                                              \
     /* weight gradients (vipnerf_wgrad.hip, vipnerf_wgrad16.hip) */                                                                       \
-    X(VN_WGRAD_SIGMA_FUSED) X(VN_WGRAD_VIEW_FUSED) X(VN_WGRAD_LATE_LOAD) X(VN_WGRAD_LATE_STORE) X(VN_WGRAD_STORE_SKEW) X(VN_WGRAD_FAST) X(VN_WGRAD_BIAS_WK0) X(VN_WGRAD_VECFRAG) X(VN_WGRAD_PREFETCH) X(VN_WGRAD_DMA) X(VN_WGRAD_W8) X(VN_WGRAD_PIPE) X(VN_WGRAD_ONE_ROUND) X(VN_WGRAD_ROUNDS) X(VN_WG16_BIG_WM) X(VN_WG16_BIG_WN)        \
+    X(VN_WGRAD_SIGMA_FUSED) X(VN_WGRAD_VIEW_FUSED) X(VN_WGRAD_HEADS_FUSED) X(VN_WGRAD_LATE_LOAD) X(VN_WGRAD_LATE_STORE) X(VN_WGRAD_STORE_SKEW) X(VN_WGRAD_FAST) X(VN_WGRAD_BIAS_WK0) X(VN_WGRAD_VECFRAG) X(VN_WGRAD_PREFETCH) X(VN_WGRAD_DMA) X(VN_WGRAD_W8) X(VN_WGRAD_PIPE) X(VN_WGRAD_ONE_ROUND) X(VN_WGRAD_ROUNDS) X(VN_WG16_BIG_WM) X(VN_WG16_BIG_WN)        \
     X(VN_WG16_BIG_NB) X(VN_WG16_HYBRID) X(VN_WG16_SIGMA_FUSED) X(VN_WG16_DMA_PIECES) X(VN_WG16_THIN_HYBRID) X(VN_WG16_BIG_SLOTS)          \
     /* optimizer (vipnerf_api.hip) */                                                                                                     \
     X(VN_ADAM_FMA_MASK)
@@ -117,6 +117,9 @@
 #endif
 #ifndef VN_WGRAD_LATE_STORE
 #define VN_WGRAD_LATE_STORE 12     // ... and behind which it stores them to LDS (a SIMD's second wave: 2 steps later)
+#endif
+#ifndef VN_WGRAD_HEADS_FUSED
+#define VN_WGRAD_HEADS_FUSED 1     // exact fp32, V <= 1: the output head's weight gradient rides in k_wgrad_view (the waves without a direction tile take it); 0: its own launch (k_wgrad<1,1,1>)
 #endif
 #ifndef VN_WGRAD_STORE_SKEW
 #define VN_WGRAD_STORE_SKEW 2      // ... the second wave's lag in k-steps for those LDS stores

@@ -169,14 +169,15 @@ __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
 // LDS stores that consume them (registers carry block b + 2 through iteration b + 1).
 struct WgViewArgs {
     const float *dyv[1 + VIPNERF_MAX_SEC], *ped[1 + VIPNERF_MAX_SEC], *feat;
+    const float *g[1 + VIPNERF_MAX_SEC], *dq[1 + VIPNERF_MAX_SEC];      // HEADS: the view hidden activations [P][128] and the head seeds [P][8] of every direction
     int64_t P;
     int chunk_pts, n_chunks;
-    float *part_vf, *part_vd;                 // chunk 0 of the two partial products ([128][256] + 128 column sums; [128][32] + 128 unused)
-    size_t stride_vf, stride_vd;
+    float *part_vf, *part_vd, *part_oh;       // chunk 0 of the partial products ([128][256] + 128 column sums; [128][32] + 128 unused; HEADS: [32][128] + 32 column sums)
+    size_t stride_vf, stride_vd, stride_oh;
 };
 // one block's worth of staged operands in registers (thread tid: float4 (row tid >> 5, columns 4 (tid & 31)) of every dYv_a, float4 tid and
 // tid + 512 of the feature block -- rows tid >> 6 and 8 + (tid >> 6) --, and, the first 128 threads, float4 (row tid >> 3, columns 4 (tid & 7)) of
-// every gamma(dir_a))
+// every gamma(dir_a)).  (HEADS: the view hidden g_a and the head seeds dq_a go HBM -> LDS by DMA instead: no registers left for them.)
 template <int NV> struct ViewStage { float4 rv[NV], rf[2], rp[NV]; };
 template <int NV>
 __device__ __forceinline__ void view_gload(ViewStage<NV> &r, const WgViewArgs &a, int64_t pb, int64_t p1, int tid) {
@@ -211,13 +212,19 @@ __device__ __forceinline__ void view_lstore(const ViewStage<NV> &r, float *t, in
         for (int k = 0; k < NV; ++k) ((float4 *)(t + O_PED + k * BP * DVE_PAD))[tid] = r.rp[k];
     }
 }
-template <int NV>
+// HEADS (NV <= 2: what LDS holds): the output head's weight gradient dW_out[c][:] = sum_a sum_p dq_a[p][c] g_a[p][:] (4 x 128; reference
+// VipNeRF01.py:591-596, views_output_linear over the view hidden g_a of every direction) rides in the same launch: the waves wk == 1 -- which
+// have no direction tile -- take its 32 x 32 tiles (M = the seeds' 4 columns in a zero-padded 32, N tile wm of the 128 hidden units), so both
+// waves of a SIMD run 8 (4 + NV) MFMAs per block; before, one more launch per level (k_wgrad<1, 1, 1>, 0.21 ms per step) read g_a and dq_a.
+template <int NV, bool HEADS>
 __global__ __launch_bounds__(512) void k_wgrad_view(WgViewArgs a) {
     constexpr int BP = 16;                                   // points per block
     constexpr int O_SUM = NV > 1 ? NV * BP * WV : 0;         // the sum tile (NV == 1: dYv_0 itself)
     constexpr int O_PED = O_SUM + (NV > 1 ? BP * WV : NV * BP * WV);
     constexpr int O_FEAT = O_PED + NV * BP * DVE_PAD;
-    constexpr int TILE_F = O_FEAT + BP * W;
+    constexpr int O_G = O_FEAT + BP * W;
+    constexpr int O_DQ = O_G + (HEADS ? NV * BP * WV : 0);
+    constexpr int TILE_F = O_DQ + (HEADS ? NV * BP * 8 : 0);          // (the seeds' blocks as they lie in HBM: [16][8])
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if ((int)blockIdx.x >= a.n_chunks) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -230,8 +237,33 @@ __global__ __launch_bounds__(512) void k_wgrad_view(WgViewArgs a) {
     floatx16 acc[4], accd = (floatx16)(0.f);
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (floatx16)(0.f);
-    float bsum = 0.f;
+    float bsum = 0.f, bsx = 0.f;
+    // the per-direction product of this wave: wk == 0: dYv_a^T gamma(dir_a) (M tile wm x the 32 direction columns); wk == 1 (HEADS): dq_a^T g_a (the
+    // seeds' padded tile x N tile wm of the hidden units) -- one code path, the operand tiles' offsets and row strides chosen once
+    const bool heads_wave = HEADS && __builtin_amdgcn_readfirstlane(wk) == 1;      // (wave-uniform, scalar)
+    const bool dir_wave = __builtin_amdgcn_readfirstlane(wk) == 0;
+    const bool seed_lane = l31 < 4;                          // the seeds are 4 columns of a 32-row operand: the other lanes supply zeros
+    // HEADS: block `pb`'s view hidden tiles (wave w: rows 2 w, 2 w + 1 of every direction = 1 KiB each) and seed blocks (wave 7's lanes 0..31: 512 B
+    // each) by DMA into buffer `buf`.  Issued BEHIND the LDS stores of a staging step and AHEAD of its register loads: VM_CNT retires in order, so
+    // the compiler's own counts for the register loads stay conservative, and vmcnt(younger register loads) in front of the block barrier
+    // proves the DMA has landed.
+    auto dma_heads = [&](int64_t pb, int buf) {
+        if (HEADS) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+                glds_chunks<1>(a.g[k] + (size_t)(pb + 2 * wave) * WV + lane * 4,
+                               __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds + buf * TILE_F + O_G + k * BP * WV + wave * 256)));
+            if (wave == 7 && lane < 32) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k)
+                    glds_chunks<1>(a.dq[k] + (size_t)pb * 8 + lane * 4, __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds + buf * TILE_F + O_DQ + k * BP * 8)));
+            }
+        }
+    };
 
+    if (HEADS) {
+        if (nblk > 0) dma_heads(p0, 0);
+    }
     // TWO register sets (block parity): a block's loads are issued two blocks ahead of the LDS stores that consume them
     ViewStage<NV> st0, st1;
     if (nblk > 0) { view_gload<NV>(st0, a, p0, p1, tid); view_lstore<NV, O_SUM, O_PED, O_FEAT>(st0, lds, tid); }
@@ -246,12 +278,16 @@ __global__ __launch_bounds__(512) void k_wgrad_view(WgViewArgs a) {
         for (int half = 0; half < 2; ++half) {
             const int b = blk + half;
             if (b < nblk) {
-                const float *t = lds + half * TILE_F;        // (blk is even: buffer = half)
+                int toff = half * TILE_F;                    // (blk is even: buffer = half)
+                if (HEADS) asm volatile("" : "+s"(toff));    // (opaque: folded into the reads' offsets, the second buffer's tiles -- beyond the 64 KiB an LDS instruction
+                                                             // offset reaches -- each took an address register of their own: 39 spilled registers)
+                const float *t = lds + toff;
 #pragma unroll
                 for (int s = 0; s < BP / 2; ++s) {
                     if (s == 1 + 4 * wk && b + 1 < nblk) {
                         ViewStage<NV> &nx = half == 0 ? st1 : st0;
                         view_lstore<NV, O_SUM, O_PED, O_FEAT>(nx, lds + (1 - half) * TILE_F, tid);
+                        dma_heads(p0 + (int64_t)(b + 1) * BP, 1 - half);
                         if (b + 3 < nblk) view_gload<NV>(nx, a, p0 + (int64_t)(b + 3) * BP, p1, tid);
                     }
                     const int row = 2 * s + h;
@@ -262,11 +298,27 @@ __global__ __launch_bounds__(512) void k_wgrad_view(WgViewArgs a) {
                     bsum += af;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[j] = mfma32(af, bf[j], acc[j]);
-                    if (wk == 0) {
+                    if (HEADS || dir_wave) {                 // ONE accumulator and one MFMA site for both roles (in two branches the compiler kept two accumulators)
+                        float x[NV], y[NV];
+                        if (dir_wave) {
 #pragma unroll
-                        for (int k = 0; k < NV; ++k)
-                            accd = mfma32(t[k * BP * WV + row * WV + 32 * wm + l31], t[O_PED + k * BP * DVE_PAD + row * DVE_PAD + l31], accd);
+                            for (int k = 0; k < NV; ++k) { x[k] = t[k * BP * WV + row * WV + 32 * wm + l31]; y[k] = t[O_PED + k * BP * DVE_PAD + row * DVE_PAD + l31]; }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < NV; ++k) {
+                                const float q = t[O_DQ + k * BP * 8 + row * 8 + (l31 & 3)];
+                                x[k] = seed_lane ? q : 0.f;
+                                bsx += x[k];
+                                y[k] = t[O_G + k * BP * WV + row * WV + 32 * wm + l31];
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < NV; ++k) accd = mfma32(x[k], y[k], accd);
                     }
+                }
+                if (HEADS) {                                 // this wave's DMA of block b + 1 has landed (younger: the NV + 2 register loads of block b + 3 every wave issues)
+                    if (b + 3 < nblk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NV + 2) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __syncthreads();
             }
@@ -284,12 +336,30 @@ __global__ __launch_bounds__(512) void k_wgrad_view(WgViewArgs a) {
         const float b = bsum + __shfl_xor(bsum, 32, 64);
         if (h == 0) pf[(size_t)WV * W + 32 * wm + l31] = b;
     }
+    if (HEADS) {
+        if (wk == 1) {                                       // [32][128] (rows 0..3: the head's four outputs) + the seeds' 32 column sums
+            float *po = a.part_oh + (size_t)blockIdx.x * a.stride_oh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) po[(size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * WV + 32 * wm + l31] = accd[r];
+            const float b = bsx + __shfl_xor(bsx, 32, 64);
+            if (wm == 0 && h == 0) po[(size_t)32 * WV + l31] = b;
+        }
+    }
 }
 template <int NV>
-static int launch_view(const WgViewArgs &va, hipStream_t st) {
+static int launch_view(const WgViewArgs &va, bool heads, hipStream_t st) {
+    if (heads) {
+        if constexpr (NV <= 2) {
+            const size_t ldsb = (size_t)2 * 16 * ((NV > 1 ? NV + 1 : 1) * WV + NV * DVE_PAD + W + NV * WV + NV * 8) * sizeof(float);
+            VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_view<NV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+            hipLaunchKernelGGL((k_wgrad_view<NV, true>), dim3(va.n_chunks), dim3(512), ldsb, st, va);
+            VN_HIP(hipGetLastError());
+            return VIPNERF_OK;
+        } else { set_error("wgrad: the output head rides in the view launch for at most two directions"); return VIPNERF_E_ARG; }
+    }
     const size_t ldsb = (size_t)2 * 16 * ((NV > 1 ? NV + 1 : 1) * WV + NV * DVE_PAD + W) * sizeof(float);
-    VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_view<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-    hipLaunchKernelGGL(k_wgrad_view<NV>, dim3(va.n_chunks), dim3(512), ldsb, st, va);
+    VN_HIP(hipFuncSetAttribute((const void *)k_wgrad_view<NV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    hipLaunchKernelGGL((k_wgrad_view<NV, false>), dim3(va.n_chunks), dim3(512), ldsb, st, va);
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;
 }
@@ -1492,7 +1562,10 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
     }
     // the view layer: exact fp32 in ONE launch over dYv_0..V (k_wgrad_view; no dYvsum); the split-precision modes as two GEMM classes
     const bool view_fused = precision == VIPNERF_PREC_FP32 && VN_WGRAD_VIEW_FUSED;
+    const bool heads_fused = view_fused && VN_WGRAD_HEADS_FUSED && V <= 1 && P % 16 == 0;       // (its DMA moves whole 16-point blocks)
     WgViewArgs va;
+    va.part_oh = nullptr; va.stride_oh = 0;
+    for (int k = 0; k <= VIPNERF_MAX_SEC; ++k) { va.g[k] = nullptr; va.dq[k] = nullptr; }
     if (view_fused) {
         for (int k = 0; k <= VIPNERF_MAX_SEC; ++k) { va.dyv[k] = bwd + bl.dyv[k <= V ? k : 0]; va.ped[k] = acts + al.ped[k <= V ? k : 0]; }
         va.feat = acts + al.feat; va.P = (int64_t)P; va.chunk_pts = chunk_single; va.n_chunks = n_single;
@@ -1503,6 +1576,13 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
         va.part_vd = partial + off;
         group(n_single, off, 1, 128, 32, WV, DVE, G->g[P_VW], W + DVE, W, nullptr);
         off += (size_t)n_single * va.stride_vd;
+        if (heads_fused) {     // the output head in the same launch (V <= 1): A = DQ[k][:, 0:4], B = view hidden of direction k, summed over k in the accumulator
+            for (int k = 0; k <= VIPNERF_MAX_SEC; ++k) { va.g[k] = acts + al.g[k <= V ? k : 0]; va.dq[k] = bwd + bl.dq[k <= V ? k : 0]; }
+            va.stride_oh = (size_t)32 * 128 + 32;
+            va.part_oh = partial + off;
+            group(n_single, off, 1, 32, 128, 4, WV, G->g[P_OW], WV, 0, G->g[P_OB]);
+            off += (size_t)n_single * va.stride_oh;
+        }
     } else {
     {   // view layer, feature columns: A = sum over directions
         const size_t o = add(c48, n48, 128, 256, bwd + bl.dyvsum, WV, WV, acts + al.feat, W, W);
@@ -1517,7 +1597,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
         group(n_thin, first, 1 + V, 128, 32, WV, DVE, G->g[P_VW], W + DVE, W, nullptr);
     }
     }
-    {   // output head: A = DQ[k][:, 0:4], B = view hidden of direction k
+    if (!heads_fused) {   // output head: A = DQ[k][:, 0:4], B = view hidden of direction k
         size_t first = 0;
         for (int k = 0; k <= V; ++k) {
             const size_t o = add(c14, n14, 32, 128, bwd + bl.dq[k], 8, 4, acts + al.g[k], WV, WV);
@@ -1562,7 +1642,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
     ProfScope ps("wgrad_small", st);
     if (precision == VIPNERF_PREC_FP32) {
         if (view_fused) {
-            rc = V == 0 ? launch_view<1>(va, st) : (V == 1 ? launch_view<2>(va, st) : (V == 2 ? launch_view<3>(va, st) : launch_view<4>(va, st)));
+            rc = V == 0 ? launch_view<1>(va, heads_fused, st) : (V == 1 ? launch_view<2>(va, heads_fused, st) : (V == 2 ? launch_view<3>(va, false, st) : launch_view<4>(va, false, st)));
             if (rc) return rc;
         } else if ((rc = launch_class<1, 8, 4>(c48, n48, n_single, st))) return rc;
         if ((rc = launch_class<2, 2, 4>(c82, n82, n_pe, st))) return rc;
@@ -1572,7 +1652,7 @@ int launch_wgrad(size_t P, int V, const float *acts, const ActLayout &al, float 
     }
     if (n41 && (rc = launch_class<1, 1, 4>(c41, n41, n_thin, st))) return rc;
     if (n18 && (rc = launch_class<1, 2, 1>(c18, n18, n_sigma, st))) return rc;
-    if ((rc = launch_class<1, 1, 1>(c14, n14, n_thin, st))) return rc;
+    if (n14 && (rc = launch_class<1, 1, 1>(c14, n14, n_thin, st))) return rc;
     return launch_wgrad_reduce(red, ng, st);
 }
 

@@ -18,7 +18,7 @@
     X(VN_PT2_TRAIN_KEEP) X(VN_PT2_EVAL_KEEP) X(VN_PT2_FAST_PE)                                                                                              \
     /* weight gradients (vipnerf_wgrad.hip, vipnerf_wgrad16.hip) */                                                                       \
     X(VN_WGRAD_SIGMA_FUSED) X(VN_WGRAD_VIEW_FUSED) X(VN_WGRAD_HEADS_FUSED) X(VN_WGRAD_LATE_LOAD) X(VN_WGRAD_LATE_STORE) X(VN_WGRAD_STORE_SKEW) X(VN_WGRAD_FAST) X(VN_WGRAD_BIAS_WK0) X(VN_WGRAD_VECFRAG) X(VN_WGRAD_PREFETCH) X(VN_WGRAD_DMA) X(VN_WGRAD_W8) X(VN_WGRAD_PIPE) X(VN_WGRAD_ONE_ROUND) X(VN_WGRAD_ROUNDS) X(VN_WG16_BIG_WM) X(VN_WG16_BIG_WN)        \
-    X(VN_WG16_BIG_NB) X(VN_WG16_HYBRID) X(VN_WG16_SIGMA_FUSED) X(VN_WG16_DMA_PIECES) X(VN_WG16_THIN_HYBRID) X(VN_WG16_BIG_SLOTS)          \
+    X(VN_WG16_BIG_NB) X(VN_WG16_HYBRID) X(VN_WG16_SIGMA_FUSED) X(VN_WG16_DMA_PIECES) X(VN_WG16_THIN_HYBRID) X(VN_WG16_BIG_SLOTS) X(VN_WG16_VIEW_FUSED) X(VN_WG16_VIEW_WN)          \
     /* optimizer (vipnerf_api.hip) */                                                                                                     \
     X(VN_ADAM_FMA_MASK)
 
@@ -171,6 +171,12 @@
 #endif
 #ifndef VN_WG16_THIN_HYBRID
 #define VN_WG16_THIN_HYBRID 0    // the 256 x 64 and 128 x 256 launches on the hybrid trip stream too (measured: docs/HISTORY.md 4.3a)
+#endif
+#ifndef VN_WG16_VIEW_FUSED
+#define VN_WG16_VIEW_FUSED 1     // 16-bit modes: the view layer's 128 x 256 and per-direction 128 x 32 weight-gradient GEMMs in one launch over dYv_0..V (k_wg16_view); the data-gradient kernels then write no dYvsum
+#endif
+#ifndef VN_WG16_VIEW_WN
+#define VN_WG16_VIEW_WN 2        // k_wg16_view: 2 x WN waves (2: four waves own 4 x 8 tiles each; 4: eight waves own 4 x 4)
 #endif
 #ifndef VN_WG16_BIG_SLOTS
 #define VN_WG16_BIG_SLOTS 256    // workgroups of the 256 x 256 launch at a large level: one round of the chip (two / three rounds measured: docs/HISTORY.md 4.3a)

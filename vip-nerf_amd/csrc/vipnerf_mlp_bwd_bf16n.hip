@@ -175,7 +175,7 @@ __global__ __launch_bounds__(BnPlan<NS>::WG) void k_mlp_bwd_bf16n(MlpBwdArgs a) 
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         split_pair<NS>(vsum[2 * s], vsum[2 * s + 1], bin[s]);
-        if (T16 && valid && !EXP_NO_EXTRAS) store_t16(a.bwd + a.bl.dyvsum, grp, 8, s, j, q, bin[s][0]);
+        if (T16 && valid && !EXP_NO_EXTRAS && !VN_WG16_VIEW_FUSED) store_t16(a.bwd + a.bl.dyvsum, grp, 8, s, j, q, bin[s][0]);
     }
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[t] = (floatx4)(0.f);

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(BnPlan<1>::WG) void k_mlp_bwd_pt2(MlpBwdArgs a) {
             split_pair<NS>(vsum[2 * s], vsum[2 * s + 1], t1);
             bin[s][0].v[pt] = t1[0];
             // (sent from inside the feature GEMM's stage instead -- DeferredT16 -- the data-gradient kernel measured 1.93 instead of 1.61 ms per step)
-            if (valid[pt] && !EXP_NO_EXTRAS) store_t16(a.bwd + a.bl.dyvsum, grp[pt], 8, s, j, q, t1[0]);
+            if (valid[pt] && !EXP_NO_EXTRAS && !VN_WG16_VIEW_FUSED) store_t16(a.bwd + a.bl.dyvsum, grp[pt], 8, s, j, q, t1[0]);
         }
     }
 

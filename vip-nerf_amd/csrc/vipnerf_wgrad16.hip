@@ -124,8 +124,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wg16(WgArgs a) {
             const int t = wm * TM + i;
             af[i] = frag16<FR>(A + t * 512, A + (MT + t) * 512, lane);
         }
-        FR ax;
-        const bool do_x = XA && has_x && wm == 0;    // (wave-uniform)
+        // (wave-uniform, and told so: as a per-lane condition the compiler predicates the extra tile's MFMAs with EXEC, which MFMA ignores --
+        // they then run in every wave on an unloaded fragment; harmless only as long as nothing else lives in accx)
+        const bool do_x = XA && has_x && __builtin_amdgcn_readfirstlane(wm) == 0;
+        FR ax = __builtin_bit_cast(FR, make_uint4(0u, 0u, 0u, 0u));
         if (do_x) ax = frag16<FR>(A + PIECES * 1024, A + PIECES * 1024 + 512, lane);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -275,6 +277,187 @@ __global__ __launch_bounds__(64 * WM * WN) void k_wg16(WgArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The view layer's weight gradient in ONE launch (the T16 counterpart of vipnerf_wgrad.hip's k_wgrad_view):
+//     dW_view[:, 0:256]   = sum_k dYv_k^T feature       (128 x 256; the sum over directions is taken in the accumulator: 1 + V MFMAs per cell)
+//     dW_view[:, 256:283] = sum_k dYv_k^T gamma(dir_k)  (128 x 32, likewise)
+//     db_view             = sum_k column sums of dYv_k
+// A 32-point block is NV x 8 KiB of dYv_0..V, 16 KiB of the feature and NV x 2 KiB of gamma(dir_0..V): every byte read ONCE -- the two
+// launches this replaces read dYv_k twice (once as dYvsum, which the data-gradient kernels no longer write: 256 B per point less stored).
+// Same stream as k_wg16's: 1 KiB DMA pieces into a ring of NB blocks (the LDS image is the HBM image), counted vmcnt, one raw barrier
+// per block, ds_read_b64_tr_b16 fragments.  Wave (wm, wn) of 2 x WN owns rows 64 wm .. + 63 and feature columns (256 / WN) wn ..; the
+// waves wn < 2 also own gamma(dir) column tile wn.
+// build switch VN_WG16_VIEW_FUSED (default 1, vipnerf_knobs.h): 0 = the 128 x 256 GEMM over dYvsum + one 128 x 32 GEMM per direction (two launches)
+struct WgView16Args {
+    const float *dyv[VIPNERF_MAX_SEC + 1], *ped[VIPNERF_MAX_SEC + 1], *feat;
+    int64_t P;
+    int chunk_pts, n_chunks;
+    float *part_vf, *part_vd;                 // per chunk: [128][256] + 128 column sums | [128][32] (+ 128 unused)
+    size_t stride_vf, stride_vd;
+};
+template <bool BF, int NV, int WN, int NB>
+__global__ __launch_bounds__(128 * WN) void k_wg16_view(WgView16Args a) {
+    typedef typename FragOf<!BF>::type FR;
+    constexpr int MT = 8, NT = 16, PT = 2, WM = 2, NW = WM * WN, TM = MT / WM, TN = NT / WN;
+    constexpr int NPA = NV * MT / NW, NPF = NT / NW, NPP = (NV * PT + NW - 1) / NW;     // pieces per wave and block: dYv, feature, gamma(dir)
+    constexpr int PIECES = NV * MT + NT + NV * PT, BLK = PIECES * 1024;
+    constexpr int PW = NPA + NPF + NPP, MINP = NPA + NPF + NV * PT / NW;               // (the waits count the waves that issue fewest)
+    constexpr int OFF_F = NV * MT * 1024, OFF_P = OFF_F + NT * 1024;
+    static_assert((NV * MT) % NW == 0 && NT % NW == 0 && NT % WN == 0 && WN >= PT && NB >= 2 && NB <= 4 && (NB - 1) * PW <= 63, "shape");
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    char *lds = (char *)lds_f;
+    if ((int)blockIdx.x >= a.n_chunks) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int64_t p0 = (int64_t)blockIdx.x * a.chunk_pts;
+    const int64_t p1 = p0 + a.chunk_pts < a.P ? p0 + a.chunk_pts : a.P;
+    const int nblk = (int)((p1 - p0) / 32);          // P and the chunk sizes are multiples of 32
+    const size_t g0 = (size_t)(p0 >> 4);             // first 16-point group of the chunk
+
+    // this wave's pieces of a block: source (block 0 of the chunk, this lane's 16 bytes) and LDS offset inside a block's image
+    const char *srcA[NPA], *srcF[NPF], *srcP[NPP];
+    int offA[NPA], offF[NPF], offP[NPP];
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+        constexpr int PER = MT / NW > 0 ? MT / NW : 1;     // pieces of one direction per wave (NW <= MT)
+        const int k = i / PER, r = (i % PER) * NW + wave;
+        srcA[i] = (const char *)a.dyv[k] + g0 * (MT * 512) + r * 1024 + lane * 16;
+        offA[i] = (k * MT + r) * 1024;
+    }
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+        const int r = i * NW + wave;
+        srcF[i] = (const char *)a.feat + g0 * (NT * 512) + r * 1024 + lane * 16;
+        offF[i] = OFF_F + r * 1024;
+    }
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) {
+        const int e = i * NW + wave, ec = e < NV * PT ? e : 0, k = ec / PT, r = ec % PT;
+        const float *pk = a.ped[0];
+#pragma unroll
+        for (int kk = 1; kk < NV; ++kk) pk = k == kk ? a.ped[kk] : pk;
+        srcP[i] = (const char *)pk + g0 * (PT * 512) + r * 1024 + lane * 16;
+        offP[i] = OFF_P + ec * 1024;
+    }
+    static_assert(NW <= MT, "a wave's dYv pieces belong to whole directions");
+
+    floatx4 acc[TM][TN], accp[TM];
+    float bsum[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        bsum[i] = 0.f; accp[i] = (floatx4)(0.f);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (floatx4)(0.f);
+    }
+    auto issue = [&](int b, int slot) {
+        const unsigned base = (unsigned)(size_t)(lds + slot * BLK);
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) glds_chunks<1>((const float *)(srcA[i] + (size_t)b * (MT * 1024)), __builtin_amdgcn_readfirstlane(base + offA[i]));
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) glds_chunks<1>((const float *)(srcF[i] + (size_t)b * (NT * 1024)), __builtin_amdgcn_readfirstlane(base + offF[i]));
+#pragma unroll
+        for (int i = 0; i < NPP; ++i)
+            if (i * NW + wave < NV * PT) glds_chunks<1>((const float *)(srcP[i] + (size_t)b * (PT * 1024)), __builtin_amdgcn_readfirstlane(base + offP[i]));
+    };
+    const bool has_p = __builtin_amdgcn_readfirstlane(wn) < PT;      // (wave-uniform, and told so: an EXEC-predicated MFMA would run regardless)
+    auto multiply = [&](int slot) {
+        const char *S = lds + slot * BLK, *F = S + OFF_F;
+        FR af[NV][TM];
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int t = wm * TM + i;
+                af[k][i] = frag16<FR>(S + k * MT * 1024 + t * 512, S + k * MT * 1024 + (MT + t) * 512, lane);
+            }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int t = wn * TN + j;
+            const FR bf = frag16<FR>(F + t * 512, F + (NT + t) * 512, lane);
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = mfma_bf(af[k][i], bf, acc[i][j]);
+        }
+        if (has_p) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const char *Pk = S + OFF_P + k * PT * 1024;
+                const FR bp = frag16<FR>(Pk + wn * 512, Pk + (PT + wn) * 512, lane);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) accp[i] = mfma_bf(af[k][i], bp, accp[i]);
+            }
+        }
+        if (wn == 0) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) bsum[i] = dot_ones(af[k][i], bsum[i]);
+        }
+    };
+
+    int fill = 0;
+#pragma unroll
+    for (int b = 0; b < NB - 1; ++b)
+        if (b < nblk) { issue(b, fill); fill = fill + 1 == NB ? 0 : fill + 1; }
+    int cur = 0;
+    for (int b = 0; b < nblk; ++b) {
+        // this wave's pieces of block b have landed: at most the pieces of the y younger blocks it has issued stay outstanding
+        const int y = nblk - 1 - b < NB - 2 ? nblk - 1 - b : NB - 2;
+        __builtin_amdgcn_sched_barrier(0);
+        if (y <= 0) wait_vm<0>();
+        else if (y == 1) wait_vm<MINP>();
+        else wait_vm<2 * MINP>();
+        __builtin_amdgcn_s_barrier();                 // every wave's pieces are in; every wave is done with the slot about to be refilled
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (b + NB - 1 < nblk) { issue(b + NB - 1, fill); fill = fill + 1 == NB ? 0 : fill + 1; }
+        multiply(cur);
+        cur = cur + 1 == NB ? 0 : cur + 1;
+    }
+
+    float *pvf = a.part_vf + (size_t)blockIdx.x * a.stride_vf, *pvd = a.part_vd + (size_t)blockIdx.x * a.stride_vd;
+    const int jn = lane & 15, qr = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int tm = wm * TM + i;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int tn = wn * TN + j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pvf[(size_t)(16 * tm + 4 * qr + r) * 256 + 16 * tn + jn] = acc[i][j][r];
+        }
+        if (has_p) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pvd[(size_t)(16 * tm + 4 * qr + r) * 32 + 16 * wn + jn] = accp[i][r];
+        }
+        if (wn == 0) {
+            float s = bsum[i];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (lane < 16) pvf[(size_t)128 * 256 + 16 * tm + lane] = s;
+        }
+    }
+}
+template <bool BF, int NV, int WN, int NB>
+static int launch_wg16_view(const WgView16Args &va, hipStream_t st) {
+    const size_t ldsb = (size_t)NB * (NV * 8 + 16 + NV * 2) * 1024;
+    VN_HIP(hipFuncSetAttribute((const void *)k_wg16_view<BF, NV, WN, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    hipLaunchKernelGGL((k_wg16_view<BF, NV, WN, NB>), dim3(va.n_chunks), dim3(128 * WN), ldsb, st, va);
+    VN_HIP(hipGetLastError());
+    return VIPNERF_OK;
+}
+// ring depth by direction count: 26 / 36 / 46 / 56 KiB per block -> 104 / 144 / 138 / 112 KiB of LDS, one workgroup per CU
+template <bool BF>
+static int launch_wg16_view_v(const WgView16Args &va, int V, hipStream_t st) {
+    switch (V) {
+    case 0: return launch_wg16_view<BF, 1, VN_WG16_VIEW_WN, 4>(va, st);
+    case 1: return launch_wg16_view<BF, 2, VN_WG16_VIEW_WN, 4>(va, st);
+    case 2: return launch_wg16_view<BF, 3, VN_WG16_VIEW_WN, 3>(va, st);
+    default: return launch_wg16_view<BF, 4, VN_WG16_VIEW_WN, 2>(va, st);
+    }
+}
+
 template <bool BF, int MT, int NT, int WM, int WN, int NB, bool XA = false, bool HY = false>
 static int launch_wg16(const WgArgs &args, int n_desc, int n_chunks, hipStream_t st) {
     if (n_desc == 0) return VIPNERF_OK;
@@ -391,17 +574,29 @@ int launch_wgrad16(size_t P, int V, const float *acts, const ActLayout &al, floa
         WgGroup &g = group(n_single, o + 4 * 256, 1, 16, 256, 1, W, G->g[P_SW], W, 0, G->g[P_SB], 3, 0);
         g.bias_off = (size_t)16 * 256 + 4 - 4 * 256;
     }
-    {   // view layer, feature columns: A = sum over directions of dYv
+    WgView16Args va;
+    if (VN_WG16_VIEW_FUSED) {   // view layer: both column classes in one launch over dYv_0..V (k_wg16_view; no dYvsum)
+        const Plan pv = plan(wgrad_chunks_split(P, WGRAD_SINGLE_SPLIT), cp0 / WGRAD_SINGLE_SPLIT, 256, 1);
+        for (int k = 0; k <= VIPNERF_MAX_SEC; ++k) { va.dyv[k] = bwd + bl.dyv[k <= V ? k : 0]; va.ped[k] = acts + al.ped[k <= V ? k : 0]; }
+        va.feat = acts + al.feat; va.P = (int64_t)P; va.chunk_pts = pv.pts; va.n_chunks = pv.n;
+        va.stride_vf = (size_t)128 * 256 + 128; va.stride_vd = (size_t)128 * 32 + 128;
+        va.part_vf = partial + off;
+        group(pv.n, off, 1, 128, 256, WV, W, G->g[P_VW], W + DVE, 0, G->g[P_VB], 3);
+        off += (size_t)pv.n * va.stride_vf;
+        va.part_vd = partial + off;
+        group(pv.n, off, 1, 128, 32, WV, 32, G->g[P_VW], W + DVE, W, nullptr, 2);
+        off += (size_t)pv.n * va.stride_vd;
+    } else {   // view layer, feature columns: A = sum over directions of dYv
         const size_t o = add(vf, nvf, n_single, 128, 256, bwd + bl.dyvsum, acts + al.feat);
         group(n_single, o, 1, 128, 256, WV, W, G->g[P_VW], W + DVE, 0, G->g[P_VB], 3);
     }
     {   // view layer, direction columns (gamma(dir) in slot order) and the output head: one GEMM per direction, summed in order
         size_t first_d = 0, first_o = 0;
-        for (int k = 0; k <= V; ++k) {
+        for (int k = 0; k <= V && !VN_WG16_VIEW_FUSED; ++k) {
             const size_t o = add(vd, nvd, n_vd, 128, 32, bwd + bl.dyv[k], acts + al.ped[k]);
             if (k == 0) first_d = o;
         }
-        group(n_vd, first_d, 1 + V, 128, 32, WV, 32, G->g[P_VW], W + DVE, W, nullptr, 2);
+        if (!VN_WG16_VIEW_FUSED) group(n_vd, first_d, 1 + V, 128, 32, WV, 32, G->g[P_VW], W + DVE, W, nullptr, 2);
         for (int k = 0; k <= V; ++k) {
             const size_t o = add(oh, noh, n_oh, 16, 128, bwd + bl.dq[k], acts + al.g[k]);
             if (k == 0) first_o = o;
@@ -414,6 +609,7 @@ int launch_wgrad16(size_t P, int V, const float *acts, const ActLayout &al, floa
                                             : launch_all<false>(big, nbig, n_chunks, pe, npe, n_pe, vf, nvf, sg, nsg, n_single, vd, nvd, n_vd, oh, noh, n_oh, st);
     if (rc) return rc;
     ProfScope ps("wgrad_small", st);
+    if (VN_WG16_VIEW_FUSED && (rc = precision == VIPNERF_PREC_BF16 ? launch_wg16_view_v<true>(va, V, st) : launch_wg16_view_v<false>(va, V, st))) return rc;
     return launch_wgrad_reduce(red, ng, st);
 }
 

@@ -229,6 +229,49 @@ def test_rare_config_branches_vs_oracle(dev, case):
         tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{case} grad {k}')
 
 
+@pytest.mark.parametrize('prec', ['fp32', 'bf16', 'fp16', 'fp16x3h'])
+def test_training_step_without_secondary_views_vs_oracle(dev, prec):
+    """V = 0 in TRAINING.  The module contract turns the secondary views on whenever it trains (VipNeRF01.py:84), the C ABI does not require
+    them: a batch that brings an EMPTY `rays_o2` (n, 0, 3) trains with the main view only.  This is what runs the one-direction
+    instantiations of the fused view-layer weight-gradient kernels (k_wgrad_view<1, .>, k_wg16_view<., 1, ., .>) and the data-gradient
+    kernels' V = 0 head -- against the oracle's training render without secondary views, MSE only."""
+    from loss_functions.LossComputerHip01 import LossComputerHip
+    n = 96
+    b = vo.synthetic_batch(n, 811, scene='fern', nf=2)
+    params = vo.init_params(812, scale=1.6)
+    rng = vo.synthetic_rng(n, 64, 128, 813)
+    cfg_o = {'ndc': b['ndc'], 'n_coarse': 64, 'n_fine': 128, 'noise_std': 1.0, 'white_bkgd': False, 'lindisp': False}
+    p = vo.params_to_torch(params, requires_grad=True)
+    ref = vo.render_rays(p, b, cfg_o, rng, train=True, sec_views=False)
+    lref = vo.total_loss(b, ref, [{'name': 'MSE01', 'weight': 1}], 0)
+    lref['TotalLoss'].backward()
+    model, cfg = tp.make_model(dev, b['ndc'], params)
+    cfg['model']['hip_precision'] = prec
+    cfg['losses'] = [{'name': 'MSEHip01', 'weight': 1}]
+    model.train()
+    model.injected_rng = {k: v.to(dev) for k, v in rng.items()}
+    model.injected_z_fine = ref['z_vals_fine'].detach().to(dev)
+    rb = tp.ref_batch(b, dev, 0)
+    rb['rays_o2'] = torch.zeros(n, 0, 3, device=dev)
+    out = model(rb)
+    assert 'visibility2_fine' not in out or out['visibility2_fine'].shape == (n, 0)
+    lh = LossComputerHip(cfg).compute_losses(rb, out)
+    lh['TotalLoss'].backward()
+    rtol, gtol = {'fp32': (1e-4, 2e-3), 'fp16x3h': (2e-4, 1e-2), 'fp16': (5e-3, 1e-1), 'bf16': (4e-2, 3e-1)}[prec]
+    tp.assert_close(out['rgb_fine'], ref['rgb_fine'], rtol=rtol, floor=1e-3 if prec in ('fp16', 'bf16') else 1e-6, what=f'{prec} V = 0 rgb_fine')
+    tp.assert_close(lh['TotalLoss'], lref['TotalLoss'], rtol=4 * rtol, floor=1e-6, what=f'{prec} V = 0 TotalLoss')
+    errs = []
+    for k, t in model.named_parameters():
+        g = p[k].grad
+        if g is None or float(g.abs().max()) == 0.0:              # (the visibility output's weights see no gradient from the MSE alone)
+            assert t.grad is None or float(t.grad.abs().max()) <= 1e-12, f'{prec} V = 0: {k} must have no gradient'
+            continue
+        tp.grad_close(t.grad.cpu().numpy(), g.numpy(), f'{prec} V = 0 grad {k}', l2_tol=gtol)
+        errs.append(float((t.grad.cpu() - g).norm() / g.norm().clamp_min(1e-30)))
+    errs.sort()
+    print(f'{prec} V = 0: gradient rel. L2 median {errs[len(errs) // 2]:.2e}, worst {errs[-1]:.2e}')
+
+
 @pytest.mark.parametrize('n,scene,nf', [(37, 'fern', 2), (1, 'fern', 2), (75, 'dtu', 3), (130, 'realestate', 4)])
 def test_partial_tile_step_vs_oracle(dev, n, scene, nf):
     """Ray counts whose points do NOT fill the MLP kernels' 128-point tiles (37 rays: 18.5 coarse tiles; 1 ray: half a tile; 75 / 130 rays with 2 / 3

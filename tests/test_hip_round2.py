@@ -351,14 +351,16 @@ ARITH16 = {'fp16': (5e-3, 5e-4, 5e-2, 4e-3), 'bf16': (4e-2, 5e-3, 1.5e-1, 1.5e-2
 
 
 @pytest.mark.parametrize('prec', list(ARITH16))
-@pytest.mark.parametrize('scene', ['fern', 'realestate', 'dtu'])
+@pytest.mark.parametrize('scene', ['fern', 'realestate', 'dtu', 'fern_nf4'])
 def test_16bit_train_step_vs_oracle_1024_rays(dev, prec, scene):
     """The single-MFMA 16-bit modes against the CPU oracle at 25x the goldens' size -- fern (NDC, V = 1), realestate (NDC, V = 2, 512
     sparse-depth rows) and BASELINE configs[4]'s DTU geometry (non-NDC, 3 views: V = 2): all outputs, the losses, every parameter
-    gradient, at the accuracy class of one 16-bit rounding per operand."""
-    nf, n_sparse = {'fern': (2, 0), 'realestate': (3, 512), 'dtu': (3, 0)}[scene]
+    gradient, at the accuracy class of one 16-bit rounding per operand.  fern_nf4: four views (V = 3, the reference's demo configs) -- the
+    four-direction instantiation of the fused view-layer weight-gradient kernel (k_wg16_view<., 4, ., 2>: a ring of two 56 KiB blocks) at a
+    size where its chunks are hundreds of blocks long."""
+    geom, nf, n_sparse = {'fern': ('fern', 2, 0), 'realestate': ('realestate', 3, 512), 'dtu': ('dtu', 3, 0), 'fern_nf4': ('fern', 4, 0)}[scene]
     n = 1024 - n_sparse
-    b = vo.synthetic_batch(n, 411, scene=scene, nf=nf, n_sparse=n_sparse)
+    b = vo.synthetic_batch(n, 411, scene=geom, nf=nf, n_sparse=n_sparse)
     params = vo.init_params(412, scale=1.6)
     rng = vo.synthetic_rng(1024, 64, 128, 413)
     cfg_o = {'ndc': b['ndc'], 'n_coarse': 64, 'n_fine': 128, 'noise_std': 1.0}

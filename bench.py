@@ -12,7 +12,7 @@ fine 8x256 MLP, fp32): forward -> fused losses (MSE 1, Visibility 0.1, Visibilit
 the random numbers of a step are drawn on the device (Philox) inside it.  Rank 0 prints ONE JSON line.
 
 `value` / `dtype` are the EXACT-fp32 MFMA arithmetic (v_mfma_f32_16x16x4_f32 / 32x32x2_f32), as configs[1] says; the faster
-arithmetics (`--also`, default fp16x3, fp16x3h, fp16, bf16) are timed by the same procedure (W warm-up + K timed steps each) and reported
+arithmetics (`--also`: bf16 and fp16x3 by default; fp16x3h, fp16 on request) are timed by the same procedure (W warm-up + K timed steps each) and reported
 beside it (`value_fp16x3`, ...), each with its own `roofline` block (MFMA-bound path, algorithmic 630,272 MAC/point
 against the dense MFMA peak of the operand dtype).  At N = 1 the line also carries `configs4_dtu`: BASELINE configs[4]'s per-GPU
 shard (DTU geometry, non-NDC, 3 views = 2 secondary views, 131,072 / 8 = 16,384 rays per iteration, bf16 / fp16 mixed precision)
@@ -424,7 +424,7 @@ def main():
     ap.add_argument('--workload', default='fern', choices=list(SCENES), help='scene geometry of `value` (BASELINE configs[1] / [3]: fern; '
                     'configs[2]: realestate; configs[4]: dtu)')
     ap.add_argument('--precision', default='fp32', choices=list(ARITH), help='arithmetic of `value` (BASELINE configs[1] says fp32)')
-    ap.add_argument('--also', default='bf16', help='comma list of further arithmetics timed the same way ("" = none, "all")')
+    ap.add_argument('--also', default='bf16,fp16x3', help='comma list of further arithmetics timed the same way ("" = none, "all"; default: BASELINE configs[4]\'s bf16 and the fp32-grade 3 x fp16 mode)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-rays', type=int, default=4096)
     ap.add_argument('--no-render', action='store_true')

@@ -436,6 +436,91 @@ def gen_f8():
     print('f8_reference_state_dict_manifest.json', len(man['keys']), 'keys')
 
 
+# ------------------------------------------------------------------------------------------------ F9
+def gen_f9(n=128, first_iter=29996, iters=8, seed=900):
+    """A K-step TRAJECTORY of the reference's training loop: the reference's own `Trainer.train_one_iter` (Trainer01.py:61-107: next batch ->
+    zero_grad -> forward -> compute_losses -> TotalLoss.backward -> optimizer.step) driven the way `Trainer.train` drives it (:292-298:
+    `lr_decayer.get_updated_learning_rate(iter_num)` written into every param group, then the iteration), with the reference's
+    NeRFLearningRateDecayer (lr_decayers/NeRFLearningRateDecayer01.py:19-23), torch.optim.Adam as Trainer01.py:519-520 builds it, and the
+    LossComputer's iteration-dependent weights (LossComputer01.py:46-60) -- the window 29996..30003 is chosen so that the visibility-prior
+    weight switches 0 -> 0.001 inside it.  A fresh batch of `n` fern rays per iteration; the CPU generator's draws and the fine depths of
+    every iteration are recorded (teacher forcing: a one-ulp CDF tie must not turn the comparison of an optimizer trajectory into one of
+    index flips).  Stored: per-iteration lr, loss values, min |gradient| per sampled element (which parameters' Adam updates are
+    determined above rounding level), digests of the parameters after every iteration and the small tensors after the last.
+
+    Trainer01 imports tensorboard / skimage / simplejson / deepdiff at module level for its file IO; they are absent here and none of them
+    is touched by train_one_iter, so empty modules stand in for the import only (as gen_f6 / gen_f7 do for skimage)."""
+    import types
+    for m, attrs in (('simplejson', ()), ('skimage', ()), ('skimage.io', ()), ('skimage.transform', ()), ('deepdiff', ('DeepDiff',)),
+                     ('torch.utils.tensorboard', ('SummaryWriter',))):
+        if m not in sys.modules:
+            try:
+                __import__(m)
+            except ImportError:
+                mod = types.ModuleType(m)
+                for a in attrs:
+                    setattr(mod, a, None)
+                sys.modules[m] = mod
+    from Trainer01 import Trainer                                                   # (reference)
+    from lr_decayers.LearningRateDecayerFactory import get_lr_decayer               # (reference)
+    cfg = ref_configs(True, netchunk=8192, chunk=4096)
+    cfg['optimizer'] = {'lr_decayer_name': 'NeRFLearningRateDecayer01', 'lr_initial': 0.0005, 'lr_decay': 250, 'beta1': 0.9, 'beta2': 0.999}
+    params = vo.init_params(seed + 1, scale=1.6)
+    model = ref_model(cfg, params).train()
+    batches = [vo.synthetic_batch(n, seed + 10 + i, scene='fern', nf=2) for i in range(iters)]
+
+    class Loader:                                                                   # what train_one_iter asks of the data loader: the next batch dict
+        def get_next_batch(self, iter_num):
+            return ref_batch(batches[iter_num - first_iter], iter_num)
+
+    out_log, rng_log = [], []
+    real_forward = model.forward
+
+    def forward(input_batch, *a, **k):
+        rlog = []
+        with record_rng(rlog):
+            o = real_forward(input_batch, *a, **k)
+        rng_log.append(split_rng(rlog, n, 64, 128))
+        out_log.append({kk: o[kk].detach().clone() for kk in ('z_vals_fine', 'rgb_fine', 'rgb_coarse')})
+        return o
+
+    model.forward = forward
+    tr = Trainer.__new__(Trainer)                                                   # no output directories, no tensorboard: only what train_one_iter reads
+    tr.configs, tr.model, tr.train_data_loader = cfg, model, Loader()
+    tr.loss_computer = LossComputer(cfg)
+    tr.optimizer = torch.optim.Adam(list(model.parameters()), lr=cfg['optimizer']['lr_initial'],
+                                    betas=(cfg['optimizer']['beta1'], cfg['optimizer']['beta2']))
+    tr.lr_decayer = get_lr_decayer(cfg)
+    d = {}
+    names = [k for k, _ in model.named_parameters()]
+    gmin = {k: None for k in names}
+    torch.manual_seed(seed)
+    for i in range(iters):
+        iter_num = first_iter + i
+        iter_lr = tr.lr_decayer.get_updated_learning_rate(iter_num)                 # Trainer01.py:293-295
+        for param_group in tr.optimizer.param_groups:
+            param_group['lr'] = iter_lr
+        losses = tr.train_one_iter(iter_num)
+        d[f'it{i}_lr'] = np.float64(iter_lr)
+        for k, v in losses.items():
+            d[f'it{i}_loss_{k}'] = np.float64(v)
+        for k, v in rng_log[i].items():
+            d[f'it{i}_rng_{k}'] = v
+        d[f'it{i}_z_vals_fine'] = out_log[i]['z_vals_fine']
+        d[f'it{i}_rgb_fine'] = out_log[i]['rgb_fine']
+        for k, p in model.named_parameters():
+            g = digest(p.grad)[2:]
+            gmin[k] = np.abs(g) if gmin[k] is None else np.minimum(gmin[k], np.abs(g))
+            d[f'it{i}_pdig_{k}'] = digest(p)[:2]                                     # [sum, l2] of the parameter after this iteration's step
+    for k, p in model.named_parameters():
+        d['gmin_' + k] = gmin[k]
+        d['adig_' + k] = digest(p)
+        if p.numel() <= 4096:
+            d['after_' + k] = p.detach().clone()
+    npz('f9_trajectory_fern', n=n, first_iter=first_iter, iters=iters, seed=seed, seed_params=seed + 1, scale_params=1.6,
+        loss_names=np.array(sorted(k for k in losses)), **d)
+
+
 # ------------------------------------------------------------------------------------------------ F7
 def gen_f7():
     """Visibility-prior generator of the reference (plane-sweep volume) on a 40x56 two-camera toy scene."""
@@ -485,3 +570,4 @@ if __name__ == '__main__':
     gen_f6b()
     gen_f7()
     gen_f8()
+    gen_f9()

@@ -336,6 +336,8 @@ def render_rays(p: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], cfg:
         z_f, inds, samples = fine_depths(z_c, comp_c['weights'], cfg['n_fine'], u)
         ret['sample_inds'] = inds
         ret['z_samples'] = samples
+        if rng is not None and rng.get('z_fine') is not None:
+            z_f = rng['z_fine']                       # teacher forcing (tests of multi-step trajectories): the given merged fine depths
         level_pass('fine', z_f, rng['noise_fine'] if use_noise else None)
     return ret
 

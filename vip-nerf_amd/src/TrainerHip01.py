@@ -135,9 +135,13 @@ class TrainerHip:
             # millions of 0-dim device tensors alive nor loses its whole log if it dies
             if not pending:
                 return
-            keys = list(pending[0][0].keys())
-            table = torch.stack([torch.stack([h[0][k].float() for k in keys]) for h in pending]).cpu().numpy()
-            history.extend(dict(zip(keys, map(float, row)), **h[1]) for row, h in zip(table, pending))
+            rows = [h for h in pending if h[0]]                  # (loss-less rows: a skipped iteration on a validation boundary)
+            values = {}
+            if rows:
+                keys = list(rows[0][0].keys())
+                table = torch.stack([torch.stack([h[0][k].float() for k in keys]) for h in rows]).cpu().numpy()
+                values = {id(h[1]): dict(zip(keys, map(float, row))) for row, h in zip(table, rows)}
+            history.extend(dict(values.get(id(h[1]), {}), **h[1]) for h in pending)
             pending.clear()
 
         flush_every = int(self.configs.get('log_flush_interval', 256))
@@ -147,12 +151,14 @@ class TrainerHip:
             for g in self.optimizer.param_groups:
                 g['lr'] = lr
             losses = self.train_one_iter(iter_num)
-            entry = {'lr': lr}
-            if losses:                                       # a skipped iteration (empty trimmed shard) logs nothing
-                pending.append((losses, entry))
+            # every row names its iteration: after a skipped iteration the row position is no longer the iteration number
+            entry = {'iter': iter_num, 'lr': lr}
+            validate = bool(val_int) and (iter_num + 1) % val_int == 0
+            if losses or validate:                           # a skipped iteration (empty trimmed shard) logs no losses; one that falls on a
+                pending.append((losses, entry))              # validation boundary still gets its (loss-less) row, so that the psnr is not lost
             if log_every and losses and self.rank == 0 and (iter_num + 1) % log_every == 0:
                 print(f"iter {iter_num + 1}: " + ' '.join(f'{k} {float(v):.5f}' for k, v in losses.items()) + f' lr {lr:.3e}', flush=True)
-            if val_int and (iter_num + 1) % val_int == 0:
+            if validate:
                 entry['validation_psnr'] = float(numpy.mean([v.get('psnr', float('nan')) for v in self.run_validation().values()]))
             if save_int and (iter_num + 1) % save_int == 0:
                 self.save_model(iter_num + 1)

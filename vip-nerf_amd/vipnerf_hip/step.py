@@ -303,29 +303,32 @@ class FusedTrainStep:
         return {'TotalLoss': B.total, 'loss_values': B.loss_values, 'loss_slots': present, 'two_levels': two}
 
 
-_NAMED_M = {}
+_NAMED_IDX = {}
 
 
 def named_losses(res: dict) -> Dict[str, torch.Tensor]:
-    """{loss name: value} like LossComputer.compute_losses reports them (coarse + fine per loss), from a FusedTrainStep result.  Two
-    launches whatever the number of losses: one (names x 8) selection matrix times the step's loss vector (a fresh tensor -- the step's
-    own buffers are overwritten by the next call), one copy of TotalLoss; the per-name values are views of the product."""
+    """{loss name: value} like LossComputer.compute_losses reports them (coarse + fine per loss), from a FusedTrainStep result.  Three
+    launches whatever the number of losses (two index_selects into the step's loss vector and their sum: fresh tensors -- the step's own
+    buffers are overwritten by the next call) and one copy of TotalLoss; the per-name values are views of the sum.  Selection by INDEX, not
+    by a 0 / 1 matrix product: one diverged loss (NaN / Inf in its slot) shows up under its own name only, as in the reference's
+    LossComputer, instead of turning every logged name into NaN through 0 * NaN."""
     lv = res['loss_values']
     names = list(res['loss_slots'])
     key = (tuple((n, res['loss_slots'][n]) for n in names), bool(res['two_levels']), lv.device)
-    M = _NAMED_M.get(key)
-    if M is None:
-        m = torch.zeros(max(len(names), 1), 8)
-        for i, n in enumerate(names):
+    idx = _NAMED_IDX.get(key)
+    if idx is None:
+        i0, i1 = [], []
+        for n in names:
             slots = res['loss_slots'][n]
             if slots is None:
-                m[i, 7] = 1.0
+                i0.append(7); i1.append(8)               # a loss that reported nothing: slot 7 (written 0 by the loss kernel); 8 = the appended zero
             else:
-                m[i, slots[0]] = 1.0
-                if res['two_levels'] and slots[1] != 7:
-                    m[i, slots[1]] = 1.0
-        M = _NAMED_M[key] = m.to(lv.device)
-    v = torch.mv(M, lv)
+                i0.append(slots[0])
+                i1.append(slots[1] if (res['two_levels'] and slots[1] != 7) else 8)
+        idx = _NAMED_IDX[key] = (torch.tensor(i0 or [8], dtype=torch.long, device=lv.device), torch.tensor(i1 or [8], dtype=torch.long, device=lv.device),
+                                 torch.zeros(1, device=lv.device))
+    ext = torch.cat([lv, idx[2]])                        # [8 loss slots, 0.0]
+    v = ext.index_select(0, idx[0]) + ext.index_select(0, idx[1])
     out = {n: v[i] for i, n in enumerate(names)}
     out['TotalLoss'] = res['TotalLoss'].clone()[0]
     return out

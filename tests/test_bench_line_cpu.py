@@ -27,7 +27,8 @@ def _canned(n_gpus):
         full.pop('cpu_baseline')
         full.pop('sizes')
         full.update({'ranks_reduced': n_gpus, 'allreduce_ms_per_step': 0.1234, 'allreduce_calls_per_step': 1.0, 'rank_ms_per_step_min': 29.1,
-                     'rank_ms_per_step_max': 29.4})
+                     'rank_ms_per_step_max': 29.4, 'grad_allreduce_vs_whole_batch': 2.5e-6, 'ranks_param_identical': True,
+                     'sharding_check': {'rel_l2': 2.5e-6, 'ranks': n_gpus, 'passed': True}})
     full['build_info_sha16'] = '0123456789abcdef'
     full['csrc_sha16'] = 'fedcba9876543210'
     return full
@@ -60,6 +61,7 @@ def test_compact_line_is_small_and_parses(n_gpus):
     else:
         assert 'cpu_baseline' not in back
         assert back['allreduce_ms_per_step'] == 0.1234 and back['rank_ms_per_step_max'] == 29.4 and back['ranks_reduced'] == 8
+        assert back['grad_allreduce_vs_whole_batch'] == 2.5e-6 and back['ranks_param_identical'] is True and 'sharding_check' not in back
     assert back['ms_per_step_bf16'] == full['ms_per_step_bf16'] and back['configs2_fp32_ms'] == full['configs2_realestate']['fp32']['ms_per_step']
     assert back['configs4_bf16_ms'] == full['configs4_dtu']['bf16']['ms_per_step'] and back['render_ms_per_frame'] == full['render_ms_per_frame']
     # every value outside config / roofline / cpu_baseline is a scalar
@@ -76,3 +78,23 @@ def test_compact_line_sheds_extras_rather_than_growing():
     assert c.get('truncated') is True and len(json.dumps(c, separators=(',', ':'))) < bench.COMPACT_LIMIT
     for k in CONTRACT + ('roofline', 'cpu_baseline'):
         assert k in c
+
+
+def test_compact_line_falls_back_to_the_bare_contract():
+    """after shedding the extras the line is measured AGAIN; members that are kept unconditionally (config, roofline, cpu_baseline)
+    and grew past the limit are cut to bounded forms instead of printing a line the driver cannot parse."""
+    import bench
+    for n_gpus in (1, 8):
+        full = _canned(n_gpus)
+        full['config']['workload'] = full['config']['workload'] + ' x' * 3000
+        full['config']['parallelism'] = 'p' * 2000
+        c = bench.compact_line(full)
+        line = json.dumps(c, separators=(',', ':'))
+        assert len(line) <= bench.COMPACT_LIMIT and c['truncated'] is True and json.loads(line) == c
+        for k in CONTRACT + ('roofline',):
+            assert k in c
+        assert c['value'] == full['value'] and c['roofline']['frac'] == round(full['roofline']['frac'], 4) and c['roofline']['bound'] == 'mfma'
+        if n_gpus == 8:
+            assert c['grad_allreduce_vs_whole_batch'] == 2.5e-6 and c['ranks_param_identical'] is True and c['ranks_reduced'] == 8
+        else:
+            assert c['cpu_baseline']['value'] == full['cpu_baseline']['value']

@@ -219,3 +219,54 @@ def test_short_batches_trim_per_row_class_on_the_host():
     assert ids == [[0, 1, 2, 7, 8], [3, 4, 5, 9, 10]]
     sh = vdist.shard_batch(dict(batch, target=torch.arange(12.)), 1, 2, uneven='trim')
     assert sh['target'].tolist() == [3., 4., 5., 9., 10.] and sh['row_class_counts'] == (3, 2) and sh['rng_ray_ids'].tolist() == ids[1]
+
+
+# ------------------------------------------------------------------------------------------------ the scaling line's self-check
+def worker_verify(rank, world, port, ret):
+    """What bench.py --gpus N runs before / after its timed region, under gloo with the oracle as the model: vdist.verify_sharded_gradient
+    (shard gradients all-reduced vs the whole global batch's gradient computed on every rank) and vdist.params_identical."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2 if world <= 2 else 1)
+    from oracle import vipnerf_oracle as vo
+    from vipnerf_hip import dist as vdist
+    r, w, _ = vdist.init_from_env(backend='gloo')
+    model = OracleModule(vo.init_params(5 + rank, scale=1.6))
+    vdist.broadcast_parameters(model, src=0)
+    n_nerf, n_sd = world, world                                   # one nerf row + one sparse-depth row per rank
+    batch = vo.synthetic_batch(n_nerf, 3, scene='realestate', nf=3, n_sparse=n_sd)
+    rng = vo.synthetic_rng(n_nerf + n_sd, 64, 128, 4)             # a row's draws: by its GLOBAL index, whatever batch it arrives in
+
+    def grad_fn(b):
+        rows = b['rng_ray_ids'] if 'rng_ray_ids' in b else torch.arange(b['rays_o'].shape[0])
+        for p in model.parameters():
+            p.grad = None
+        out = vo.render_rays(model.pdict(), b, CFG, {k: v[rows] for k, v in rng.items()}, train=True, sec_views=True)
+        vo.total_loss(b, out, LOSSES8, 40000)['TotalLoss'].backward()
+        return torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+
+    res = vdist.verify_sharded_gradient(grad_fn, batch, r, w)
+    same0 = vdist.params_identical(model.parameters())
+    # a broken reduction must be caught: this rank's shard gradient scaled by (1 + rank) before the collective
+    bad = vdist.verify_sharded_gradient(lambda b: grad_fn(b) * (1.0 + (r if 'rng_ray_ids' in b else 0)), batch, r, w)
+    # ranks that drifted apart must be caught: one element of one rank's parameters moved by one ulp
+    if r == w - 1:
+        with torch.no_grad():
+            p = list(model.parameters())[3]
+            p.view(-1)[7] = torch.nextafter(p.view(-1)[7], torch.tensor(10.0))
+    same1 = vdist.params_identical(model.parameters())
+    ret[rank] = (res, same0, bad, same1)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_sharding_self_check_under_gloo(world):
+    port = 25500 + (os.getpid() % 2000) + world
+    ret = mp.Manager().dict()
+    mp.spawn(worker_verify, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        res, same0, bad, same1 = ret[r]
+        assert res['ranks'] == world and res['rel_l2'] == ret[0][0]['rel_l2'], 'every rank must hold the same verdict'
+        assert res['rel_l2'] <= 2e-5 and res['rel_l2_rank'] <= res['rel_l2'], res
+        assert same0 == {'identical': True, 'max_bits_diff': 0, 'max_sum_diff': 0.0}
+        assert bad['rel_l2'] > 0.1, bad                                     # the scaled shards are not the whole batch's gradient
+        assert same1['identical'] is False and same1['max_bits_diff'] >= 1, same1

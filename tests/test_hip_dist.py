@@ -157,8 +157,11 @@ def test_bench_self_spawns_eight_ranks_strong_scaling():
     # attribution of the collective and of a slow rank: present at N > 1
     assert res['allreduce_ms_per_step'] > 0 and res['allreduce_calls_per_step'] == 1.0
     assert 0 < res['rank_ms_per_step_min'] <= res['rank_ms_per_step_max'] <= res['ms_per_step'] * 1.001
-    full = json.load(open(os.path.join(ROOT, 'bench_full.json')))          # the nested blocks live in the full report
+    full = json.load(open(os.path.join(ROOT, res['full_report'])))          # the nested blocks live in the full report (the line names the file)
     assert full['value'] == res['value'] and full['n_gpus'] == 8
+    # the scaling line's own parity evidence: reduced shard gradients == whole-batch gradient, identical parameters after K steps
+    assert 0 <= res['grad_allreduce_vs_whole_batch'] <= 1e-5 and res['ranks_param_identical'] is True
+    assert full['sharding_check']['ranks'] == 8 and full['sharding_check']['global_rows'] == 8192 and full['sharding_check']['passed'] is True
     assert full['render']['fp32']['row_strips'] == 8 and res['render_ms_per_frame'] > 0
     assert 'VN_EXP=unset' in full['build_info']
 
@@ -181,7 +184,9 @@ def test_bench_two_ranks_on_one_gpu():
     res = json.loads(lines[0])
     assert res['n_gpus'] == 2 and res['scaling'] == 'weak' and res['value'] > 0 and res['config']['global_rays'] == 2048
     # N > 1 lines carry the configs[4] arithmetic beside `value`, and the configs[4] block (every rank its own DTU shard)
-    full = json.load(open(os.path.join(ROOT, 'bench_full.json')))          # the nested blocks live in the full report, scalars of them in the line
+    full = json.load(open(os.path.join(ROOT, res['full_report'])))          # the nested blocks live in the full report, scalars of them in the line
+    assert 0 <= res['grad_allreduce_vs_whole_batch'] <= 1e-5 and res['ranks_param_identical'] is True and full['sharding_check']['ranks'] == 2
+    assert len(full['runs_ms_per_step']) == 3 and sorted(full['runs_ms_per_step'])[1] == res['ms_per_step']      # the line reports the median run
     assert res['value_bf16'] > 0 and full['configs4_dtu']['n_gpus'] == 2 and full['configs4_dtu']['global_rays'] == 1024
     assert full['configs4_dtu']['bf16']['value'] > 0 and full['configs4_dtu']['bf16']['roofline']['bound'] == 'mfma'
     assert res['configs4_bf16_ms'] == full['configs4_dtu']['bf16']['ms_per_step']
@@ -370,6 +375,8 @@ def test_bench_force_dist_single_rank_rccl():
     assert len(lines) == 1, r.stdout[-2000:]
     res = json.loads(lines[0])
     assert res['n_gpus'] == 1 and res['value'] > 0 and res['config'].get('collectives') == 'forced (nccl, world_size 1)'
+    # the self-check of the sharded step runs on this path too (one rank: the shard is the batch, the collective is RCCL's): fields present, run passed
+    assert res['grad_allreduce_vs_whole_batch'] == 0.0 and res['ranks_param_identical'] is True
 
 
 def test_uneven_row_classes_trim_instead_of_raising():

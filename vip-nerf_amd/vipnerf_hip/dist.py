@@ -248,3 +248,46 @@ def shard_batch(batch: dict, rank: int, world: int, uneven: str = 'raise') -> di
         out['row_class_counts'] = tuple(int(c) // world for c in batch['row_class_counts'])
     out['rng_ray_ids'] = ids if 'rng_ray_ids' not in batch else batch['rng_ray_ids'][ids.to(batch['rng_ray_ids'].device)]
     return out
+
+
+# ------------------------------------------------------------------------------------------------ self-verification of a sharded step
+def verify_sharded_gradient(grad_fn, global_batch: dict, rank: int, world: int) -> dict:
+    """Parity evidence for a multi-rank step, computed by the ranks themselves (bench.py --gpus N, tests/test_hip_multigpu.py): every rank
+    takes ITS shard of `global_batch` (shard_batch: row-class aware, Philox streams keyed by the rows' global indices), all-reduces the
+    shard gradients with the step's own collective (all_reduce_mean_flat), and ALSO computes the gradient of the WHOLE global batch
+    locally; the two must agree -- what torch.nn.DataParallel's gather + one backward gives the reference for free (reference
+    src/Trainer01.py:517; the losses are means over their row classes, loss_functions/MSE01.py:55-59).
+
+    grad_fn(batch) -> flat fp32 gradient (any device) of the batch's TotalLoss at the current weights, NO collective inside; it must draw
+    the same random numbers for a row whatever batch the row arrives in.  -> {'rel_l2': max over ranks of |reduced - whole| / |whole|,
+    'rel_l2_rank': this rank's, 'whole_norm': |whole|, 'ranks': ranks that took part}.  World size 1 (forced collectives): the shard is
+    the batch, the collective is RCCL's single-rank all-reduce."""
+    shard = shard_batch(global_batch, rank, world)
+    g = grad_fn(shard).detach().clone()
+    all_reduce_mean_flat(g)
+    whole = grad_fn(global_batch).detach()
+    den = whole.double().norm()
+    rel = ((g.double() - whole.double()).norm() / den.clamp_min(1e-300)).reshape(1)
+    worst, ranks = rel.clone(), torch.ones(1, dtype=torch.float64, device=rel.device)
+    if _active():
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ranks, op=dist.ReduceOp.SUM)
+    return {'rel_l2': float(worst.item()), 'rel_l2_rank': float(rel.item()), 'whole_norm': float(den.item()), 'ranks': int(ranks.item())}
+
+
+def params_identical(params: Iterable[torch.Tensor]) -> dict:
+    """Are the ranks' parameters the same BITS (identical weights, identical reduced gradient, identical Adam step on every rank)?  Two
+    checksums per rank -- the sum of the parameters' bit patterns as integers (exact, order independent) and their fp64 sum -- are compared
+    with rank 0's (broadcast) and the differences reduced with MAX.  -> {'identical': bool, 'max_bits_diff': int, 'max_sum_diff': float}."""
+    ps = [p.detach() for p in params]
+    bits = torch.stack([p.contiguous().view(torch.int32).to(torch.int64).sum() for p in ps]).sum().reshape(1)
+    fsum = torch.stack([p.double().sum() for p in ps]).sum().reshape(1)
+    d_bits, d_sum = torch.zeros(1, dtype=torch.float64, device=bits.device), torch.zeros(1, dtype=torch.float64, device=bits.device)
+    if _active():
+        b0, f0 = bits.clone(), fsum.clone()
+        dist.broadcast(b0, src=0)
+        dist.broadcast(f0, src=0)
+        d_bits, d_sum = (bits - b0).abs().double(), (fsum - f0).abs()
+        dist.all_reduce(d_bits, op=dist.ReduceOp.MAX)
+        dist.all_reduce(d_sum, op=dist.ReduceOp.MAX)
+    return {'identical': bool(d_bits.item() == 0 and d_sum.item() == 0), 'max_bits_diff': int(d_bits.item()), 'max_sum_diff': float(d_sum.item())}

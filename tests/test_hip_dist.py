@@ -376,7 +376,7 @@ def test_bench_force_dist_single_rank_rccl():
     res = json.loads(lines[0])
     assert res['n_gpus'] == 1 and res['value'] > 0 and res['config'].get('collectives') == 'forced (nccl, world_size 1)'
     # the self-check of the sharded step runs on this path too (one rank: the shard is the batch, the collective is RCCL's): fields present, run passed
-    assert res['grad_allreduce_vs_whole_batch'] == 0.0 and res['ranks_param_identical'] is True
+    assert 0 <= res['grad_allreduce_vs_whole_batch'] <= 1e-7 and res['ranks_param_identical'] is True
 
 
 def test_uneven_row_classes_trim_instead_of_raising():

@@ -20,7 +20,7 @@ import test_hip_parity as tp  # noqa: E402
 PRECS = ['fp16x3']
 MODES = ['fp16x3', 'fp16x3h']
 # relative-L2 tolerance on parameter gradients: fp32 grade (the same bar as the fp32 path)
-GRAD_TOL = {'fp16x3': 2e-3, 'fp16x3h': 2e-3, 'fp32': 2e-3}
+GRAD_TOL = {'fp16x3': None, 'fp16x3h': None, 'fp32': None}      # None: tp.grad_close's fp32-grade default (1e-4; 5e-4 at >= 4096 rows)
 
 
 @pytest.fixture(scope='module')

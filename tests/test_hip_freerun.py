@@ -55,4 +55,9 @@ def test_free_running_index_agreement_and_rgb_error_1024_rays(scene, nf, train):
           f'rays beyond 1e-4: {beyond:.4f}' + ('' if train else f'; u = 1 column: {float(same[:, -1].float().mean()):.3f} equal'))
     assert agree >= 0.99995, f'{scene}: index agreement {agree:.6f}'          # measured: 0 of 131,072 differ in training, 1 of 130,048 in eval (fern)
     assert worst <= 1, 'a differing index is a neighbouring bin (a cdf value within rounding of the draw)'
+    u = rng['u'] if train else torch.linspace(0., 1., steps=128).expand(N, 128)
+    differ = ~same if train else torch.cat([~same[:, :-1], torch.zeros(N, 1, dtype=torch.bool)], 1)
+    gaps = tp.cdf_tie_gaps(ref['weights_coarse'], u, torch.where(differ, inds, ref_inds), ref_inds)
+    print(f'  differing indices: distance of u to the separating CDF entry in ulp of u: {np.round(gaps, 2).tolist()} (bound {tp.TIE_ULP})')
+    assert (gaps <= tp.TIE_ULP).all(), f'{scene}: an index differs where the draw is NOT on a CDF value: {gaps}'
     assert beyond == 0.0 and float(e.max()) <= 1e-4, (beyond, float(e.max()))   # north_star: rendered RGB within 1e-4 (measured max 5.9e-5 training, 3.6e-7 eval)

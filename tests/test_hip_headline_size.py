@@ -77,7 +77,7 @@ def test_fp32_train_step_vs_oracle_4096_rows(scene, nf, n_sparse):
         assert float(lref['SparseDepthMSE01']) > 0
     worst = 0.0
     for k, t in model.named_parameters():
-        tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{scene} grad {k}', l2_tol=2e-3)
+        tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{scene} grad {k}', rows=4096)
         worst = max(worst, float((t.grad.cpu() - p[k].grad).norm() / p[k].grad.norm()))
     print(f'fp32 {scene} {rows} rows ({n_sparse} sparse-depth; depth statistics at most {worst_depth:.2f} x their per-ray first-order bound): rgb_fine max abs error {float(e):.2e}; worst relative L2 gradient error over 48 tensors {worst:.2e}')
 
@@ -107,4 +107,9 @@ def test_free_running_index_agreement_4096_rays():
           f'rgb_fine error median {q[0]:.1e}, p99.9 {q[1]:.1e}, max {float(e.max()):.2e}')
     assert same.numel() == 4096 * 128
     assert agree >= 0.99995 and worst <= 1
+    # ... and every differing index is a TIE: the draw sits on the oracle's CDF entry between the two answers, within the rounding the CDF
+    # inherits from the coarse pass (not only "few differ")
+    gaps = tp.cdf_tie_gaps(ref['weights_coarse'], rng['u'], inds, ref_inds)
+    print(f'  differing indices: distance of u to the separating CDF entry, in ulp of u: {np.round(gaps, 2).tolist()} (bound {tp.TIE_ULP})')
+    assert (gaps <= tp.TIE_ULP).all(), gaps
     assert float(e.max()) <= 1e-4

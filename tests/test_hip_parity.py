@@ -75,16 +75,49 @@ KEYMAP = {'rgb': 'rgb', 'acc': 'acc', 'depth': 'depth', 'depth_var': 'depth_var'
           'raw_visibility': 'raw_vis', 'raw_visibility2': 'raw_vis2'}
 
 
-def grad_close(a, ref, what, scale=0.0, l2_tol=2e-3):
-    """Gradients are sums over ~1e4..1e6 fp32 products in a different order, and a ReLU whose pre-activation sits
-    within rounding of 0 may fall on the other side in the two implementations (a single point's contribution then
-    appears/disappears).  So: relative L2 error <= 2e-3 and no element off by more than 2 % of the largest."""
+TIE_ULP = 4.0          # a differing free-running index must have its draw within this many fp32 ulp of the separating CDF entry
+GRAD_LOG = []          # (what, rel L2, max err / max|g|, bound) of every grad_close call of the session; VIPNERF_GRAD_LOG=<file> appends them there
+
+
+def grad_close(a, ref, what, scale=0.0, l2_tol=None, rows=0):
+    """Parameter gradients against the oracle's / the reference's: relative L2 error and largest element error over the largest element.
+
+    Bounds (what is measured, not what is comfortable).  fp32 / fp16x3 arithmetic, default: 1e-4 on the reference's
+    goldens and the small oracle cases (measured <= 4e-5), 5e-4 at >= 4096 rows (measured <= 2.8e-4: sums over ~1e6 fp32 products in
+    another order, and a ReLU whose pre-activation sits within rounding of 0 falls on either side -- one point's contribution then appears
+    or disappears).  The 16-bit modes pass their own class explicitly.  The element bound is 10 x the L2 bound."""
+    if l2_tol is None:
+        l2_tol = 5e-4 if rows >= 4096 else 1e-4
     a, ref = np.asarray(a, np.float64).reshape(-1), np.asarray(ref, np.float64).reshape(-1)
     assert np.isfinite(a).all(), what
     nrm = max(np.linalg.norm(ref), scale * np.sqrt(ref.size), 1e-30)
     l2 = np.linalg.norm(a - ref) / nrm
     mx = np.abs(a - ref).max() / max(np.abs(ref).max(), scale, 1e-30)
-    assert l2 <= l2_tol and mx <= 10 * l2_tol, f'{what}: rel L2 err {l2:.3e}, max err / max|g| {mx:.3e}'
+    GRAD_LOG.append((what, l2, mx, l2_tol))
+    if os.environ.get('VIPNERF_GRAD_LOG'):
+        with open(os.environ['VIPNERF_GRAD_LOG'], 'a') as f:
+            f.write('%-70s l2 %.3e max %.3e bound %.1e ratio %.3f\n' % (what, l2, mx, l2_tol, l2 / l2_tol))
+    if os.environ.get('VIPNERF_GRAD_NOASSERT'):          # (a measurement pass: record every tensor, decide the bounds afterwards)
+        return
+    assert l2 <= l2_tol and mx <= 10 * l2_tol, f'{what}: rel L2 err {l2:.3e} (bound {l2_tol:.1e}), max err / max|g| {mx:.3e}'
+
+
+def cdf_tie_gaps(w_coarse, u, inds, ref_inds):
+    """north_star says "bit-exact for sample indices".  On identical inputs the sampler IS bit-exact (F1, the stage sweeps); free-running, the
+    CDF inherits the coarse MLP's last-bit rounding, so an index may differ only where the draw u sits ON a CDF value: for every differing
+    (ray, draw) the distance from u to the oracle's CDF entry that separates the two answers, in units of u's fp32 spacing.  searchsorted(cdf,
+    u, right=True) counts the entries <= u, so answers k and k + 1 differ exactly on which side of u entry k lies.
+    w_coarse (N, Sc) the ORACLE's coarse weights; u (N, J); inds / ref_inds (N, J).  -> float array of gaps in ulp (empty when all agree)."""
+    w = w_coarse[:, 1:-1].float() + 1e-5
+    pdf = w / torch.sum(w, dim=-1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, dim=-1)], dim=-1).double()
+    rows, cols = torch.nonzero(inds != ref_inds, as_tuple=True)
+    if rows.numel() == 0:
+        return np.zeros(0)
+    edge = torch.minimum(inds[rows, cols], ref_inds[rows, cols]).clamp(max=cdf.shape[1] - 1)
+    uu = u[rows, cols].float()
+    gap = (cdf[rows, edge] - uu.double()).abs().numpy()
+    return gap / np.spacing(np.maximum(uu.numpy(), np.float32(2.0 ** -24)))
 
 
 # ------------------------------------------------------------------------------------------------ stage-wise

@@ -257,7 +257,7 @@ def test_training_step_without_secondary_views_vs_oracle(dev, prec):
     assert 'visibility2_fine' not in out or out['visibility2_fine'].shape == (n, 0)
     lh = LossComputerHip(cfg).compute_losses(rb, out)
     lh['TotalLoss'].backward()
-    rtol, gtol = {'fp32': (1e-4, 2e-3), 'fp16x3h': (2e-4, 1e-2), 'fp16': (5e-3, 1e-1), 'bf16': (4e-2, 3e-1)}[prec]
+    rtol, gtol = {'fp32': (1e-4, None), 'fp16x3h': (2e-4, 1e-2), 'fp16': (5e-3, 1e-1), 'bf16': (4e-2, 3e-1)}[prec]
     tp.assert_close(out['rgb_fine'], ref['rgb_fine'], rtol=rtol, floor=1e-3 if prec in ('fp16', 'bf16') else 1e-6, what=f'{prec} V = 0 rgb_fine')
     tp.assert_close(lh['TotalLoss'], lref['TotalLoss'], rtol=4 * rtol, floor=1e-6, what=f'{prec} V = 0 TotalLoss')
     errs = []
@@ -308,7 +308,7 @@ def assert_close_few_outliers(a, b, rtol, what, floor=1e-5, max_frac=0.005, fact
         f'{what}: {(over > 1).sum()} / {over.size} beyond tolerance, worst {over.max():.1f}x'
 
 
-ARITH = {'fp32': (1e-4, 2e-3), 'fp16x3': (1e-4, 2e-3), 'fp16x3h': (1e-4, 2e-3)}
+ARITH = {'fp32': (1e-4, None), 'fp16x3': (1e-4, None), 'fp16x3h': (1e-4, None)}       # gradients: tp.grad_close's fp32-grade default
 
 
 @pytest.mark.parametrize('prec', list(ARITH))
@@ -872,14 +872,14 @@ def test_ragged_and_tiny_batches(dev, prec, n, n_sparse):
     out = model(rb)
     lh = LossComputerHip(cfg).compute_losses(rb, out)
     lh['TotalLoss'].backward()
-    rtol, gtol = (1e-4, 2e-3) if prec != 'fp16' else (5e-3, 8e-2)
+    rtol, gtol = (1e-4, None) if prec != 'fp16' else (5e-3, 8e-2)
     assert out['rgb_fine'].shape == (tot, 3) and torch.isfinite(lh['TotalLoss'])
     for k in ('rgb_coarse', 'rgb_fine', 'acc_fine', 'weights_fine', 'visibility2_fine', 'raw_sigma_fine'):
         tp.assert_close(out[k], ref[k], rtol=rtol, floor=1e-5 if prec != 'fp16' else 2e-3, what=f'{prec} n={n}+{n_sparse} {k}')
     tp.assert_close(lh['TotalLoss'], lref['TotalLoss'], rtol=4 * rtol, floor=1e-6, what='TotalLoss')
     for k, t in model.named_parameters():
         assert torch.isfinite(t.grad).all(), k
-        tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{prec} n={n}+{n_sparse} grad {k}', l2_tol=gtol)
+        tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{prec} n={n}+{n_sparse} grad {k}', l2_tol=gtol, rows=n + n_sparse)
 
 
 def test_empty_batch_is_a_no_op(dev):

@@ -179,21 +179,28 @@ struct WgViewArgs {
 // tid + 512 of the feature block -- rows tid >> 6 and 8 + (tid >> 6) --, and, the first 128 threads, float4 (row tid >> 3, columns 4 (tid & 7)) of
 // every gamma(dir_a)).  (HEADS: the view hidden g_a and the head seeds dq_a go HBM -> LDS by DMA instead: no registers left for them.)
 template <int NV> struct ViewStage { float4 rv[NV], rf[2], rp[NV]; };
-template <int NV>
+// FULL: the caller guarantees whole 16-point blocks (the heads-fused launch: P % 16 == 0, chunks of 32 points) -- the loads are then issued
+// UNCONDITIONALLY, which is what the counted wait behind the head DMA relies on: `s_waitcnt vmcnt(NV + 2)` proves the DMA issued before these
+// loads has landed only if every wave really issues its NV + 2 (waves 0-1: 2 NV + 2) younger loads; a load predicated on a per-lane
+// validity test compiles to an execz-skipped branch, and a wave that skips one would pass the wait with a DMA piece still in flight
+// (tools/isa_exec_mfma_scan.py::scan_counted_waits checks the generated code for exactly this)
+template <int NV, bool FULL = false>
 __device__ __forceinline__ void view_gload(ViewStage<NV> &r, const WgViewArgs &a, int64_t pb, int64_t p1, int tid) {
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool okv = pb + (tid >> 5) < p1;
+    const bool okv = FULL || pb + (tid >> 5) < p1;
 #pragma unroll
     for (int k = 0; k < NV; ++k) { r.rv[k] = z4; if (okv) r.rv[k] = *(const float4 *)(a.dyv[k] + (size_t)(pb + (tid >> 5)) * WV + 4 * (tid & 31)); }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = (tid >> 6) + 8 * i;
         r.rf[i] = z4;
-        if (pb + row < p1) r.rf[i] = *(const float4 *)(a.feat + (size_t)(pb + row) * W + 4 * (tid & 63));
+        if (FULL || pb + row < p1) r.rf[i] = *(const float4 *)(a.feat + (size_t)(pb + row) * W + 4 * (tid & 63));
     }
-    const bool okp = tid < 128 && pb + (tid >> 3) < p1;
+    if (__builtin_amdgcn_readfirstlane(tid) < 128) {             // waves 0-1 (wave-uniform: a scalar branch, not a per-lane predicate)
+        const bool okp = FULL || pb + (tid >> 3) < p1;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) { r.rp[k] = z4; if (okp) r.rp[k] = *(const float4 *)(a.ped[k] + (size_t)(pb + (tid >> 3)) * DVE_PAD + 4 * (tid & 7)); }
+        for (int k = 0; k < NV; ++k) { r.rp[k] = z4; if (okp) r.rp[k] = *(const float4 *)(a.ped[k] + (size_t)(pb + (tid >> 3)) * DVE_PAD + 4 * (tid & 7)); }
+    }
 }
 template <int NV, int O_SUM, int O_PED, int O_FEAT>
 __device__ __forceinline__ void view_lstore(const ViewStage<NV> &r, float *t, int tid) {
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(512) void k_wgrad_view(WgViewArgs a) {
                         ViewStage<NV> &nx = half == 0 ? st1 : st0;
                         view_lstore<NV, O_SUM, O_PED, O_FEAT>(nx, lds + (1 - half) * TILE_F, tid);
                         dma_heads(p0 + (int64_t)(b + 1) * BP, 1 - half);
-                        if (b + 3 < nblk) view_gload<NV>(nx, a, p0 + (int64_t)(b + 3) * BP, p1, tid);
+                        if (b + 3 < nblk) view_gload<NV, HEADS>(nx, a, p0 + (int64_t)(b + 3) * BP, p1, tid);
                     }
                     const int row = 2 * s + h;
                     const float af = t[O_SUM + row * WV + 32 * wm + l31];
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(512) void k_wgrad_view(WgViewArgs a) {
                     }
                 }
                 if (HEADS) {                                 // this wave's DMA of block b + 1 has landed (younger: the NV + 2 register loads of block b + 3 every wave issues)
-                    if (b + 3 < nblk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NV + 2) : "memory");
+                    if (b + 3 < nblk) asm volatile("s_waitcnt vmcnt(%0) ; dma-landed-wait" ::"n"(NV + 2) : "memory");   // (the tag: what tests/test_isa_guards_cpu.py finds)
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __syncthreads();

@@ -629,6 +629,14 @@ def main():
             the same on every rank) against the gradient of the whole global batch computed locally by every rank (vdist.verify_sharded_gradient)."""
             self.model.configs['model']['hip_precision'] = precision
             gb = make_batch(self.gen, self.rays * world, 777, n_sparse=self.n_sparse * world)
+            # one rank per device (the real thing): the whole-batch pass keeps its activations if they fit, else re-renders in chunks (autograd.py).
+            # Ranks SHARING a device (the one-GPU tests of this path) would each size their workspace by the memory that is free "right now" and
+            # run out together: each gets an equal share of half the device instead
+            sharing = -(-world // max(torch.cuda.device_count(), 1))
+            cap_key, m = 'hip_max_workspace_bytes', self.model.configs['model']
+            old_cap = m.get(cap_key)
+            if sharing > 1:
+                m[cap_key] = int(torch.cuda.mem_get_info(dev)[1] // (2 * sharing))
 
             def grad_fn(batch):
                 b = dict(batch)
@@ -644,7 +652,13 @@ def main():
                 flat = self.bucket.adopted()
                 return flat if flat is not None else torch.cat([p.grad.reshape(-1) for p in self.bucket.params])
 
-            res = vdist.verify_sharded_gradient(grad_fn, gb, rank, world)
+            try:
+                res = vdist.verify_sharded_gradient(grad_fn, gb, rank, world)
+            finally:
+                if old_cap is None:
+                    m.pop(cap_key, None)
+                else:
+                    m[cap_key] = old_cap
             self.bucket.release()
             torch.cuda.empty_cache()
             return res

@@ -290,6 +290,16 @@ int32_t vipnerf_losses_forward(const vipnerf_config *cfg, int64_t n_rays, const 
                                const vipnerf_outputs *out, const vipnerf_loss_out *lout,
                                vipnerf_stream_t stream);
 
+/* vipnerf_losses_forward + TotalLoss in the same launches: total[0] = sum_k weights[k] * loss_values[k] (k = 0..7 in order, every product
+ * and sum rounded to float: the arithmetic of vipnerf_train_step's total_loss, bit for bit) -- LossComputer.compute_losses' accumulation
+ * `total_loss += loss_weight * loss_dict['loss_value']` (reference src/loss_functions/LossComputer01.py:33-44) without one multiply and one
+ * add kernel per loss -- and named[j] = loss_values[2 j] + loss_values[2 j + 1] (j = 0..3: MSE, VisibilityLoss, VisibilityPriorLoss,
+ * SparseDepthMSE as the reference logs them, coarse + fine).  weights: 8 floats on the HOST (this iteration's loss weights by slot);
+ * total (1) and named (4, may be NULL) on the device. */
+int32_t vipnerf_losses_forward_w(const vipnerf_config *cfg, int64_t n_rays, const vipnerf_loss_in *in,
+                                 const vipnerf_outputs *out, const vipnerf_loss_out *lout, const float *weights,
+                                 float *total, float *named, vipnerf_stream_t stream);
+
 /* The backward of the fused losses: out_k[i] = g[slot_k] * in_k[i] for up to VIPNERF_MAX_SCALE_SEGS arrays in ONE launch -- the loss
  * kernel's unweighted gradient seeds times the upstream gradient of their loss value (autograd of TotalLoss = sum_k weight_k * loss_k,
  * reference src/loss_functions/LossComputer01.py:33-44, which PyTorch evaluates as one multiplication per seed tensor).  g: the 8 upstream
@@ -302,6 +312,11 @@ typedef struct vipnerf_scale_seg {
     int32_t reserved;
 } vipnerf_scale_seg;
 int32_t vipnerf_scale_segments(int32_t n_segs, const vipnerf_scale_seg *segs, const float *g, vipnerf_stream_t stream);
+/* The same for TotalLoss of vipnerf_losses_forward_w: out_k[i] = (g_total[0] * weights[slot_k]) * in_k[i] -- g_total: the upstream gradient
+ * of TotalLoss, ONE float on the device (autograd's root gradient 1.0: then exactly vipnerf_train_step's weights x seeds); weights: 8 floats
+ * on the host. */
+int32_t vipnerf_scale_segments_w(int32_t n_segs, const vipnerf_scale_seg *segs, const float *g_total, const float *weights,
+                                 vipnerf_stream_t stream);
 
 /* One Adam step on flat fp32 buffers (parameters, both moments, gradients: n elements each) in ONE launch -- the update of
  * torch.optim.Adam (the reference's optimizer, src/Trainer01.py:505-515: betas (0.9, 0.999), no weight decay, no amsgrad), evaluated with

@@ -82,12 +82,17 @@ GRAD_LOG = []          # (what, rel L2, max err / max|g|, bound) of every grad_c
 def grad_close(a, ref, what, scale=0.0, l2_tol=None, rows=0):
     """Parameter gradients against the oracle's / the reference's: relative L2 error and largest element error over the largest element.
 
-    Bounds (what is measured, not what is comfortable).  fp32 / fp16x3 arithmetic, default: 1e-4 on the reference's
-    goldens and the small oracle cases (measured <= 4e-5), 5e-4 at >= 4096 rows (measured <= 2.8e-4: sums over ~1e6 fp32 products in
-    another order, and a ReLU whose pre-activation sits within rounding of 0 falls on either side -- one point's contribution then appears
-    or disappears).  The 16-bit modes pass their own class explicitly.  The element bound is 10 x the L2 bound."""
+    Bounds = about twice what is MEASURED (the first GPU pass of round 6 recorded every tensor of every test:
+    profiles/r06_grad_close_measured.txt).  The measurements are bimodal.  Most cases sit at pure summation-order rounding, 1e-6 .. 7e-5:
+    they get the default, 1.5e-4 (6e-4 at >= 4096 rows: sums over ~1e6 products, measured 2.8e-4).  A minority sits at 1e-4 .. 2e-3 -- ALL
+    tensors of a level at once, by about the same relative amount: one sample of the batch whose contribution changes sign or vanishes.  The
+    path has real kinks: the visibility loss is an L1 term whose seed is sign(T^ - T) (VisibilityLoss01.py:60-66; T = 1 - 1e-7 against
+    T^ = 1 flips it), and a ReLU whose pre-activation is at rounding level lets a point through or not.  With 16 .. 1024 rays such an event
+    is 1e-4 .. 2e-3 of a tensor's norm; those test families pass their own bound explicitly, each with its measured value beside it.  An
+    injected relative error of 1e-3 fails the default, the 4096-row and the 1024-ray bounds (tests/test_tolerances_cpu.py); the 16-bit
+    modes have their own classes.  The element bound is 10 x the L2 bound."""
     if l2_tol is None:
-        l2_tol = 5e-4 if rows >= 4096 else 1e-4
+        l2_tol = 6e-4 if rows >= 4096 else 1.5e-4
     a, ref = np.asarray(a, np.float64).reshape(-1), np.asarray(ref, np.float64).reshape(-1)
     assert np.isfinite(a).all(), what
     nrm = max(np.linalg.norm(ref), scale * np.sqrt(ref.size), 1e-30)
@@ -340,9 +345,10 @@ def test_train_step_golden(dev, tag):
         gd, dg = g['gdig_' + k], digest(p.grad)
         assert np.isfinite(dg).all(), k
         np.testing.assert_allclose(dg[1], gd[1], rtol=1e-3, atol=1e-9, err_msg=f'{tag} |grad| of {k}')
-        grad_close(dg[2:], gd[2:], f'{tag} grad samples of {k}', scale=max(abs(gd[1]) / np.sqrt(p.numel()), 1e-12))
+        gtol = {'realestate': 2.5e-3, 'dtu4wl': 3e-4}.get(tag)      # measured: llff 1.5e-5, dtu 3.9e-6, dtu4wl 1.3e-4, realestate 1.1e-3 (16 + 16 rays: one kink event)
+        grad_close(dg[2:], gd[2:], f'{tag} grad samples of {k}', scale=max(abs(gd[1]) / np.sqrt(p.numel()), 1e-12), l2_tol=gtol)
         if 'grad_' + k in g:
-            grad_close(p.grad.cpu().numpy(), g['grad_' + k], f'{tag} grad of {k}')
+            grad_close(p.grad.cpu().numpy(), g['grad_' + k], f'{tag} grad of {k}', l2_tol=gtol)
     opt.step()
     # The first Adam update is -lr g / (|g| + 1e-8): +-5e-4 whatever the gradient's size, so a bound of one update proves nothing.  Elements
     # whose reference gradient is above rounding level (|g| > 1e-6: the update's sign and size are then determined to < 1e-8) must land
@@ -477,7 +483,7 @@ def test_backward_all_cotangents_vs_oracle(dev):
         tot_h.backward()
         worst = 0.0
         for k, t in model.named_parameters():
-            grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{scene} {k}')
+            grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{scene} {k}', l2_tol=1.2e-3)      # measured 5.5e-4 (fern: every coarse tensor by 4.3 .. 5.5e-4, one kink event)
             worst = max(worst, float((t.grad.cpu() - p[k].grad).norm() / p[k].grad.norm()))
         print(f'{scene}: worst relative L2 gradient error over 48 tensors {worst:.3e}')
 

@@ -226,7 +226,7 @@ def test_rare_config_branches_vs_oracle(dev, case):
             tp.assert_close(out[k], ref[k], what=f'{case} {k}')
     tp.assert_close(lh['TotalLoss'], lref['TotalLoss'], rtol=1e-4, floor=1e-6, what=f'{case} TotalLoss')
     for k, t in model.named_parameters():
-        tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{case} grad {k}')
+        tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{case} grad {k}', l2_tol=3e-3)       # measured: v3_ndc 4.4e-5, samples_32_96 1.5e-5, v3_white_lindisp 1.3e-3 (kink event)
 
 
 @pytest.mark.parametrize('prec', ['fp32', 'bf16', 'fp16', 'fp16x3h'])
@@ -290,7 +290,7 @@ def test_partial_tile_step_vs_oracle(dev, n, scene, nf):
                 tp.assert_close(out[k], ref[k], what=f'{n} rays {scene} {k}')
     tp.assert_close(lh['TotalLoss'], lref['TotalLoss'], rtol=1e-4, floor=1e-6, what=f'{n} rays TotalLoss')
     for k, t in model.named_parameters():
-        tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{n} rays {scene} grad {k}')
+        tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{n} rays {scene} grad {k}', l2_tol=8e-4)      # measured: 1 / 37 rays fern <= 1.1e-5, 75 rays dtu 1.4e-4, 130 rays realestate 3.3e-4
 
 
 def assert_close_few_outliers(a, b, rtol, what, floor=1e-5, max_frac=0.005, factor=100.0):
@@ -308,7 +308,7 @@ def assert_close_few_outliers(a, b, rtol, what, floor=1e-5, max_frac=0.005, fact
         f'{what}: {(over > 1).sum()} / {over.size} beyond tolerance, worst {over.max():.1f}x'
 
 
-ARITH = {'fp32': (1e-4, None), 'fp16x3': (1e-4, None), 'fp16x3h': (1e-4, None)}       # gradients: tp.grad_close's fp32-grade default
+ARITH = {'fp32': (1e-4, 8e-4), 'fp16x3': (1e-4, 8e-4), 'fp16x3h': (1e-4, 8e-4)}       # gradients at 1024 rays, measured: fern 1.2 .. 1.3e-4, realestate 3.1 .. 3.7e-4 (old bound: 2e-3)
 
 
 @pytest.mark.parametrize('prec', list(ARITH))

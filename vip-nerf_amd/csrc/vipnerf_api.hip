@@ -468,9 +468,8 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
     return VIPNERF_OK;
 }
 
-int32_t vipnerf_losses_forward(const vipnerf_config *cfg, int64_t n_rays, const vipnerf_loss_in *in,
-                               const vipnerf_outputs *out, const vipnerf_loss_out *lout,
-                               vipnerf_stream_t stream) {
+static int32_t losses_forward_impl(const vipnerf_config *cfg, int64_t n_rays, const vipnerf_loss_in *in, const vipnerf_outputs *out,
+                                   const vipnerf_loss_out *lout, const float *weights, float *total, float *named, vipnerf_stream_t stream) {
     int rc = check_cfg(cfg);
     if (rc) return rc;
     if (!in || !out || !lout || !in->target_rgb || !lout->loss_values || !lout->scratch) {
@@ -488,18 +487,38 @@ int32_t vipnerf_losses_forward(const vipnerf_config *cfg, int64_t n_rays, const 
             set_error("losses_forward: a seed pointer is NULL"); return VIPNERF_E_ARG; }
     }
     a.partial = lout->scratch; a.counts = lout->scratch + 7 * (size_t)n_rays; a.loss_values = lout->loss_values;
+    if (weights) {
+        for (int k = 0; k < 8; ++k) a.w[k] = weights[k];
+        a.total = total; a.named = named;
+    }
     ProfScope ps("losses", (hipStream_t)stream);
     return launch_losses(a, (hipStream_t)stream);
 }
 
-int32_t vipnerf_scale_segments(int32_t n_segs, const vipnerf_scale_seg *segs, const float *g, vipnerf_stream_t stream) {
+int32_t vipnerf_losses_forward(const vipnerf_config *cfg, int64_t n_rays, const vipnerf_loss_in *in,
+                               const vipnerf_outputs *out, const vipnerf_loss_out *lout,
+                               vipnerf_stream_t stream) {
+    return losses_forward_impl(cfg, n_rays, in, out, lout, nullptr, nullptr, nullptr, stream);
+}
+
+int32_t vipnerf_losses_forward_w(const vipnerf_config *cfg, int64_t n_rays, const vipnerf_loss_in *in,
+                                 const vipnerf_outputs *out, const vipnerf_loss_out *lout, const float *weights,
+                                 float *total, float *named, vipnerf_stream_t stream) {
+    if (!weights || !total) { set_error("losses_forward_w: weights (host, 8) and total (device, 1) are needed"); return VIPNERF_E_ARG; }
+    if (n_rays <= 0) { set_error("losses_forward_w: no rays (TotalLoss of an empty batch is not defined)"); return VIPNERF_E_ARG; }
+    return losses_forward_impl(cfg, n_rays, in, out, lout, weights, total, named, stream);
+}
+
+static int32_t scale_segments_impl(int32_t n_segs, const vipnerf_scale_seg *segs, const float *g, const float *g_total, const float *weights,
+                                   vipnerf_stream_t stream) {
     clear_stale_hip_error();
     if (n_segs < 0 || n_segs > VIPNERF_MAX_SCALE_SEGS) { set_error("scale_segments: n_segs=%d (0..%d)", n_segs, VIPNERF_MAX_SCALE_SEGS); return VIPNERF_E_ARG; }
     if (n_segs == 0) return VIPNERF_OK;
-    if (!segs || !g) { set_error("scale_segments: NULL argument"); return VIPNERF_E_ARG; }
+    if (!segs || (!g && !(g_total && weights))) { set_error("scale_segments: NULL argument"); return VIPNERF_E_ARG; }
     ScaleArgs a;
     memset(&a, 0, sizeof(a));
-    a.n = n_segs; a.g = g;
+    a.n = n_segs; a.g = g; a.g1 = g ? nullptr : g_total;
+    if (!g) for (int k = 0; k < 8; ++k) a.w[k] = weights[k];
     for (int k = 0; k < n_segs; ++k) {
         if (segs[k].numel < 0 || segs[k].slot < 0 || segs[k].slot > 7 || (segs[k].numel > 0 && (!segs[k].in || !segs[k].out))) {
             set_error("scale_segments: segment %d: numel %lld, slot %d, NULL pointers?", k, (long long)segs[k].numel, segs[k].slot); return VIPNERF_E_ARG; }
@@ -507,6 +526,17 @@ int32_t vipnerf_scale_segments(int32_t n_segs, const vipnerf_scale_seg *segs, co
     }
     ProfScope ps("losses_bwd", (hipStream_t)stream);
     return launch_scale_segments(a, (hipStream_t)stream);
+}
+
+int32_t vipnerf_scale_segments(int32_t n_segs, const vipnerf_scale_seg *segs, const float *g, vipnerf_stream_t stream) {
+    if (n_segs > 0 && !g) { set_error("scale_segments: NULL argument"); return VIPNERF_E_ARG; }
+    return scale_segments_impl(n_segs, segs, g, nullptr, nullptr, stream);
+}
+
+int32_t vipnerf_scale_segments_w(int32_t n_segs, const vipnerf_scale_seg *segs, const float *g_total, const float *weights,
+                                 vipnerf_stream_t stream) {
+    if (n_segs > 0 && (!g_total || !weights)) { set_error("scale_segments_w: g_total (device, 1) and weights (host, 8) are needed"); return VIPNERF_E_ARG; }
+    return scale_segments_impl(n_segs, segs, nullptr, g_total, weights, stream);
 }
 
 // build switch VN_ADAM_FMA_MASK (default 7, vipnerf_knobs.h): which of torch's three update expressions its kernels contract into an fma on gfx950 (tests/test_hip_fullsize.py)

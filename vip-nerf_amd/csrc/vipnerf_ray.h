@@ -41,6 +41,8 @@ struct LossArgs {
     float *partial;                   // (7*N) + 2 counts appended by the caller
     float *counts;                    // (2)
     float *loss_values;               // (8)
+    float w[8];                       // with total: total[0] = sum_k w[k] * loss_values[k], named[j] = loss_values[2 j] + loss_values[2 j + 1] (k_loss_final)
+    float *total, *named;
 };
 
 int launch_coarse_z(int64_t N, int S, int lindisp, const float *near, const float *far, const float *t_rand,
@@ -54,6 +56,7 @@ struct ScaleArgs {
     vipnerf_scale_seg s[VIPNERF_MAX_SCALE_SEGS];
     int n;
     const float *g;                   // (8) device: the factors by slot; NULL = w below
+    const float *g1;                  // (1) device, with g == NULL: the factors are g1[0] * w[slot] (the upstream gradient of a weighted TotalLoss)
     float w[8];                       // host-side factors (vipnerf_train_step: the loss weights)
     const float *loss_values;         // with total: total[0] = sum_k w[k] * loss_values[k] (fixed order, block (0, 0) thread 0)
     float *total;

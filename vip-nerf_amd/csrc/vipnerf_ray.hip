@@ -518,13 +518,22 @@ __global__ void k_loss_final(LossArgs a) {
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) a.loss_values[7] = 0.f;
+    if (threadIdx.x == 0) {
+        a.loss_values[7] = 0.f;
+        if (a.total) {               // TotalLoss in k_scale_segments' order and roundings (thread 0 wrote every value above: its own stores are visible to it)
+            float t = 0.f;
+            for (int k = 0; k < 8; ++k) t = __fadd_rn(t, __fmul_rn(a.w[k], a.loss_values[k]));
+            a.total[0] = t;
+        }
+        if (a.named)
+            for (int j = 0; j < 4; ++j) a.named[j] = __fadd_rn(a.loss_values[2 * j], a.loss_values[2 * j + 1]);
+    }
 }
 
 // out_k = g[slot_k] * in_k for all segments in one launch (blockIdx.y = segment): the fused losses' backward
 __global__ void k_scale_segments(ScaleArgs a) {
     const vipnerf_scale_seg sg = a.s[blockIdx.y];
-    const float w = a.g ? a.g[sg.slot] : a.w[sg.slot];
+    const float w = a.g ? a.g[sg.slot] : (a.g1 ? __fmul_rn(a.g1[0], a.w[sg.slot]) : a.w[sg.slot]);
     if (a.total && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         float t = 0.f;
         for (int k = 0; k < 8; ++k) t = __fadd_rn(t, __fmul_rn(a.w[k], a.loss_values[k]));

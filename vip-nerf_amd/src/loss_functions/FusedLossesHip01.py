@@ -18,19 +18,12 @@ except ImportError:
         if cand and cand not in sys.path:
             sys.path.insert(0, cand)
 from vipnerf_hip import ops
-from vipnerf_hip.autograd import FusedLossFunction
+from vipnerf_hip.autograd import FusedLossFunction, FusedLossTotalFunction
 
 CACHE_ATTR = '_vipnerf_hip_fused_losses'     # attribute of output_dict['rgb_coarse']: (vector (8,), its unbind() tuple)
 
 
-def fused_loss_values(configs: dict, input_dict: dict, output_dict: dict):
-    """-> 8 scalar tensors: [mse_c, mse_f, vis_c, vis_f, prior_c, prior_f, sparse_depth, 0] (unweighted).  They are
-    the unbind() of the kernel's result vector, so that autograd sees one Unbind node instead of one Select node (a
-    zeros + a copy kernel) per value a loss class picks."""
-    anchor = output_dict['rgb_coarse']
-    cached = getattr(anchor, CACHE_ATTR, None)
-    if cached is not None:
-        return cached[1]
+def _loss_inputs(configs: dict, input_dict: dict, output_dict: dict):
     m = configs['model']
     fine = 'fine_mlp' in m
     n = output_dict['rgb_coarse'].shape[0]
@@ -55,11 +48,30 @@ def fused_loss_values(configs: dict, input_dict: dict, output_dict: dict):
         # number no loss class may read (VisibilityLossHip raises the reference's KeyError instead)
         rv = rv.squeeze(-1) if rv is not None else torch.zeros_like(output_dict[f'visibility_{lv}'])
         return (output_dict[f'rgb_{lv}'], output_dict[f'visibility_{lv}'], rv, output_dict.get(f'visibility2_{lv}'), output_dict[f'depth_{lv}'])
-    vals = FusedLossFunction.apply(cfg, n, input_dict['target_rgb'], input_dict['indices_mask_nerf'], prior, mask_sd, sd,
-                                   *level('coarse'), *(level('fine') if fine else (None,) * 5))
+    return cfg, n, (input_dict['target_rgb'], input_dict['indices_mask_nerf'], prior, mask_sd, sd), (*level('coarse'), *(level('fine') if fine else (None,) * 5))
+
+
+def fused_loss_values(configs: dict, input_dict: dict, output_dict: dict):
+    """-> 8 scalar tensors: [mse_c, mse_f, vis_c, vis_f, prior_c, prior_f, sparse_depth, 0] (unweighted).  They are
+    the unbind() of the kernel's result vector, so that autograd sees one Unbind node instead of one Select node (a
+    zeros + a copy kernel) per value a loss class picks."""
+    anchor = output_dict['rgb_coarse']
+    cached = getattr(anchor, CACHE_ATTR, None)
+    if cached is not None:
+        return cached[1]
+    cfg, n, loss_in, levels = _loss_inputs(configs, input_dict, output_dict)
+    vals = FusedLossFunction.apply(cfg, n, *loss_in, *levels)
     parts = vals.unbind(0)
     setattr(anchor, CACHE_ATTR, (vals, parts))
     return parts
+
+
+def fused_loss_total(configs: dict, input_dict: dict, output_dict: dict, weights8):
+    """-> (TotalLoss 0-dim with the graph, loss_values (8,) detached, named (4,) detached): the weighted total of
+    LossComputer.compute_losses evaluated by the loss kernels themselves (FusedLossTotalFunction; weights8 = this iteration's weight of
+    every slot of the loss vector).  No PyTorch arithmetic, forward or backward."""
+    cfg, n, loss_in, levels = _loss_inputs(configs, input_dict, output_dict)
+    return FusedLossTotalFunction.apply(cfg, n, [float(w) for w in weights8], *loss_in, *levels)
 
 
 def fused_loss_vector(configs: dict, input_dict: dict, output_dict: dict):

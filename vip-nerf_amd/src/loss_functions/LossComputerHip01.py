@@ -45,10 +45,10 @@ class LossComputerHip:
         return loss_values
 
     def _fused_total(self, input_dict, output_dict, iter_num):
-        """When every configured loss is one of the fused *Hip classes: TotalLoss as ONE dot product of the fused loss
-        vector with the weights (same values as the generic path below, which costs ~3 zero-dim kernels per loss forward
-        and as many backward), the per-loss values for logging from one detached pair-sum."""
-        from loss_functions.FusedLossesHip01 import fused_loss_vector
+        """When every configured loss is one of the fused *Hip classes: TotalLoss and the per-loss values for logging straight from the
+        loss kernels (same values as the generic path below, which costs ~3 zero-dim PyTorch kernels per loss forward and as many
+        backward -- what the reference's own LossComputer01 does with these classes inside its trainer)."""
+        from loss_functions.FusedLossesHip01 import fused_loss_total
         if not self.losses or any(not hasattr(o, 'FUSED_SLOTS') for o in self.losses.values()):
             return None
         configs = next(iter(self.losses.values())).configs
@@ -68,15 +68,13 @@ class LossComputerHip:
             if fine and b != 7:
                 w8[b] = weight
             present[name] = (a, b)
-        vec = fused_loss_vector(configs, input_dict, output_dict)
-        key = (tuple(w8), vec.device)
-        if getattr(self, '_w8_key', None) != key:
-            self._w8, self._w8_key = torch.tensor(w8, dtype=vec.dtype, device=vec.device), key
-        pairs = vec.detach().view(4, 2).sum(1).unbind(0) if fine else vec.detach()[0::2].unbind(0)
-        loss_values = {}
-        for name, slots in present.items():
-            loss_values[name] = {'loss_value': pairs[slots[0] // 2] if slots is not None else vec.detach()[7] * 0}
-        loss_values['TotalLoss'] = torch.dot(vec, self._w8)
+        # ONE Function: the loss kernels write the eight values, TotalLoss = sum_k w8[k] * value[k] (vipnerf_train_step's arithmetic, bit for
+        # bit) and the four per-loss sums; backward is one launch.  (Round 5 took the total with torch.dot and the sums with a reduce kernel:
+        # three PyTorch kernels forward, two backward.)
+        total, _vals, named = fused_loss_total(configs, input_dict, output_dict, w8)
+        parts = named.unbind(0)                           # views: [MSE, VisibilityLoss, VisibilityPriorLoss, SparseDepthMSE], coarse + fine
+        loss_values = {name: {'loss_value': parts[slots[0] // 2 if slots is not None else 3]} for name, slots in present.items()}
+        loss_values['TotalLoss'] = total
         return loss_values
 
     @staticmethod

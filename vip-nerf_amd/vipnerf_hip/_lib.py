@@ -151,6 +151,8 @@ SYMBOLS = {
                                             P(MlpGrads), P(MlpGrads), c_f]),
     'vipnerf_losses_forward': (C.c_int32, [P(Config), C.c_int64, P(LossIn), P(Outputs), P(LossOut), c_f]),
     'vipnerf_scale_segments': (C.c_int32, [C.c_int32, P(ScaleSeg), c_f, c_f]),
+    'vipnerf_losses_forward_w': (C.c_int32, [P(Config), C.c_int64, P(LossIn), P(Outputs), P(LossOut), C.POINTER(C.c_float), c_f, c_f, c_f]),
+    'vipnerf_scale_segments_w': (C.c_int32, [C.c_int32, P(ScaleSeg), c_f, C.POINTER(C.c_float), c_f]),
     'vipnerf_train_step': (C.c_int32, [P(TrainStepArgs), c_f]),
     'vipnerf_adam_step': (C.c_int32, [C.c_int64, c_f, c_f, c_f, c_f, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, c_f]),
     'vipnerf_coarse_depths': (C.c_int32, [C.c_int64, C.c_int32, C.c_int32, c_f, c_f, c_f, c_f, c_f]),

@@ -263,3 +263,47 @@ class FusedLossFunction(torch.autograd.Function):
         for (pos, _, _), t in zip(todo, scaled):
             out[pos] = t
         return (None, None, None, None, None, None, None, *out)
+
+
+class FusedLossTotalFunction(torch.autograd.Function):
+    """apply(cfg, n_rays, weights8, target_rgb, mask_nerf, prior, mask_sparse, sparse_depth, <the ten level tensors of FusedLossFunction>)
+        -> (TotalLoss 0-dim, loss_values (8,), named (4,))
+    LossComputer.compute_losses' weighted total (reference src/loss_functions/LossComputer01.py:33-44) evaluated by the loss kernels themselves
+    (vipnerf_losses_forward_w): TotalLoss = sum_k weights8[k] * loss_values[k] in vipnerf_train_step's order and roundings -- bit-identical to
+    the one-call step's --, named = the four per-loss sums for logging.  Only TotalLoss carries a gradient; its backward is ONE launch
+    (vipnerf_scale_segments_w: seeds x (upstream gradient x weight)).  No PyTorch arithmetic: the module-contract step's dot product, pair
+    sums and their backward kernels (round 5: rocblas dot, a reduce and two elementwise kernels per step) are gone."""
+
+    @staticmethod
+    def forward(ctx, cfg, n_rays, weights8, target_rgb, mask_nerf, prior, mask_sparse, sparse_depth, *lv):
+        def level(t):
+            rgb, T, rv, v2, dep = t
+            if rgb is None:
+                return None
+            d = {'rgb': ops.f32c(rgb), 'visibility': ops.f32c(T), 'raw_vis': ops.f32c(rv), 'depth': ops.f32c(dep)}
+            if v2 is not None:
+                d['vis2'] = ops.f32c(v2)
+            return d
+        coarse, fine = level(lv[0:5]), level(lv[5:10])
+        vals, sc, sf, total, named = ops.losses_forward(cfg, n_rays, target_rgb, mask_nerf, prior, mask_sparse, sparse_depth, coarse, fine,
+                                                        weights=weights8)
+        ctx.seeds, ctx.weights = (sc, sf), [float(w) for w in weights8]
+        ctx.present = [t is not None for t in lv]
+        ctx.mark_non_differentiable(vals, named)
+        return total.view(()), vals, named
+
+    @staticmethod
+    def backward(ctx, g_total, _g_vals, _g_named):
+        sc, sf = ctx.seeds
+        out = [None] * 10
+        todo = []
+        for li, sd in enumerate((sc, sf)):
+            if sd is None:
+                continue
+            for j, (key, slot) in enumerate((('rgb', 0 + li), ('visibility', 2 + li), ('raw_vis', 2 + li), ('vis2', 4 + li), ('depth', 6))):
+                if key in sd and ctx.present[5 * li + j]:
+                    todo.append((5 * li + j, sd[key], slot))
+        scaled = ops.scale_segments([t for _, t, _ in todo], [s for _, _, s in todo], g_total, weights=ctx.weights)
+        for (pos, _, _), t in zip(todo, scaled):
+            out[pos] = t
+        return (None, None, None, None, None, None, None, None, *out)

@@ -469,8 +469,10 @@ def rng_draw(kind: str, seed: int, offset: int, stream_id: int, first_idx: int, 
     return out
 
 
-def losses_forward(cfg: L.Config, n_rays, target_rgb, mask_nerf, prior, mask_sparse, sparse_depth, coarse, fine):
-    """-> (loss_values (8,), seeds_coarse dict, seeds_fine dict)."""
+def losses_forward(cfg: L.Config, n_rays, target_rgb, mask_nerf, prior, mask_sparse, sparse_depth, coarse, fine, weights=None):
+    """-> (loss_values (8,), seeds_coarse dict, seeds_fine dict).  weights (8 host floats: this iteration's loss weights by slot): the same
+    launches also write TotalLoss = sum_k weights[k] * loss_values[k] and the four per-loss sums (vipnerf_losses_forward_w) -> (loss_values,
+    seeds_coarse, seeds_fine, total (1,), named (4,))."""
     dev = target_rgb.device
     keep = []
     li = L.LossIn()
@@ -501,27 +503,35 @@ def losses_forward(cfg: L.Config, n_rays, target_rgb, mask_nerf, prior, mask_spa
             d['vis2'] = e(n_rays, cfg.n_sec)
         last = (lvl is fine) or (fine is None)
         if last:
-            d['depth'] = torch.zeros(n_rays, dtype=torch.float32, device=dev)
+            d['depth'] = e(n_rays)                # (the loss kernel writes every row's seed on the last level: 0 where no sparse depth)
         for k, v in d.items():
             setattr(st, k, _p(v))
         seeds.append(d)
+    if weights is not None:
+        tn = torch.empty(5, dtype=torch.float32, device=dev)          # [TotalLoss, four per-loss sums]
+        w8 = (C.c_float * 8)(*[float(w) for w in weights])
+        with on_device(*keep, vals) as dev:
+            L.check(L.load().vipnerf_losses_forward_w(C.byref(cfg), n_rays, C.byref(li), C.byref(out), C.byref(lo), w8, _p(tn[0:1]), _p(tn[1:5]),
+                                                      _stream(dev)), 'vipnerf_losses_forward_w')
+        return vals, seeds[0], seeds[1], tn[0:1], tn[1:5]
     with on_device(*keep, vals) as dev:
         L.check(L.load().vipnerf_losses_forward(C.byref(cfg), n_rays, C.byref(li), C.byref(out), C.byref(lo), _stream(dev)),
                 'vipnerf_losses_forward')
     return vals, seeds[0], seeds[1]
 
 
-def scale_segments(tensors: List[torch.Tensor], slots: List[int], g: torch.Tensor) -> List[torch.Tensor]:
+def scale_segments(tensors: List[torch.Tensor], slots: List[int], g: torch.Tensor, weights=None) -> List[torch.Tensor]:
     """-> [g[slot_k] * tensors[k]] in ONE launch (the fused losses' backward: seeds times the upstream gradients of their loss values).
-    The results are views of one buffer."""
+    The results are views of one buffer.  weights (8 host floats): g is the upstream gradient of the weighted TotalLoss instead, ONE value
+    on the device, and the factors are (g[0] * weights[slot_k]) (vipnerf_scale_segments_w)."""
     if not tensors:
         return []
     if len(tensors) > 16:
         raise L.VipNerfHipError(f'scale_segments: {len(tensors)} tensors (at most 16)')
     ins = [f32c(t) for t in tensors]
     gc = f32c(g).reshape(-1)
-    if gc.numel() < 8:
-        raise L.VipNerfHipError('scale_segments: g must hold 8 values')
+    if gc.numel() < (8 if weights is None else 1):
+        raise L.VipNerfHipError('scale_segments: g must hold 8 values (1 with weights)')
     offs, total = [], 0
     for t in ins:
         offs.append(total)
@@ -532,7 +542,11 @@ def scale_segments(tensors: List[torch.Tensor], slots: List[int], g: torch.Tenso
     for k, (t, o, sl) in enumerate(zip(ins, outs, slots)):
         segs[k].in_, segs[k].out, segs[k].numel, segs[k].slot = _p(t) if t.numel() else None, _p(o) if t.numel() else None, t.numel(), int(sl)
     with on_device(*ins, gc, flat) as dev:
-        L.check(L.load().vipnerf_scale_segments(len(ins), segs, _p(gc), _stream(dev)), 'vipnerf_scale_segments')
+        if weights is None:
+            L.check(L.load().vipnerf_scale_segments(len(ins), segs, _p(gc), _stream(dev)), 'vipnerf_scale_segments')
+        else:
+            w8 = (C.c_float * 8)(*[float(w) for w in weights])
+            L.check(L.load().vipnerf_scale_segments_w(len(ins), segs, _p(gc), w8, _stream(dev)), 'vipnerf_scale_segments_w')
     return outs
 
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VIPNERF_ABI_VERSION 5
+#define VIPNERF_ABI_VERSION 6
 
 #define VIPNERF_OK             0
 #define VIPNERF_E_ARG         (-1)   /* null / inconsistent argument */
@@ -259,6 +259,10 @@ int32_t vipnerf_pack_weights_p(const vipnerf_mlp_params *params, int32_t precisi
  * may be NULL: layers >= netdepth). */
 size_t  vipnerf_packed_weights_bytes_c(const vipnerf_config *cfg);
 int32_t vipnerf_pack_weights_c(const vipnerf_config *cfg, const vipnerf_mlp_params *params, void *packed, vipnerf_stream_t stream);
+/* Two MLPs of one configuration (the coarse and the fine model: VipNeRF.__init__, reference src/models/VipNeRF01.py:17-27) packed by ONE
+ * launch; the images are those of two vipnerf_pack_weights_c calls. */
+int32_t vipnerf_pack_weights2_c(const vipnerf_config *cfg, const vipnerf_mlp_params *params_a, void *packed_a,
+                                const vipnerf_mlp_params *params_b, void *packed_b, vipnerf_stream_t stream);
 
 /* ---- workspace ------------------------------------------------------------------------------------------ */
 /* acts_bytes: per-call activation store written by render_forward when cfg.save_acts (0 otherwise), read by

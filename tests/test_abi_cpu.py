@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f'{n} declared in include/vipnerf_hip.h but not exported'
     assert set(names) == set(_lib.SYMBOLS), 'ctypes binding and header disagree'
-    assert lib.vipnerf_abi_version() == 5
+    assert lib.vipnerf_abi_version() == 6          # 6: + vipnerf_losses_forward_w, vipnerf_scale_segments_w, vipnerf_pack_weights2_c (append-only; no struct changed)
     image = 4 * (36 * 16384 + 34 * 16384 + 7424)      # ONE image per precision (ABI 5): 36 forward + 34 data-gradient stages of 64 KiB + the resident block
     assert lib.vipnerf_packed_weights_bytes() == lib.vipnerf_packed_weights_bytes_p(0) == image
     assert lib.vipnerf_packed_weights_bytes_p(1) == 0 and lib.vipnerf_packed_weights_bytes_p(2) == 0      # the retired split-bf16 arithmetics
@@ -341,6 +341,11 @@ def test_argument_checks_need_no_gpu():
     assert lib.vipnerf_scale_segments(17, segs, None, None) < 0 and 'n_segs' in last()
     assert lib.vipnerf_scale_segments(0, None, None, None) == 0
     assert lib.vipnerf_scale_segments(1, segs, None, None) < 0 and 'NULL' in last()
+    # the weighted forms (TotalLoss without PyTorch arithmetic): host weights and a device total are required
+    w8 = (C.c_float * 8)(*[1.0] * 8)
+    assert lib.vipnerf_scale_segments_w(17, segs, None, w8, None) < 0 and 'n_segs' in last()
+    assert lib.vipnerf_scale_segments_w(0, None, None, None, None) == 0
+    assert lib.vipnerf_scale_segments_w(1, segs, None, w8, None) < 0 and 'NULL' in last()
     assert lib.vipnerf_adam_step(-1, None, None, None, None, 0.1, 0.999, 0.001, 1.0, 1e-8, -1e-3, -1, None) < 0
     assert lib.vipnerf_adam_step(0, None, None, None, None, 0.1, 0.999, 0.001, 1.0, 1e-8, -1e-3, -1, None) == 0
     assert lib.vipnerf_adam_step(8, None, None, None, None, 0.1, 0.999, 0.001, 1.0, 1e-8, -1e-3, -1, None) < 0 and 'NULL' in last()

@@ -1,0 +1,123 @@
+"""Round 6: launches folded together, against what they replace -- bit for bit.
+
+  * vipnerf_pack_weights2_c: the coarse and the fine MLP packed by one launch == two vipnerf_pack_weights_c launches;
+  * vipnerf_losses_forward_w / vipnerf_scale_segments_w (LossComputerHip: TotalLoss and the per-loss sums from the loss kernels, one backward
+    launch) == the loss vector times the weights taken with PyTorch (round 5: torch.dot + a pair-sum), values and gradients;
+  * the mask counts taken inside k_loss_rays (<= 8192 rows) == the k_loss_counts launch in front (> 8192 rows): both against a host count.
+(The other cameras' centres written by k_coarse_z inside vipnerf_train_step: tests/test_hip_step.py.)
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'vip-nerf_amd'), os.path.join(ROOT, 'vip-nerf_amd', 'src'), os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from oracle import vipnerf_oracle as vo  # noqa: E402  (synthetic batches / initial weights only)
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16', 'fp16x3'])
+def test_pack_two_mlps_in_one_launch(prec):
+    from vipnerf_hip import ops
+    dev = torch.device('cuda:0')
+    params = vo.init_params(61, scale=1.3)
+    pc = [torch.from_numpy(params['coarse_model.' + n]).to(dev) for n in ops.PARAM_ORDER]
+    pf = [torch.from_numpy(params['fine_model.' + n]).to(dev) for n in ops.PARAM_ORDER]
+    cfg = ops.make_config(True, 64, 128, 1, True, precision=ops.PRECISIONS[prec])
+    a, b = ops.pack_weights2(pc, pf, cfg)
+    assert torch.equal(a.view(torch.int32), ops.pack_weights(pc, cfg=cfg).view(torch.int32))
+    assert torch.equal(b.view(torch.int32), ops.pack_weights(pf, cfg=cfg).view(torch.int32))
+    assert not torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+def _step_inputs(dev, scene, n, n_sparse, it):
+    import test_hip_parity as tp
+    nf = {'fern': 2, 'realestate': 3, 'dtu': 3}[scene]
+    b = vo.synthetic_batch(n, 71, scene=scene, nf=nf, n_sparse=n_sparse)
+    model, cfg = tp.make_model(dev, b['ndc'], vo.init_params(72, scale=1.6), sparse=n_sparse > 0)
+    model.train()
+    return model, cfg, tp.ref_batch(b, dev, it)
+
+
+@pytest.mark.parametrize('scene,n,n_sparse,it', [('fern', 96, 0, 40000), ('fern', 64, 0, 10), ('realestate', 48, 48, 40000), ('dtu', 40, 0, 31000)])
+def test_total_loss_from_the_loss_kernels_equals_the_torch_arithmetic(scene, n, n_sparse, it):
+    """LossComputerHip (new: FusedLossTotalFunction) against the loss vector x weights evaluated with PyTorch as round 5 did (fused_loss_vector,
+    torch.dot, pair sums): TotalLoss to rounding (torch.dot's order is its own), the per-loss values and EVERY parameter gradient bit for bit
+    (the backward factors are (1.0 x weight) x seed either way)."""
+    from loss_functions.FusedLossesHip01 import VECTOR_ATTR, fused_loss_vector
+    from loss_functions.LossComputerHip01 import LossComputerHip
+    dev = torch.device('cuda:0')
+    model, cfg, rb = _step_inputs(dev, scene, n, n_sparse, it)
+    lossc = LossComputerHip(cfg)
+    torch.manual_seed(5)
+    out = model(dict(rb, common_data=dict(rb['common_data'])))
+    new = lossc.compute_losses(rb, out)
+    vec = getattr(out['rgb_coarse'], VECTOR_ATTR)
+    new['TotalLoss'].backward()
+    g_new = [p.grad.clone() for p in model.parameters()]
+    for p in model.parameters():
+        p.grad = None
+    model._last_iter = None
+    torch.manual_seed(5)
+    out2 = model(dict(rb, common_data=dict(rb['common_data'])))
+    v2 = fused_loss_vector(cfg, rb, out2)
+    assert torch.equal(v2.detach(), vec)
+    w8 = torch.zeros(8, device=dev)
+    for name, obj in lossc.losses.items():
+        a, b = obj.FUSED_SLOTS
+        if a == 6 and n_sparse == 0:
+            continue
+        w = float(lossc.get_loss_weight(obj, it))
+        w8[a] = w
+        if b != 7:
+            w8[b] = w
+    total_old = torch.dot(v2, w8)
+    assert abs(float(total_old) - float(new['TotalLoss'])) <= 3e-7 * abs(float(total_old))
+    exact = 0.0                                          # the library's order: k = 0..7, every product and sum rounded to float
+    for k in range(8):
+        exact = np.float32(exact + np.float32(np.float32(w8[k].item()) * np.float32(vec[k].item())))
+    assert np.float32(new['TotalLoss'].item()) == exact
+    pairs = v2.detach().view(4, 2).sum(1)
+    for name, j in (('MSEHip01', 0), ('VisibilityLossHip01', 1), ('VisibilityPriorLossHip01', 2)):
+        assert float(new[name]['loss_value']) == float(pairs[j]), name
+    if n_sparse:
+        assert float(new['SparseDepthMSEHip01']['loss_value']) == float(pairs[3]) > 0
+    total_old.backward()
+    for p, g in zip(model.parameters(), g_new):
+        assert torch.equal(p.grad, g)
+
+
+@pytest.mark.parametrize('n_rows', [8192, 8448])
+def test_mask_counts_inside_the_ray_kernel_and_in_front_of_it(n_rows):
+    """<= 8192 rows: every workgroup of k_loss_rays counts the masks itself; above: the k_loss_counts launch.  MSE / sparse-depth values against
+    the plain definition (means over the mask rows, MSE01.py:55-59, SparseDepthMSE01.py:59-63) on random outputs."""
+    from vipnerf_hip import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(n_rows)
+    n_nerf = n_rows - 1111
+    mask_nerf = (torch.arange(n_rows) < n_nerf)
+    mask_sd = ~mask_nerf
+    tgt, rgb_c, rgb_f = (torch.rand(n_rows, 3, generator=g) for _ in range(3))
+    depth, sd = torch.rand(n_rows, generator=g) * 4, torch.rand(n_rows, generator=g) * 4
+    cfg = ops.make_config(True, 64, 128, 0, False)
+    lvl = lambda S, rgb: {'rgb': rgb.to(dev), 'visibility': torch.rand(n_rows, S, generator=g).to(dev), 'raw_vis': torch.rand(n_rows, S, generator=g).to(dev),
+                          'depth': depth.to(dev)}
+    coarse, fine = lvl(64, rgb_c), lvl(192, rgb_f)
+    vals, sc, sf = ops.losses_forward(cfg, n_rows, tgt.to(dev), mask_nerf.to(dev), None, mask_sd.to(dev), sd.to(dev), coarse, fine)
+    v = vals.cpu().double()
+    for k, rgb in ((0, rgb_c), (1, rgb_f)):
+        ref = ((rgb - tgt)[mask_nerf].double() ** 2).mean()
+        assert abs(v[k] - ref) <= 2e-6 * ref, (k, float(v[k]), float(ref))
+    ref_sd = ((depth - sd)[mask_sd].double() ** 2).mean()
+    assert abs(v[6] - ref_sd) <= 2e-6 * ref_sd
+    # the seeds carry 1 / count: d mse / d rgb = 2 e / (3 n_nerf) on nerf rows, 0 elsewhere
+    s = sf['rgb'].cpu()
+    ref_seed = (2 * (rgb_f - tgt) / (3 * n_nerf)) * mask_nerf[:, None]
+    assert torch.allclose(s, ref_seed, rtol=2e-6, atol=1e-12)
+    assert torch.allclose(sf['depth'].cpu(), (2 * (depth - sd) / 1111) * mask_sd, rtol=2e-6, atol=1e-12)

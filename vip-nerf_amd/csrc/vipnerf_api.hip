@@ -218,6 +218,18 @@ int32_t vipnerf_pack_weights_c(const vipnerf_config *cfg, const vipnerf_mlp_para
     return launch_gen_pack(cfg_topo(cfg), params, (float *)packed, (hipStream_t)stream);
 }
 
+int32_t vipnerf_pack_weights2_c(const vipnerf_config *cfg, const vipnerf_mlp_params *params_a, void *packed_a, const vipnerf_mlp_params *params_b,
+                                void *packed_b, vipnerf_stream_t stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (cfg_generic(cfg) || precision_retired(cfg->precision)) {          // generic topologies: one launch per MLP as before
+        if ((rc = vipnerf_pack_weights_c(cfg, params_a, packed_a, stream))) return rc;
+        return vipnerf_pack_weights_c(cfg, params_b, packed_b, stream);
+    }
+    if ((rc = check_pack_args(params_a, packed_a)) || (rc = check_pack_args(params_b, packed_b))) return rc;
+    return launch_pack_bf16n(params_a, cfg->precision, packed_a, (hipStream_t)stream, params_b, packed_b);
+}
+
 int32_t vipnerf_query_workspace(const vipnerf_config *cfg, int64_t n_rays, size_t *acts_bytes, size_t *bwd_bytes) {
     int rc = check_cfg(cfg);
     if (rc) return rc;
@@ -305,9 +317,19 @@ int32_t vipnerf_composite(const vipnerf_config *cfg, const vipnerf_rays *rays, i
     return launch_composite(a, (hipStream_t)stream);
 }
 
+static int32_t render_forward_impl(const vipnerf_config *cfg, const vipnerf_rays *rays, const vipnerf_rng *rng,
+                                   const void *packed_coarse, const void *packed_fine,
+                                   const vipnerf_outputs *out, void *acts, vipnerf_stream_t stream, const SecOriginArgs *so);
+
 int32_t vipnerf_render_forward(const vipnerf_config *cfg, const vipnerf_rays *rays, const vipnerf_rng *rng,
                                const void *packed_coarse, const void *packed_fine,
                                const vipnerf_outputs *out, void *acts, vipnerf_stream_t stream) {
+    return render_forward_impl(cfg, rays, rng, packed_coarse, packed_fine, out, acts, stream, nullptr);
+}
+
+static int32_t render_forward_impl(const vipnerf_config *cfg, const vipnerf_rays *rays, const vipnerf_rng *rng,
+                                   const void *packed_coarse, const void *packed_fine,
+                                   const vipnerf_outputs *out, void *acts, vipnerf_stream_t stream, const SecOriginArgs *so) {
     int rc = check_cfg(cfg);
     if (rc) return rc;
     if ((rc = check_rays(cfg, rays))) return rc;
@@ -330,7 +352,7 @@ int32_t vipnerf_render_forward(const vipnerf_config *cfg, const vipnerf_rays *ra
     {
         ProfScope ps("coarse_z", st);
         rc = launch_coarse_z(N, Sc, cfg->lindisp, rays->near, rays->far, t_rand, perturb && !t_rand, seed, offset, ray_base, ray_ids,
-                             out->coarse.z_vals, st);
+                             out->coarse.z_vals, st, so);
     }
     if (rc) return rc;
 
@@ -529,13 +551,11 @@ static int32_t scale_segments_impl(int32_t n_segs, const vipnerf_scale_seg *segs
 }
 
 int32_t vipnerf_scale_segments(int32_t n_segs, const vipnerf_scale_seg *segs, const float *g, vipnerf_stream_t stream) {
-    if (n_segs > 0 && !g) { set_error("scale_segments: NULL argument"); return VIPNERF_E_ARG; }
     return scale_segments_impl(n_segs, segs, g, nullptr, nullptr, stream);
 }
 
 int32_t vipnerf_scale_segments_w(int32_t n_segs, const vipnerf_scale_seg *segs, const float *g_total, const float *weights,
                                  vipnerf_stream_t stream) {
-    if (n_segs > 0 && (!g_total || !weights)) { set_error("scale_segments_w: g_total (device, 1) and weights (host, 8) are needed"); return VIPNERF_E_ARG; }
     return scale_segments_impl(n_segs, segs, nullptr, g_total, weights, stream);
 }
 
@@ -569,13 +589,18 @@ int32_t vipnerf_train_step(const vipnerf_train_step_args *t, vipnerf_stream_t st
     if (t->poses) {
         if (!t->pixel_id || !t->rays_o2_out || t->rays_o2_out != t->rays->rays_o2) {
             set_error("train_step: poses given, so pixel_id and rays_o2_out (== rays->rays_o2) are needed"); return VIPNERF_E_ARG; }
-        if ((rc = vipnerf_secondary_origins(N, t->n_frames, t->poses, t->pixel_id, t->pixel_id_is_int64, t->rays_o2_out, stream))) return rc;
+        if (t->n_frames < 1 || t->n_frames > 1 + VIPNERF_MAX_SEC) { set_error("train_step: n_frames=%d", t->n_frames); return VIPNERF_E_ARG; }
     }
+    // (the centres are written by the step's first launch, k_coarse_z: no launch of their own)
+    SecOriginArgs so;
+    memset(&so, 0, sizeof(so));
+    if (t->poses && t->n_frames > 1 && N > 0) { so.poses = t->poses; so.pixel_id = t->pixel_id; so.idx64 = t->pixel_id_is_int64; so.nf = t->n_frames; so.rays_o2 = t->rays_o2_out; }
     // 1. this iteration's weights in fragment order
-    if ((rc = vipnerf_pack_weights_c(cfg, t->params_coarse, t->packed_coarse, stream))) return rc;
-    if (two && (rc = vipnerf_pack_weights_c(cfg, t->params_fine, t->packed_fine, stream))) return rc;
+    if (two) {
+        if ((rc = vipnerf_pack_weights2_c(cfg, t->params_coarse, t->packed_coarse, t->params_fine, t->packed_fine, stream))) return rc;
+    } else if ((rc = vipnerf_pack_weights_c(cfg, t->params_coarse, t->packed_coarse, stream))) return rc;
     // 2. forward, 3. losses
-    if ((rc = vipnerf_render_forward(cfg, t->rays, t->rng, t->packed_coarse, t->packed_fine, t->out, t->acts, stream))) return rc;
+    if ((rc = render_forward_impl(cfg, t->rays, t->rng, t->packed_coarse, t->packed_fine, t->out, t->acts, stream, so.rays_o2 ? &so : nullptr))) return rc;
     if ((rc = vipnerf_losses_forward(cfg, N, t->loss_in, t->out, t->lout, stream))) return rc;
     // 4. d TotalLoss / d outputs = weight of the loss x its unweighted seeds, in place (what autograd does with the five-call path's seeds:
     //    the same segments in the same order through the same kernel), and TotalLoss itself

@@ -481,6 +481,6 @@ template <> struct FragOf<false, true> { typedef f32q type; };
 
 // workgroups of a persistent launch of the 160 KB-of-LDS MLP kernels: one per CU of the current device (queried once)
 int persistent_grid();
-int launch_pack_bf16n(const vipnerf_mlp_params *p, int precision, void *packed_bn, hipStream_t st);   // precision 0 (fp32 narrow) .. 4
+int launch_pack_bf16n(const vipnerf_mlp_params *p, int precision, void *packed_bn, hipStream_t st, const vipnerf_mlp_params *p2 = nullptr, void *packed2 = nullptr);   // precision 0 (fp32 narrow) .. 4
 
 }  // namespace vn

@@ -6,8 +6,8 @@
 namespace vn {
 
 struct PackBnArgs {
-    vipnerf_mlp_params p;
-    uint32_t *out;
+    vipnerf_mlp_params pp[2];         // blockIdx.y selects the MLP: coarse and fine in ONE launch (vipnerf_pack_weights2_c)
+    uint32_t *outs[2];
 };
 
 __device__ __forceinline__ _Float16 split_part_h(float x, int i) {
@@ -31,11 +31,12 @@ __device__ __forceinline__ uint32_t pack2n(float w0, float w1, int part) {
 // F32 (fp32-narrow image): a 32-bit cell is ONE weight -- element e = 4 part + (cell & 3) of the lane's 8-float k-step
 // operand (f32q parts, vipnerf_bf16.h) -- instead of two 16-bit parts of elements e0, e0 + 1.
 template <int NS, bool F16, bool F32 = false>
-__global__ void k_pack_bf16n(PackBnArgs a) {
+__global__ void k_pack_bf16n(PackBnArgs a2) {
     typedef BnPlan<NS> PL;
     constexpr int NU = F32 ? 1 : 2;              // weights per 32-bit cell
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= PL::PK_TOTAL_F) return;
+    const struct { const vipnerf_mlp_params &p; uint32_t *out; } a = {a2.pp[blockIdx.y], a2.outs[blockIdx.y]};
     uint32_t cell = 0;
     if (idx < PL::PK_RES) {
         const bool bwd = idx >= PL::PK_BWD;
@@ -131,19 +132,23 @@ int persistent_grid() {
     return n;
 }
 
-int launch_pack_bf16n(const vipnerf_mlp_params *p, int precision, void *packed_bn, hipStream_t st) {
+// p2 / packed2: a second MLP packed by the same launch (NULL: one)
+int launch_pack_bf16n(const vipnerf_mlp_params *p, int precision, void *packed_bn, hipStream_t st, const vipnerf_mlp_params *p2, void *packed2) {
     PackBnArgs a;
-    a.p = *p;
-    a.out = (uint32_t *)packed_bn;
+    a.pp[0] = *p;
+    a.outs[0] = (uint32_t *)packed_bn;
+    a.pp[1] = p2 ? *p2 : *p;
+    a.outs[1] = (uint32_t *)(p2 ? packed2 : packed_bn);
+    const unsigned ny = p2 ? 2 : 1;
     const int bs = 256;
     if (precision == 0) {
-        hipLaunchKernelGGL((k_pack_bf16n<2, false, true>), dim3((unsigned)((BnPlan<2>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);
+        hipLaunchKernelGGL((k_pack_bf16n<2, false, true>), dim3((unsigned)((BnPlan<2>::PK_TOTAL_F + bs - 1) / bs), ny), dim3(bs), 0, st, a);
     } else if (precision == 3 || precision == 4) {
-        hipLaunchKernelGGL((k_pack_bf16n<2, true>), dim3((unsigned)((BnPlan<2>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);
+        hipLaunchKernelGGL((k_pack_bf16n<2, true>), dim3((unsigned)((BnPlan<2>::PK_TOTAL_F + bs - 1) / bs), ny), dim3(bs), 0, st, a);
     } else if (precision == 5) {
-        hipLaunchKernelGGL((k_pack_bf16n<1, true>), dim3((unsigned)((BnPlan<1>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);
+        hipLaunchKernelGGL((k_pack_bf16n<1, true>), dim3((unsigned)((BnPlan<1>::PK_TOTAL_F + bs - 1) / bs), ny), dim3(bs), 0, st, a);
     } else if (precision == 6) {
-        hipLaunchKernelGGL((k_pack_bf16n<1, false>), dim3((unsigned)((BnPlan<1>::PK_TOTAL_F + bs - 1) / bs)), dim3(bs), 0, st, a);
+        hipLaunchKernelGGL((k_pack_bf16n<1, false>), dim3((unsigned)((BnPlan<1>::PK_TOTAL_F + bs - 1) / bs), ny), dim3(bs), 0, st, a);
     } else {
         set_error("pack_bf16n: precision %d", precision);
         return VIPNERF_E_ARG;

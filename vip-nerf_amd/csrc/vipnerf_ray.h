@@ -45,9 +45,12 @@ struct LossArgs {
     float *total, *named;
 };
 
+struct SecOriginArgs {                // k_coarse_z's side job in vipnerf_train_step: the other cameras' centres per row (rays_o2 == NULL: none)
+    const float *poses; const void *pixel_id; int idx64, nf; float *rays_o2;
+};
 int launch_coarse_z(int64_t N, int S, int lindisp, const float *near, const float *far, const float *t_rand,
                     int device_rng, uint64_t seed, uint64_t offset, uint64_t ray_base, const int64_t *ray_ids, float *z_out,
-                    hipStream_t st);
+                    hipStream_t st, const SecOriginArgs *so = nullptr);
 int launch_composite(const CompositeArgs &a, hipStream_t st);
 int launch_composite_bwd(const CompositeBwdArgs &a, hipStream_t st);
 int launch_sample_fine(const SampleArgs &a, hipStream_t st);

@@ -19,13 +19,20 @@ __device__ __forceinline__ float linspace01(int i, int n) {
 
 // ------------------------------------------------------------------------------------------- coarse depths
 // VipNeRF.get_z_vals_coarse (VipNeRF01.py:173-203)
+// so (vipnerf_train_step): the ray's first 3 (nf - 1) sample threads also write the centres of the OTHER cameras of its row (k_secondary_origins' values:
+// VipNeRF01.py:88-98) -- the step's first launch does both jobs.
 __global__ void k_coarse_z(int64_t N, int S, int lindisp, const float *near, const float *far,
                            const float *t_rand, int device_rng, uint64_t seed, uint64_t offset, uint64_t ray_base,
-                           const int64_t *ray_ids, float *z_out) {
+                           const int64_t *ray_ids, float *z_out, SecOriginArgs so) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * S) return;
     const int64_t n = idx / S;
     const int k = (int)(idx % S);
+    if (so.rays_o2 && k < 3 * (so.nf - 1)) {
+        const int v = k / 3, c = k % 3;
+        const int f = so.idx64 ? (int)((const int64_t *)so.pixel_id)[3 * n] : (int)((const int32_t *)so.pixel_id)[3 * n];
+        so.rays_o2[3 * (n * (so.nf - 1) + v) + c] = so.poses[(size_t)(v + (v >= f ? 1 : 0)) * 16 + 3 + 4 * c];
+    }
     const float nr = near[n], fr = far[n];
     auto zk = [&](int i) {
         const float t = linspace01(i, S);
@@ -406,18 +413,22 @@ int launch_sample_fine(const SampleArgs &a, hipStream_t st) {
 
 int launch_coarse_z(int64_t N, int S, int lindisp, const float *near, const float *far, const float *t_rand,
                     int device_rng, uint64_t seed, uint64_t offset, uint64_t ray_base, const int64_t *ray_ids, float *z_out,
-                    hipStream_t st) {
+                    hipStream_t st, const SecOriginArgs *so) {
     if (N <= 0) return VIPNERF_OK;
+    if (so && so->rays_o2 && 3 * (so->nf - 1) > S) { set_error("coarse_z: %d secondary views need %d sample threads per ray, S = %d", so->nf - 1, 3 * (so->nf - 1), S); return VIPNERF_E_ARG; }
     const int64_t tot = N * S;
+    const SecOriginArgs s0 = {nullptr, nullptr, 0, 0, nullptr};
     hipLaunchKernelGGL(k_coarse_z, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, S, lindisp, near, far,
-                       t_rand, device_rng, seed, offset, ray_base, ray_ids, z_out);
+                       t_rand, device_rng, seed, offset, ray_base, ray_ids, z_out, so ? *so : s0);
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;
 }
 
 // ------------------------------------------------------------------------------------------- fused losses
 // MSE01 / VisibilityLoss01 / VisibilityPriorLoss01 / SparseDepthMSE01 (src/loss_functions/*.py): values and
-// unweighted gradient seeds.  Three tiny launches: mask counts -> per-ray partials + seeds -> ordered final sum.
+// unweighted gradient seeds.  Two launches up to LOSS_INLINE_COUNT_MAX rows (per-ray partials + seeds with the mask counts taken by every
+// workgroup itself -> ordered final sum), three beyond (a mask-count launch in front).
+constexpr int64_t LOSS_INLINE_COUNT_MAX = 8192;
 __global__ void k_loss_counts(int64_t N, const uint8_t *m_nerf, const uint8_t *m_sd, float *counts) {
     __shared__ float sh[2][16];
     float c0 = 0.f, c1 = 0.f;
@@ -436,11 +447,32 @@ __global__ void k_loss_counts(int64_t N, const uint8_t *m_nerf, const uint8_t *m
 }
 
 // one wave per ray; partial[k*N + n], k: 0 mse_c 1 mse_f 2 vis_c 3 vis_f 4 prior_c 5 prior_f 6 sd
+// COUNT: every workgroup counts the mask rows itself (N <= LOSS_INLINE_COUNT_MAX: a few KB from L2 per workgroup) instead of a k_loss_counts
+// launch in front; the counts are integers below 2^24, so any summation order gives k_loss_counts' floats exactly.  Workgroup 0 leaves them in
+// a.counts for k_loss_final.
+template <bool COUNT>
 __global__ __launch_bounds__(RAY_WG) void k_loss_rays(LossArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t n = (int64_t)blockIdx.x * (RAY_WG / 64) + (threadIdx.x >> 6);
-    if (n >= a.N) return;
-    const float n_m = a.counts[0], n_q = a.counts[1];
+    float n_m, n_q;
+    if (COUNT) {
+        __shared__ float shc[2][RAY_WG / 64];
+        float c0 = 0.f, c1 = 0.f;
+        for (int64_t i = threadIdx.x; i < a.N; i += RAY_WG) {
+            c0 += a.in.mask_nerf ? (a.in.mask_nerf[i] ? 1.f : 0.f) : 1.f;
+            c1 += a.in.mask_sparse ? (a.in.mask_sparse[i] ? 1.f : 0.f) : 0.f;
+        }
+        c0 = wave_sum(c0); c1 = wave_sum(c1);
+        if (lane == 0) { shc[0][threadIdx.x >> 6] = c0; shc[1][threadIdx.x >> 6] = c1; }
+        __syncthreads();
+        n_m = 0.f; n_q = 0.f;
+        for (int i = 0; i < RAY_WG / 64; ++i) { n_m += shc[0][i]; n_q += shc[1][i]; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { a.counts[0] = n_m; a.counts[1] = n_q; }
+        if (n >= a.N) return;
+    } else {
+        if (n >= a.N) return;
+        n_m = a.counts[0]; n_q = a.counts[1];
+    }
     const bool in_m = a.in.mask_nerf ? a.in.mask_nerf[n] != 0 : true;
     const bool in_q = a.in.mask_sparse ? a.in.mask_sparse[n] != 0 : false;
     const int V = a.V;
@@ -588,8 +620,12 @@ int launch_adam_step(int64_t n, float *p, float *m, float *v, const float *g, fl
 
 int launch_losses(const LossArgs &a, hipStream_t st) {
     if (a.N <= 0) return VIPNERF_OK;
-    hipLaunchKernelGGL(k_loss_counts, dim3(1), dim3(1024), 0, st, a.N, a.in.mask_nerf, a.in.mask_sparse, a.counts);
-    hipLaunchKernelGGL(k_loss_rays, dim3((unsigned)((a.N + 3) / 4)), dim3(RAY_WG), 0, st, a);
+    if (a.N <= LOSS_INLINE_COUNT_MAX) {
+        hipLaunchKernelGGL(k_loss_rays<true>, dim3((unsigned)((a.N + 3) / 4)), dim3(RAY_WG), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(k_loss_counts, dim3(1), dim3(1024), 0, st, a.N, a.in.mask_nerf, a.in.mask_sparse, a.counts);
+        hipLaunchKernelGGL(k_loss_rays<false>, dim3((unsigned)((a.N + 3) / 4)), dim3(RAY_WG), 0, st, a);
+    }
     hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(1024), 0, st, a);
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;

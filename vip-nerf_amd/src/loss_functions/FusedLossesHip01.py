@@ -20,6 +20,7 @@ except ImportError:
 from vipnerf_hip import ops
 from vipnerf_hip.autograd import FusedLossFunction, FusedLossTotalFunction
 
+VECTOR_ATTR = '_vipnerf_hip_loss_vector'      # attribute of output_dict['rgb_coarse'] after fused_loss_total: the (8,) loss vector, detached
 CACHE_ATTR = '_vipnerf_hip_fused_losses'     # attribute of output_dict['rgb_coarse']: (vector (8,), its unbind() tuple)
 
 
@@ -71,7 +72,9 @@ def fused_loss_total(configs: dict, input_dict: dict, output_dict: dict, weights
     LossComputer.compute_losses evaluated by the loss kernels themselves (FusedLossTotalFunction; weights8 = this iteration's weight of
     every slot of the loss vector).  No PyTorch arithmetic, forward or backward."""
     cfg, n, loss_in, levels = _loss_inputs(configs, input_dict, output_dict)
-    return FusedLossTotalFunction.apply(cfg, n, [float(w) for w in weights8], *loss_in, *levels)
+    res = FusedLossTotalFunction.apply(cfg, n, [float(w) for w in weights8], *loss_in, *levels)
+    setattr(output_dict['rgb_coarse'], VECTOR_ATTR, res[1])      # (for whoever wants the eight raw values: tests, diagnostics; no graph attached)
+    return res
 
 
 def fused_loss_vector(configs: dict, input_dict: dict, output_dict: dict):

@@ -8,7 +8,7 @@ import os
 
 VIPNERF_MAX_SEC = 3
 VIPNERF_N_PARAMS = 24
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VIPNERF_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libvipnerf_hip.so')
@@ -143,6 +143,7 @@ SYMBOLS = {
     'vipnerf_pack_weights_p': (C.c_int32, [P(MlpParams), C.c_int32, c_f, c_f]),
     'vipnerf_packed_weights_bytes_c': (C.c_size_t, [P(Config)]),
     'vipnerf_pack_weights_c': (C.c_int32, [P(Config), P(MlpParams), c_f, c_f]),
+    'vipnerf_pack_weights2_c': (C.c_int32, [P(Config), P(MlpParams), c_f, P(MlpParams), c_f, c_f]),
     'vipnerf_mlp_forward_p': (C.c_int32, [C.c_int64, C.c_int32, c_f, c_f, c_f, c_f, C.c_float, C.c_int32, c_f, c_f, c_f,
                                           c_f, c_f, c_f]),
     'vipnerf_query_workspace': (C.c_int32, [P(Config), C.c_int64, P(C.c_size_t), P(C.c_size_t)]),

@@ -36,8 +36,10 @@ class RenderFunction(torch.autograd.Function):
         cfg = state.cfg
         two = cfg.n_fine > 0
         n_mlp = len(ops.param_order(ops.topology_of(cfg)))        # tensors per MLP (24 for the default topology)
-        pc = ops.pack_weights(list(params[:n_mlp]), cfg=cfg)
-        pf = ops.pack_weights(list(params[n_mlp:]), cfg=cfg) if two else None
+        if two:                                                   # both MLPs' images by one launch
+            pc, pf = ops.pack_weights2(list(params[:n_mlp]), list(params[n_mlp:]), cfg)
+        else:
+            pc, pf = ops.pack_weights(list(params[:n_mlp]), cfg=cfg), None
         need_bwd = state.grad_enabled and any(ctx.needs_input_grad)   # grad mode as seen by the caller of apply()
         cfg.save_acts = int(need_bwd)
         acts = None

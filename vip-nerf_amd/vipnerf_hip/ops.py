@@ -201,6 +201,35 @@ def pack_weights(params: List[torch.Tensor], out: Optional[torch.Tensor] = None,
     return out
 
 
+def _mlp_struct(params: List[torch.Tensor], topo, keep: list) -> L.MlpParams:
+    names, slots, shapes = param_order(topo), param_slots(topo), param_shapes(topo)
+    if len(params) != len(names):
+        raise L.VipNerfHipError(f'expected {len(names)} parameter tensors for netdepth {topo[0]}, got {len(params)}')
+    mp = L.MlpParams()
+    for t, name, slot, shp in zip(params, names, slots, shapes):
+        if tuple(t.shape) != shp:
+            raise L.VipNerfHipError(f'parameter {name} has shape {tuple(t.shape)}, expected {shp} for topology {topo}')
+        tc = f32c(t)
+        keep.append(tc)
+        mp.p[slot] = _p(tc, name=name)
+    return mp
+
+
+def pack_weights2(params_a: List[torch.Tensor], params_b: List[torch.Tensor], cfg: L.Config):
+    """The coarse and the fine MLP of one configuration packed by ONE launch (vipnerf_pack_weights2_c) -> (image_a, image_b), the images of
+    two pack_weights(cfg=cfg) calls."""
+    lib = L.load()
+    topo, keep = topology_of(cfg), []
+    ma, mb = _mlp_struct(params_a, topo, keep), _mlp_struct(params_b, topo, keep)
+    with on_device(*keep) as dev:
+        nbytes = lib.vipnerf_packed_weights_bytes_c(C.byref(cfg))
+        if nbytes == 0:
+            L.check(-2, 'vipnerf_packed_weights_bytes_c')
+        both = torch.empty(2, nbytes // 4, dtype=torch.float32, device=dev)
+        L.check(lib.vipnerf_pack_weights2_c(C.byref(cfg), C.byref(ma), _p(both[0]), C.byref(mb), _p(both[1]), _stream(dev)), 'vipnerf_pack_weights2_c')
+    return both[0], both[1]
+
+
 def query_workspace(cfg: L.Config, n_rays: int):
     a, b = C.c_size_t(0), C.c_size_t(0)
     L.check(L.load().vipnerf_query_workspace(C.byref(cfg), n_rays, C.byref(a), C.byref(b)), 'vipnerf_query_workspace')

@@ -359,17 +359,7 @@ static int32_t render_forward_impl(const vipnerf_config *cfg, const vipnerf_rays
     for (int lv = 0; lv < (Sf > 0 ? 2 : 1); ++lv) {
         const vipnerf_level_out &L = lv ? out->fine : out->coarse;
         const int S = lv ? Sc + Sf : Sc;
-        if (lv == 1 && !cfg->given_z_fine) {
-            // 4. importance sampling + sorted merge
-            SampleArgs sa;
-            memset(&sa, 0, sizeof(sa));
-            sa.N = N; sa.Sc = Sc; sa.Sf = Sf; sa.z_coarse = out->coarse.z_vals; sa.w_coarse = out->coarse.weights;
-            sa.u = (perturb && rng) ? rng->u : nullptr;
-            sa.device_rng = perturb && !sa.u; sa.seed = seed; sa.offset = offset; sa.ray_base = ray_base; sa.ray_ids = ray_ids;
-            sa.z_fine = L.z_vals; sa.inds = out->sample_inds; sa.z_samples = out->z_samples;
-            ProfScope ps("sample_fine", st);
-            if ((rc = launch_sample_fine(sa, st))) return rc;
-        }
+        // (4. importance sampling + sorted merge: in the coarse level's compositing launch, below)
         // 2./5. MLP
         MlpFwdArgs ma;
         memset(&ma, 0, sizeof(ma));
@@ -402,6 +392,18 @@ static int32_t render_forward_impl(const vipnerf_config *cfg, const vipnerf_rays
         memset(&ca, 0, sizeof(ca));
         ca.N = N; ca.S = S; ca.V = V; ca.ndc = cfg->ndc; ca.white_bkgd = cfg->white_bkgd;
         ca.rays_o = rays->rays_o; ca.rays_d = rays->rays_d; ca.rays_d_s = rays->rays_d_s; ca.lvl = L;
+        if (lv == 0 && Sf > 0 && !cfg->given_z_fine) {
+            // 3. + 4. the coarse level's compositing AND the importance sampling + sorted merge its weights feed, one launch
+            SampleArgs sa;
+            memset(&sa, 0, sizeof(sa));
+            sa.N = N; sa.Sc = Sc; sa.Sf = Sf; sa.z_coarse = out->coarse.z_vals; sa.w_coarse = out->coarse.weights;
+            sa.u = (perturb && rng) ? rng->u : nullptr;
+            sa.device_rng = perturb && !sa.u; sa.seed = seed; sa.offset = offset; sa.ray_base = ray_base; sa.ray_ids = ray_ids;
+            sa.z_fine = out->fine.z_vals; sa.inds = out->sample_inds; sa.z_samples = out->z_samples;
+            ProfScope ps("composite", st);
+            if ((rc = launch_composite_sample(ca, sa, st))) return rc;
+            continue;
+        }
         ProfScope ps("composite", st);
         if ((rc = launch_composite(ca, st))) return rc;
     }
@@ -490,8 +492,10 @@ int32_t vipnerf_render_backward(const vipnerf_config *cfg, const vipnerf_rays *r
     return VIPNERF_OK;
 }
 
+// defer: the final sums are NOT launched; *defer receives the arguments for whoever carries them (vipnerf_train_step: its seeds x weights launch)
 static int32_t losses_forward_impl(const vipnerf_config *cfg, int64_t n_rays, const vipnerf_loss_in *in, const vipnerf_outputs *out,
-                                   const vipnerf_loss_out *lout, const float *weights, float *total, float *named, vipnerf_stream_t stream) {
+                                   const vipnerf_loss_out *lout, const float *weights, float *total, float *named, vipnerf_stream_t stream,
+                                   LossArgs *defer = nullptr) {
     int rc = check_cfg(cfg);
     if (rc) return rc;
     if (!in || !out || !lout || !in->target_rgb || !lout->loss_values || !lout->scratch) {
@@ -513,8 +517,9 @@ static int32_t losses_forward_impl(const vipnerf_config *cfg, int64_t n_rays, co
         for (int k = 0; k < 8; ++k) a.w[k] = weights[k];
         a.total = total; a.named = named;
     }
+    if (defer) *defer = a;
     ProfScope ps("losses", (hipStream_t)stream);
-    return launch_losses(a, (hipStream_t)stream);
+    return launch_losses(a, (hipStream_t)stream, defer != nullptr);
 }
 
 int32_t vipnerf_losses_forward(const vipnerf_config *cfg, int64_t n_rays, const vipnerf_loss_in *in,
@@ -601,14 +606,15 @@ int32_t vipnerf_train_step(const vipnerf_train_step_args *t, vipnerf_stream_t st
     } else if ((rc = vipnerf_pack_weights_c(cfg, t->params_coarse, t->packed_coarse, stream))) return rc;
     // 2. forward, 3. losses
     if ((rc = render_forward_impl(cfg, t->rays, t->rng, t->packed_coarse, t->packed_fine, t->out, t->acts, stream, so.rays_o2 ? &so : nullptr))) return rc;
-    if ((rc = vipnerf_losses_forward(cfg, N, t->loss_in, t->out, t->lout, stream))) return rc;
+    LossArgs la;
+    if ((rc = losses_forward_impl(cfg, N, t->loss_in, t->out, t->lout, t->loss_weights, t->total_loss, nullptr, stream, &la))) return rc;
     // 4. d TotalLoss / d outputs = weight of the loss x its unweighted seeds, in place (what autograd does with the five-call path's seeds:
     //    the same segments in the same order through the same kernel), and TotalLoss itself
     const int V = cfg->n_sec, Sc = cfg->n_coarse, Sf = cfg->n_coarse + cfg->n_fine;
     ScaleArgs sa;
     memset(&sa, 0, sizeof(sa));
     for (int k = 0; k < 8; ++k) sa.w[k] = t->loss_weights[k];
-    sa.loss_values = t->lout->loss_values; sa.total = t->total_loss;
+    // (TotalLoss and the loss values' final sums: loss_final_body, carried by the same launch -- `la` above; the seeds x weights do not depend on them)
     vipnerf_out_grads og;
     memset(&og, 0, sizeof(og));
     for (int lv = 0; lv < (two ? 2 : 1); ++lv) {
@@ -627,7 +633,7 @@ int32_t vipnerf_train_step(const vipnerf_train_step_args *t, vipnerf_stream_t st
     }
     if (N > 0) {
         ProfScope ps("losses_bwd", (hipStream_t)stream);
-        if ((rc = launch_scale_segments(sa, (hipStream_t)stream))) return rc;
+        if ((rc = launch_scale_segments(sa, (hipStream_t)stream, &la))) return rc;
     }
     // 5. backward
     if ((rc = vipnerf_render_backward(cfg, t->rays, t->packed_coarse, t->packed_fine, t->out, &og, t->acts, t->bwd_ws, t->grads_coarse,

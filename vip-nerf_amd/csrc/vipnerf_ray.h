@@ -54,7 +54,9 @@ int launch_coarse_z(int64_t N, int S, int lindisp, const float *near, const floa
 int launch_composite(const CompositeArgs &a, hipStream_t st);
 int launch_composite_bwd(const CompositeBwdArgs &a, hipStream_t st);
 int launch_sample_fine(const SampleArgs &a, hipStream_t st);
-int launch_losses(const LossArgs &a, hipStream_t st);
+int launch_composite_sample(const CompositeArgs &c, const SampleArgs &a, hipStream_t st);      // the coarse level's compositing + the sampling it feeds, one launch
+int launch_losses(const LossArgs &a, hipStream_t st, bool defer_final = false);
+struct LossFinalTail { LossArgs a; };
 struct ScaleArgs {
     vipnerf_scale_seg s[VIPNERF_MAX_SCALE_SEGS];
     int n;
@@ -64,7 +66,7 @@ struct ScaleArgs {
     const float *loss_values;         // with total: total[0] = sum_k w[k] * loss_values[k] (fixed order, block (0, 0) thread 0)
     float *total;
 };
-int launch_scale_segments(const ScaleArgs &a, hipStream_t st);
+int launch_scale_segments(const ScaleArgs &a, hipStream_t st, const LossArgs *fin = nullptr);
 int launch_adam_step(int64_t n, float *p, float *m, float *v, const float *g, float lerp_w, float beta2, float sq_w, float inv_s, float eps,
                      float neg_step, int mask, hipStream_t st);
 

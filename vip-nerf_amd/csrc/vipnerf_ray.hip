@@ -4,6 +4,7 @@
 // contiguous per wave) and the transmittance product / suffix sums are wavefront scans.
 // These stages are < 1.5 % of the path's work and HBM/latency bound.
 #include "vipnerf_ray.h"
+#include <cstring>
 
 namespace vn {
 
@@ -62,10 +63,7 @@ __device__ __forceinline__ float metric_depth(float z_ndc, float oz, float dz) {
 }
 
 template <int IPL>
-__global__ __launch_bounds__(RAY_WG) void k_composite(CompositeArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int64_t n = (int64_t)blockIdx.x * (RAY_WG / 64) + (threadIdx.x >> 6);
-    if (n >= a.N) return;
+__device__ __forceinline__ void composite_body(const CompositeArgs &a, int64_t n, int lane) {
     const int S = a.S, V = a.V;
     const int k0 = lane * IPL;
     const float *zr = a.lvl.z_vals + n * S, *sg = a.lvl.raw_sigma + n * S;
@@ -142,6 +140,13 @@ __global__ __launch_bounds__(RAY_WG) void k_composite(CompositeArgs a) {
         }
         for (int v = 0; v < V; ++v) a.lvl.vis2[n * V + v] = __fdiv_rn(s_v2[v], den);
     }
+}
+template <int IPL>
+__global__ __launch_bounds__(RAY_WG) void k_composite(CompositeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * (RAY_WG / 64) + (threadIdx.x >> 6);
+    if (n >= a.N) return;
+    composite_body<IPL>(a, n, lane);
 }
 
 int launch_composite(const CompositeArgs &a, hipStream_t st) {
@@ -273,10 +278,7 @@ int launch_composite_bwd(const CompositeBwdArgs &a, hipStream_t st) {
 // ------------------------------------------------------------------------------------------- importance sampling
 // VipNeRF.get_z_vals_fine + sample_pdf (VipNeRF01.py:205-262).  One wave per ray; LDS per wave:
 // cdf[Sc-1], bins[Sc-1], merged values [Sc+Sf].
-__global__ __launch_bounds__(RAY_WG) void k_sample_fine(SampleArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sl[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t n = (int64_t)blockIdx.x * (RAY_WG / 64) + wv;
+__device__ __forceinline__ void sample_fine_body(const SampleArgs &a, float *sl, int lane, int wv, int64_t n) {
     const int Sc = a.Sc, Sf = a.Sf, NB = Sc - 1, NW = Sc - 2, ST = Sc + Sf;
     float *cdf = sl + wv * (2 * NB + ST), *bins = cdf + NB, *vals = bins + NB;
     const bool live = n < a.N;
@@ -401,12 +403,44 @@ __global__ __launch_bounds__(RAY_WG) void k_sample_fine(SampleArgs a) {
         if (live) a.z_fine[n * ST + rank] = v;
     }
 }
+__global__ __launch_bounds__(RAY_WG) void k_sample_fine(SampleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sl[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    sample_fine_body(a, sl, lane, wv, (int64_t)blockIdx.x * (RAY_WG / 64) + wv);
+}
+// The coarse level's compositing and the importance sampling it feeds in ONE launch: a wave composites its ray (k_composite's body), then samples from the
+// weights it has just written (k_sample_fine's body; both are one wave per ray with no cross-wave step).  The same values as the two launches.
+template <int IPL>
+__global__ __launch_bounds__(RAY_WG) void k_composite_sample(CompositeArgs c, SampleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sl[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * (RAY_WG / 64) + wv;
+    if (n < c.N) composite_body<IPL>(c, n, lane);
+    __threadfence_block();                        // the ray's weights: stored above by the lanes of this wave, read below by other lanes of it
+    __builtin_amdgcn_wave_barrier();
+    sample_fine_body(a, sl, lane, wv, n);
+}
 
 int launch_sample_fine(const SampleArgs &a, hipStream_t st) {
     if (a.N <= 0) return VIPNERF_OK;
     const unsigned grid = (unsigned)((a.N + 3) / 4);
     const size_t lds = (size_t)4 * (2 * (a.Sc - 1) + a.Sc + a.Sf) * sizeof(float);
     hipLaunchKernelGGL(k_sample_fine, dim3(grid), dim3(RAY_WG), lds, st, a);
+    VN_HIP(hipGetLastError());
+    return VIPNERF_OK;
+}
+int launch_composite_sample(const CompositeArgs &c, const SampleArgs &a, hipStream_t st) {
+    if (a.N <= 0) return VIPNERF_OK;
+    if (c.N != a.N || c.S != a.Sc || c.lvl.weights != a.w_coarse || c.lvl.z_vals != a.z_coarse) { set_error("composite_sample: the two stages disagree"); return VIPNERF_E_ARG; }
+    const unsigned grid = (unsigned)((a.N + 3) / 4);
+    const size_t lds = (size_t)4 * (2 * (a.Sc - 1) + a.Sc + a.Sf) * sizeof(float);
+    switch ((c.S + 63) / 64) {
+        case 1: hipLaunchKernelGGL(k_composite_sample<1>, dim3(grid), dim3(RAY_WG), lds, st, c, a); break;
+        case 2: hipLaunchKernelGGL(k_composite_sample<2>, dim3(grid), dim3(RAY_WG), lds, st, c, a); break;
+        case 3: hipLaunchKernelGGL(k_composite_sample<3>, dim3(grid), dim3(RAY_WG), lds, st, c, a); break;
+        case 4: hipLaunchKernelGGL(k_composite_sample<4>, dim3(grid), dim3(RAY_WG), lds, st, c, a); break;
+        default: set_error("composite: n_samples %d > 256", c.S); return VIPNERF_E_UNSUPPORTED;
+    }
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;
 }
@@ -528,20 +562,25 @@ __global__ __launch_bounds__(RAY_WG) void k_loss_rays(LossArgs a) {
     }
 }
 
-// ordered reduction of the 7 partial arrays (one workgroup; fixed order -> deterministic)
-__global__ void k_loss_final(LossArgs a) {
-    __shared__ float sh[16];
+// ordered reduction of the 7 partial arrays by ONE workgroup of 1024 / NV threads, each standing for NV of k_loss_final's 1024 threads (thread t + r * blockDim.x
+// is its r-th): the same partial sums, folded in the same order, whatever the launch that carries it -- the values are k_loss_final's bit for bit
+template <int NV>
+__device__ __forceinline__ void loss_final_body(const LossArgs &a, float *sh) {
+    const int nthr = 1024 / NV;                                     // == blockDim.x
     for (int k = 0; k < 7; ++k) {
-        float s = 0.f;
         const bool used = (k == 6) || ((k & 1) < a.n_levels);
-        if (used)
-            for (int64_t i = threadIdx.x; i < a.N; i += blockDim.x) s += a.partial[(size_t)k * a.N + i];
-        s = wave_sum(s);
-        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+#pragma unroll
+        for (int r = 0; r < NV; ++r) {
+            float s = 0.f;
+            if (used)
+                for (int64_t i = threadIdx.x + r * nthr; i < a.N; i += 1024) s += a.partial[(size_t)k * a.N + i];
+            s = wave_sum(s);
+            if ((threadIdx.x & 63) == 0) sh[((threadIdx.x + r * nthr) >> 6)] = s;
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
             float t = 0.f;
-            for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+            for (int i = 0; i < 16; ++i) t += sh[i];
             float dnm;
             if (k < 2 || k == 4 || k == 5) dnm = a.counts[0];       // mean over nerf rays
             else if (k < 4) dnm = (float)a.N;                        // mean over all rays
@@ -561,9 +600,20 @@ __global__ void k_loss_final(LossArgs a) {
             for (int j = 0; j < 4; ++j) a.named[j] = __fadd_rn(a.loss_values[2 * j], a.loss_values[2 * j + 1]);
     }
 }
+__global__ void k_loss_final(LossArgs a) {
+    __shared__ float sh[16];
+    loss_final_body<1>(a, sh);               // launched with 1024 threads
+}
 
 // out_k = g[slot_k] * in_k for all segments in one launch (blockIdx.y = segment): the fused losses' backward
-__global__ void k_scale_segments(ScaleArgs a) {
+// fin (vipnerf_train_step): the workgroups of row blockIdx.y == a.n are not a segment -- the first of them runs the loss values' final sums
+// (loss_final_body: k_loss_final's job, which the seeds x weights do not depend on) in THIS launch
+__global__ void k_scale_segments(ScaleArgs a, LossFinalTail fin) {
+    if (blockIdx.y == (unsigned)a.n) {
+        __shared__ float sh[16];
+        if (blockIdx.x == 0) loss_final_body<4>(fin.a, sh);      // (this launch has 256 threads per workgroup)
+        return;
+    }
     const vipnerf_scale_seg sg = a.s[blockIdx.y];
     const float w = a.g ? a.g[sg.slot] : (a.g1 ? __fmul_rn(a.g1[0], a.w[sg.slot]) : a.w[sg.slot]);
     if (a.total && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
@@ -573,13 +623,19 @@ __global__ void k_scale_segments(ScaleArgs a) {
     }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < sg.numel; i += (int64_t)gridDim.x * blockDim.x) sg.out[i] = w * sg.in[i];
 }
-int launch_scale_segments(const ScaleArgs &a, hipStream_t st) {
+int launch_scale_segments(const ScaleArgs &a, hipStream_t st, const LossArgs *fin) {
     int64_t most = 0;
     for (int k = 0; k < a.n; ++k) most = a.s[k].numel > most ? a.s[k].numel : most;
-    if (a.n <= 0 || most <= 0) return VIPNERF_OK;
+    if (a.n <= 0 || most <= 0) {
+        if (fin) { set_error("scale_segments: the loss values' final sums ride in a launch that has nothing to scale"); return VIPNERF_E_ARG; }
+        return VIPNERF_OK;
+    }
     int64_t bx = (most + 1023) / 1024;              // 256 threads x 4 elements each where the segment is that long
     if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(k_scale_segments, dim3((unsigned)bx, (unsigned)a.n), dim3(256), 0, st, a);
+    LossFinalTail tail;
+    memset((void *)&tail, 0, sizeof(tail));
+    if (fin) tail.a = *fin;
+    hipLaunchKernelGGL(k_scale_segments, dim3((unsigned)bx, (unsigned)(a.n + (fin ? 1 : 0))), dim3(256), 0, st, a, tail);
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;
 }
@@ -618,7 +674,8 @@ int launch_adam_step(int64_t n, float *p, float *m, float *v, const float *g, fl
     return VIPNERF_OK;
 }
 
-int launch_losses(const LossArgs &a, hipStream_t st) {
+// defer_final: the caller runs the final sums itself (vipnerf_train_step: inside its seeds x weights launch)
+int launch_losses(const LossArgs &a, hipStream_t st, bool defer_final) {
     if (a.N <= 0) return VIPNERF_OK;
     if (a.N <= LOSS_INLINE_COUNT_MAX) {
         hipLaunchKernelGGL(k_loss_rays<true>, dim3((unsigned)((a.N + 3) / 4)), dim3(RAY_WG), 0, st, a);
@@ -626,7 +683,7 @@ int launch_losses(const LossArgs &a, hipStream_t st) {
         hipLaunchKernelGGL(k_loss_counts, dim3(1), dim3(1024), 0, st, a.N, a.in.mask_nerf, a.in.mask_sparse, a.counts);
         hipLaunchKernelGGL(k_loss_rays<false>, dim3((unsigned)((a.N + 3) / 4)), dim3(RAY_WG), 0, st, a);
     }
-    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(1024), 0, st, a);
+    if (!defer_final) hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(1024), 0, st, a);
     VN_HIP(hipGetLastError());
     return VIPNERF_OK;
 }

@@ -292,6 +292,7 @@ class FusedLossTotalFunction(torch.autograd.Function):
         ctx.seeds, ctx.weights = (sc, sf), [float(w) for w in weights8]
         ctx.present = [t is not None for t in lv]
         ctx.mark_non_differentiable(vals, named)
+        ctx.set_materialize_grads(False)          # (the two value vectors carry no gradient: without this the engine fills a zero tensor for each, every step)
         return total.view(()), vals, named
 
     @staticmethod

@@ -415,7 +415,7 @@ def test_depth_var_cotangents_vs_oracle(dev):
                 assert t.grad is None or float(t.grad.abs().max()) == 0, k
                 continue
             assert float(t.grad.abs().max()) > 0, k
-            tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{scene} depth_var grad {k}')
+            tp.grad_close(t.grad.cpu().numpy(), p[k].grad.numpy(), f'{scene} depth_var grad {k}', l2_tol=1.2e-3)      # measured 5.5e-4 (fern: the variance of NDC depths weights the far samples)
 
 
 # ------------------------------------------------------------------------------------------------ memory-bounded training

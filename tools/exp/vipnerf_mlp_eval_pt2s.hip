@@ -10,8 +10,8 @@
 // How: the 64 KiB weight stages of the image are consumed as two 32 KiB INTERVALS each (a stage is k-step-major, so its halves are k-steps 0-1 and
 // 2-3: no other image), through a ring of four 32 KiB buffers (the same LDS as two 64 KiB ones).  Waves 0-3 ("group 0": one per SIMD) take weight
 // interval s in workgroup interval s, waves 4-7 (their SIMD partners) in workgroup interval s + 1.  Every workgroup interval starts with ONE barrier
-// (all eight waves: counts stay equal through an idle interval at group 1's start and group 0's end); behind it every wave issues 4 of the 32 DMA pieces
-// of weight interval i + 2 into the buffer that barrier freed (last read two intervals ago by group 1).  A layer is four intervals; group 0's epilogue
+// (all eight waves: counts stay equal through an idle interval at group 1's start and group 0's end); the 32 DMA pieces of weight interval i + 2 go into
+// the buffer that barrier freed (last read by group 1, one interval ago), issued by ONE group's four waves BEHIND their MFMAs of the interval (StagStream::late).  A layer is four intervals; group 0's epilogue
 // of layer L opens the interval in which group 1 still multiplies layer L's last quarter, and vice versa one interval later.  gamma(x)'s two zero-padded
 // half stages of the image (k-steps 2-3 of the PE stages: the 64 KiB plan pads K = 64 to a whole stage) are skipped by the stream, not multiplied.
 #include "vipnerf_bf16n.h"
@@ -35,37 +35,61 @@ static_assert(PL::R_TOTAL_PAD + IV_RING * IV_F == PL::LDS_F, "the ring of four 3
 // half stage of the image that weight interval s reads (the second halves of the two gamma(x) stages are zero padding: skipped)
 __device__ __forceinline__ int iv_source(int s) { return s + (s >= IV_L1 ? 1 : 0) + (s >= IV_L6 ? 1 : 0); }
 
+// weight interval s opens a layer (its wave starts the interval with the previous layer's epilogue)
+__device__ __forceinline__ bool iv_opens_layer(int s) {
+    return s >= IV_L1 && (s < IV_L5PE ? ((s - IV_L1) & 3) == 0 : (s >= IV_L6 && ((s - IV_L6) & 3) == 0));
+}
+
 struct StagStream {
     const float *img;       // the forward image (PK_FWD), + lane * 4
     float *ring;
     int iv;                 // workgroup interval about to start (the same number in every wave)
     int lag;                // 0: waves 0-3, 1: waves 4-7 (scalar)
     int wave;
-    __device__ __forceinline__ void issue(int s) {          // this wave's pieces of weight interval s
-        if (s < IV_TOTAL)
-            glds_run<IV_PER_WAVE>(img + (size_t)iv_source(s) * IV_F + (wave * IV_PER_WAVE) * CHUNK_F, ring + (s & (IV_RING - 1)) * IV_F + (wave * IV_PER_WAVE) * CHUNK_F);
+    int younger;            // DMA pieces this wave has issued AFTER its pieces of the weight interval the next open() needs (0, 4 or 8)
+    // pieces [first, first + N) of weight interval s
+    template <int N>
+    __device__ __forceinline__ void issue(int s, int first) {
+        glds_run<N>(img + (size_t)iv_source(s) * IV_F + first * CHUNK_F, ring + (s & (IV_RING - 1)) * IV_F + first * CHUNK_F);
     }
     __device__ __forceinline__ void start(const float *image, float *lds_ring, int lane, int wave_) {
         img = image + lane * 4; ring = lds_ring; iv = 0; wave = wave_;
         lag = __builtin_amdgcn_readfirstlane(wave_ >> 2);
-        issue(0);
-        issue(1);
+        issue<IV_PER_WAVE>(0, wave * IV_PER_WAVE);            // the first two intervals: every wave its eighth
+        issue<IV_PER_WAVE>(1, wave * IV_PER_WAVE);
+        younger = IV_PER_WAVE;
     }
-    // Opens workgroup interval iv: this wave's pieces of weight interval iv have landed (its pieces of iv + 1 -- issued one interval ago -- may still be in
-    // flight: VM_CNT retires in order, the eval kernel has no stores; at the stream's end nothing younger exists: drain), barrier (everybody's pieces have
-    // landed; everybody is done with the buffer of weight interval iv - 2), then the DMA of weight interval iv + 2 into that buffer.
+    // Opens workgroup interval iv.  (1) This wave's pieces of weight interval iv have landed: VM_CNT retires in order and the eval kernel has no stores,
+    // so vmcnt(younger) -- the pieces it issued later, for weight interval iv + 1 -- proves it.  (2) Barrier: everybody's pieces have landed, and
+    // everybody is done with the buffer of weight interval iv - 2 (which late() refills).
     // -> the buffer of THIS wave's weight interval (iv - lag); meaningless in the wave's idle interval.
     __device__ __forceinline__ const float *open() {
         __builtin_amdgcn_sched_barrier(0);
-        if (iv + 1 < IV_TOTAL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IV_PER_WAVE) : "memory");
+        if (younger == 2 * IV_PER_WAVE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IV_PER_WAVE) : "memory");
+        else if (younger == IV_PER_WAVE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IV_PER_WAVE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        issue(iv + 2);
         __builtin_amdgcn_sched_barrier(0);
+        younger = 0;
         const float *mine = ring + ((iv - lag) & (IV_RING - 1)) * IV_F;
         ++iv;
         return mine;
+    }
+    // Behind this wave's MFMAs of the interval open() opened (at once in its idle interval): the DMA of weight interval (that interval + 2) into the
+    // buffer open()'s barrier freed, by the four waves of ONE group, 8 pieces each (~60 cycles of issue per piece).  Which group: the one whose SIMD
+    // partners START the interval with a layer epilogue -- they multiply late, exactly while these waves issue --, group 0 (the older waves: the arbiter
+    // lets them multiply first) where neither does, group 1 in interval 0 (its idle one).
+    __device__ __forceinline__ void late() {
+        const int i = iv - 1;
+        if (i + 2 >= IV_TOTAL) return;
+        const int issuer = i == 0 ? 1 : (iv_opens_layer(i) ? 1 : 0);          // (group 0 opens a layer in interval i: group 1 issues; group 1 does, or nobody: group 0)
+        if (issuer == lag) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue<2 * IV_PER_WAVE>(i + 2, (wave & 3) * 2 * IV_PER_WAVE);
+            younger = 2 * IV_PER_WAVE;
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 };
 }  // namespace
@@ -190,7 +214,7 @@ __global__ __launch_bounds__(PL::WG) void k_mlp_eval_pt2s(MlpFwdArgs a) {
     };
 
     __syncthreads();                         // resident block visible
-    if (ws.lag) ws.open();                   // group 1's idle interval: group 0 multiplies gamma(x) meanwhile
+    if (ws.lag) { ws.open(); ws.late(); }    // group 1's idle interval: group 0 multiplies gamma(x) meanwhile
     // ---------------------------------------------------------------- layer 0: gamma(x) only
     BT bpe_keep[2][NS];
     {
@@ -200,23 +224,44 @@ __global__ __launch_bounds__(PL::WG) void k_mlp_eval_pt2s(MlpFwdArgs a) {
         init_acc(0);
         const float *st = ws.open();
         gemm_stage_bf<16, 2, NS>(st, lane, acc, bpe, 0, none);
-        epilogue(0);
+        ws.late();
     }
-    // ---------------------------------------------------------------- layers 1..7 + feature layer (8): four intervals of two k-steps each
+    // ---------------------------------------------------------------- layers 1..7 + feature layer (8): four intervals of two k-steps each.  A layer's
+    // epilogue runs BEHIND the barrier that opens the next layer's first interval: the SIMD partner -- one interval behind or ahead -- multiplies meanwhile
 #pragma unroll 1
     for (int layer = 1; layer < 9; ++layer) {
-        init_acc(layer);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const float *st = ws.open();
+            if (jj == 0) { epilogue(layer - 1); init_acc(layer); }
             gemm_stage_bf<16, 2, NS>(st, lane, acc, bin, 2 * jj, none);
+            ws.late();
         }
         if (layer == SKIP_LAYER) {           // gamma(x) columns last
             const float *st = ws.open();
             gemm_stage_bf<16, 2, NS>(st, lane, acc, bpe_keep, 0, none);
+            ws.late();
         }
-        epilogue(layer);
     }
+    // ---------------------------------------------------------------- view branch: the 256 feature columns once per point (two intervals of four k-steps) ...
+    AT vb[8];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const float *st = ws.open();
+        if (jj == 0) {
+            epilogue(8);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float4 b4 = *(const float4 *)(rf + PL::N_BVIEW + 16 * t + 4 * q);
+                const floatx4 b = {b4.x, b4.y, b4.z, b4.w};
+                vb[t].v[0] = b; vb[t].v[1] = b;
+            }
+        }
+        gemm_stage_bf<8, 4, NS>(st, lane, vb, bin, 4 * jj, none);
+        ws.late();
+    }
+    // group 0's idle interval: its view tail below runs under group 1's last interval.  (Nothing reads the ring after this barrier but group 1.)
+    if (!ws.lag) { ws.open(); ws.late(); }
 
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
@@ -226,22 +271,6 @@ __global__ __launch_bounds__(PL::WG) void k_mlp_eval_pt2s(MlpFwdArgs a) {
         const float sgm = relu_lo<true>(__fadd_rn(sigma_raw[pt], __fmul_rn(nz, a.ns.std)), 0.f);
         if (valid[pt] && q == 0) a.sigma[p[pt]] = sgm;
     }
-
-    // ---------------------------------------------------------------- view branch: the 256 feature columns once per point (two intervals of four k-steps) ...
-    AT vb[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const float4 b4 = *(const float4 *)(rf + PL::N_BVIEW + 16 * t + 4 * q);
-        const floatx4 b = {b4.x, b4.y, b4.z, b4.w};
-        vb[t].v[0] = b; vb[t].v[1] = b;
-    }
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const float *st = ws.open();
-        gemm_stage_bf<8, 4, NS>(st, lane, vb, bin, 4 * jj, none);
-    }
-    // group 0's idle interval: its view tail below runs under group 1's last interval.  (Nothing reads the ring after this barrier but group 1.)
-    if (!ws.lag) ws.open();
 
     // ... then per point tile and direction a K = 32 GEMM from the LDS-resident direction columns, ReLU, the 128 -> 4 head
 #pragma unroll 1
@@ -312,11 +341,10 @@ static int launch_eval(const MlpFwdArgs &a, hipStream_t st) {
     return VIPNERF_OK;
 }
 
-// eval only (a.acts == NULL); a.packed: the narrow single-part image of the precision (VIPNERF_PREC_FP16 = 5 / BF16 = 6)
+// eval only (a.acts == NULL), bf16 only (see launch_mlp_fwd_pt2); a.packed: the narrow single-part image of VIPNERF_PREC_BF16
 int launch_mlp_eval_pt2s(const MlpFwdArgs &a, int precision, hipStream_t st) {
     if (a.src.P <= 0) return VIPNERF_OK;
     if (a.acts) { set_error("mlp_eval_pt2s: the staggered kernel is the eval form (no activation store)"); return VIPNERF_E_ARG; }
-    if (precision == VIPNERF_PREC_FP16) return launch_eval<true>(a, st);
     if (precision == VIPNERF_PREC_BF16) return launch_eval<false>(a, st);
     set_error("mlp_eval_pt2s: precision %d", precision);
     return VIPNERF_E_ARG;

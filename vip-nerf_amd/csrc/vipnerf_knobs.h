@@ -15,7 +15,7 @@
     X(VN_STORE_GROUP_A) X(VN_STORE_GROUP_B) X(VN_F32_PERSISTENT) X(VN_F32_EVAL_ROTATE) X(VN_F32B_CONV_GROUP) X(VN_DMA_ROT_WAVES) X(VN_F32_DMA_ISSUERS)                                                              \
     /* single-MFMA 16-bit modes: storage and the two-point-tile kernels (vipnerf_bf16n.h, vipnerf_mlp_pt2.h, vipnerf_mlp_*_pt2.hip) */    \
     X(VN_BF16_H16) X(VN_T16) X(VN_T16_X4) X(VN_T16_NT) X(VN_PT2_SPREAD) X(VN_PT2_SKEW) X(VN_PT2_G) X(VN_PT2_D)                  \
-    X(VN_PT2_TRAIN_KEEP) X(VN_PT2_EVAL_KEEP) X(VN_PT2_FAST_PE) X(VN_PT2_EVAL_STAGGER)                                                                                              \
+    X(VN_PT2_TRAIN_KEEP) X(VN_PT2_EVAL_KEEP) X(VN_PT2_FAST_PE)                                                                                              \
     /* weight gradients (vipnerf_wgrad.hip, vipnerf_wgrad16.hip) */                                                                       \
     X(VN_WGRAD_SIGMA_FUSED) X(VN_WGRAD_VIEW_FUSED) X(VN_WGRAD_HEADS_FUSED) X(VN_WGRAD_LATE_LOAD) X(VN_WGRAD_LATE_STORE) X(VN_WGRAD_STORE_SKEW) X(VN_WGRAD_FAST) X(VN_WGRAD_BIAS_WK0) X(VN_WGRAD_VECFRAG) X(VN_WGRAD_PREFETCH) X(VN_WGRAD_DMA) X(VN_WGRAD_W8) X(VN_WGRAD_PIPE) X(VN_WGRAD_ONE_ROUND) X(VN_WGRAD_ROUNDS) X(VN_WG16_BIG_WM) X(VN_WG16_BIG_WN)        \
     X(VN_WG16_BIG_NB) X(VN_WG16_HYBRID) X(VN_WG16_SIGMA_FUSED) X(VN_WG16_DMA_PIECES) X(VN_WG16_THIN_HYBRID) X(VN_WG16_BIG_SLOTS) X(VN_WG16_VIEW_FUSED) X(VN_WG16_VIEW_WN)          \
@@ -108,9 +108,6 @@
 #endif
 #ifndef VN_PT2_EVAL_KEEP
 #define VN_PT2_EVAL_KEEP 1       // eval: 1 = gamma(x)'s fragments stay in 16 registers from layer 0 to layer 5 (measured: fp16 1023 -> 1080, bf16 1181 -> 1226 TFLOP/s); 0 = evaluated again at layer 5
-#endif
-#ifndef VN_PT2_EVAL_STAGGER
-#define VN_PT2_EVAL_STAGGER 1    // 16-bit eval forward: 1 = k_mlp_eval_pt2s (the two waves of a SIMD one 32 KiB weight interval apart: one's layer epilogue under the other's MFMAs); 0 = k_mlp_fwd_pt2<false, .>
 #endif
 #ifndef VN_PT2_FAST_PE
 #define VN_PT2_FAST_PE 1         // single-MFMA 16-bit kernels: gamma(x), gamma(dir) with v_fract + v_sin_f32 / v_cos_f32 (vipnerf_bf16n.h sincos_rev); 0: sincosf

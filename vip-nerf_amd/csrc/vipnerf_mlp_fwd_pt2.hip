@@ -407,7 +407,6 @@ static int launch_pt2(const MlpFwdArgs &a, hipStream_t st) {
 int launch_mlp_fwd_pt2(const MlpFwdArgs &a, int precision, hipStream_t st) {
     if (a.src.P <= 0) return VIPNERF_OK;
     if (a.acts && a.src.P % 16) { set_error("mlp_fwd: the 16-bit training kernels need a multiple of 16 points (got %lld)", (long long)a.src.P); return VIPNERF_E_UNSUPPORTED; }
-    if (!a.acts && VN_PT2_EVAL_STAGGER) return launch_mlp_eval_pt2s(a, precision, st);      // build switch VN_PT2_EVAL_STAGGER (vipnerf_knobs.h)
     if (precision == VIPNERF_PREC_FP16) return a.acts ? launch_pt2<true, true>(a, st) : launch_pt2<false, true>(a, st);
     if (precision == VIPNERF_PREC_BF16) return a.acts ? launch_pt2<true, false>(a, st) : launch_pt2<false, false>(a, st);
     set_error("mlp_fwd_pt2: precision %d", precision);

@@ -134,6 +134,5 @@ __device__ __forceinline__ unsigned mask_pk16(unsigned w, unsigned a, int i, uns
 
 int launch_mlp_fwd_pt2(const MlpFwdArgs &a, int precision, hipStream_t st);
 int launch_mlp_bwd_pt2(const MlpBwdArgs &a, int precision, hipStream_t st);
-int launch_mlp_eval_pt2s(const MlpFwdArgs &a, int precision, hipStream_t st);      // vipnerf_mlp_eval_pt2s.hip: the eval form with the SIMD partners one weight interval apart
 
 }  // namespace vn

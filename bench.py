@@ -241,7 +241,7 @@ def pmc_reference(prec, rays, workload):
     """HBM bytes per step from the committed rocprofv3 --pmc passes of this very command (profiles/r04_pmc_traffic_<prec>.json;
     counters cannot be collected from inside the process).  Used only when the workload matches the one profiled; the block
     says which file, of which commit and date, it quotes -- the figure goes stale when a kernel changes without re-profiling."""
-    for name in ('r05_pmc_traffic_%s.json' % prec, 'r04_pmc_traffic_%s.json' % prec, 'r03_pmc_traffic_%s.json' % prec):
+    for name in ('r06_pmc_traffic_%s.json' % prec, 'r05_pmc_traffic_%s.json' % prec, 'r04_pmc_traffic_%s.json' % prec, 'r03_pmc_traffic_%s.json' % prec):
         try:
             tr = json.load(open(os.path.join(ROOT, 'profiles', name)))
             if tr['workload']['rays_per_gpu'] == rays and tr['workload']['precision'] == prec and tr['workload'].get('scene', 'fern') == workload:
@@ -629,14 +629,13 @@ def main():
             the same on every rank) against the gradient of the whole global batch computed locally by every rank (vdist.verify_sharded_gradient)."""
             self.model.configs['model']['hip_precision'] = precision
             gb = make_batch(self.gen, self.rays * world, 777, n_sparse=self.n_sparse * world)
-            # one rank per device (the real thing): the whole-batch pass keeps its activations if they fit, else re-renders in chunks (autograd.py).
-            # Ranks SHARING a device (the one-GPU tests of this path) would each size their workspace by the memory that is free "right now" and
-            # run out together: each gets an equal share of half the device instead
+            # The whole-batch pass (world x rays rows on EVERY rank) runs through the re-rendering backward in chunks of <= 8192 rays (autograd.py:
+            # the path tests/test_hip_fullsize.py holds at 65,536 rays) under a workspace cap, instead of keeping 5.4 MB of activations per ray
+            # for 32,768+ rays at once.  Ranks SHARING a device (the one-GPU tests of this path) each get an equal share of half of it.
             sharing = -(-world // max(torch.cuda.device_count(), 1))
             cap_key, m = 'hip_max_workspace_bytes', self.model.configs['model']
             old_cap = m.get(cap_key)
-            if sharing > 1:
-                m[cap_key] = int(torch.cuda.mem_get_info(dev)[1] // (2 * sharing))
+            m[cap_key] = int(min(48 << 30, torch.cuda.mem_get_info(dev)[1] // (2 * sharing)))
 
             def grad_fn(batch):
                 b = dict(batch)

@@ -1,6 +1,6 @@
-"""profiles/r05_pmc_traffic_<prec>.json from the per-counter summaries tools/profile_round.sh leaves (tools/pmc_summary.py
+"""profiles/r06_pmc_traffic_<prec>.json from the per-counter summaries tools/profile_round.sh leaves (tools/pmc_summary.py
 tables): HBM bytes per training step and stage, MFMA-pipe busy fraction and shader clock per kernel.
-    python tools/pmc_traffic.py gpurun_out/round fp32 profiles/r05_pmc_traffic_fp32.json"""
+    python tools/pmc_traffic.py gpurun_out/round fp32 profiles/r06_pmc_traffic_fp32.json"""
 import datetime
 import json
 import subprocess

@@ -458,6 +458,8 @@ def main():
                     'bench_full.json next to bench.py); the line names it in `full_report`')
     ap.add_argument('--repeats', type=int, default=3, help='timed regions of K steps each for `value` (and the --also arithmetics): the line reports the MEDIAN '
                     'run (its K steps, its ms_per_step); every run is in the full report under `runs_ms_per_step`')
+    ap.add_argument('--verify-rows', type=int, default=None, help='rows of the self-check\'s global batch (default: rays per GPU x ranks); lets ONE GPU run the '
+                    'check at the size an 8-GPU run gives it (tests/test_hip_dist.py)')
     ap.add_argument('--check-ranks', action='store_true', help='spawn / join the ranks, count them with one all-reduce, print {"n_gpus", "ranks_reduced"} '
                     'and exit without touching a GPU (the CPU test of the --gpus N launcher)')
     args = ap.parse_args()
@@ -628,7 +630,7 @@ def main():
             """Before the timed region of a multi-rank run: the all-reduced gradient of the ranks' shards of ONE global batch (world x rays rows,
             the same on every rank) against the gradient of the whole global batch computed locally by every rank (vdist.verify_sharded_gradient)."""
             self.model.configs['model']['hip_precision'] = precision
-            gb = make_batch(self.gen, self.rays * world, 777, n_sparse=self.n_sparse * world)
+            gb = make_batch(self.gen, args.verify_rows or self.rays * world, 777, n_sparse=self.n_sparse * world)
             # The whole-batch pass (world x rays rows on EVERY rank) runs through the re-rendering backward in chunks of <= 8192 rays (autograd.py:
             # the path tests/test_hip_fullsize.py holds at 65,536 rays) under a workspace cap, instead of keeping 5.4 MB of activations per ray
             # for 32,768+ rays at once.  Ranks SHARING a device (the one-GPU tests of this path) each get an equal share of half of it.
@@ -826,7 +828,7 @@ def main():
         result.update({k: v for k, v in main_extra.items() if v is not None})
         result['grad_allreduce_vs_whole_batch'] = float('%.3e' % verify['rel_l2'])
         result['ranks_param_identical'] = same['identical']
-        result['sharding_check'] = dict(verify, tolerance=GRAD_SHARD_TOL, global_rows=(rays + main_wl.n_sparse) * world, params=same,
+        result['sharding_check'] = dict(verify, tolerance=GRAD_SHARD_TOL, global_rows=args.verify_rows or (rays + main_wl.n_sparse) * world, params=same,
                                         passed=not verify_failed)
     import hashlib
     bi = vlib.build_info()

@@ -160,6 +160,7 @@ def test_bench_self_spawns_eight_ranks_strong_scaling():
     full = json.load(open(os.path.join(ROOT, res['full_report'])))          # the nested blocks live in the full report (the line names the file)
     assert full['value'] == res['value'] and full['n_gpus'] == 8
     # the scaling line's own parity evidence: reduced shard gradients == whole-batch gradient, identical parameters after K steps
+    print('8 ranks on one GPU: reduced shard gradients vs whole-batch gradient, rel L2', res['grad_allreduce_vs_whole_batch'])
     assert 0 <= res['grad_allreduce_vs_whole_batch'] <= 1e-5 and res['ranks_param_identical'] is True
     assert full['sharding_check']['ranks'] == 8 and full['sharding_check']['global_rows'] == 8192 and full['sharding_check']['passed'] is True
     assert full['render']['fp32']['row_strips'] == 8 and res['render_ms_per_frame'] > 0
@@ -185,6 +186,7 @@ def test_bench_two_ranks_on_one_gpu():
     assert res['n_gpus'] == 2 and res['scaling'] == 'weak' and res['value'] > 0 and res['config']['global_rays'] == 2048
     # N > 1 lines carry the configs[4] arithmetic beside `value`, and the configs[4] block (every rank its own DTU shard)
     full = json.load(open(os.path.join(ROOT, res['full_report'])))          # the nested blocks live in the full report, scalars of them in the line
+    print('2 ranks on one GPU: reduced shard gradients vs whole-batch gradient, rel L2', res['grad_allreduce_vs_whole_batch'])
     assert 0 <= res['grad_allreduce_vs_whole_batch'] <= 1e-5 and res['ranks_param_identical'] is True and full['sharding_check']['ranks'] == 2
     assert len(full['runs_ms_per_step']) == 3 and sorted(full['runs_ms_per_step'])[1] == res['ms_per_step']      # the line reports the median run
     assert res['value_bf16'] > 0 and full['configs4_dtu']['n_gpus'] == 2 and full['configs4_dtu']['global_rays'] == 1024
@@ -377,6 +379,25 @@ def test_bench_force_dist_single_rank_rccl():
     assert res['n_gpus'] == 1 and res['value'] > 0 and res['config'].get('collectives') == 'forced (nccl, world_size 1)'
     # the self-check of the sharded step runs on this path too (one rank: the shard is the batch, the collective is RCCL's): fields present, run passed
     assert 0 <= res['grad_allreduce_vs_whole_batch'] <= 1e-7 and res['ranks_param_identical'] is True
+
+
+def test_bench_self_check_at_the_eight_gpu_global_batch_size():
+    """The self-check of `bench.py --gpus 8` has every rank compute the gradient of the WHOLE global batch -- 8 x 4096 = 32,768 rays -- through the
+    re-rendering backward in <= 8192-ray chunks under its workspace cap.  One GPU runs that pass at that size here (`--verify-rows 32768`; with one rank
+    the shard is the batch, so both passes take it and must agree bit for bit): the first 8-GPU run must not be the first time this size executes."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(36000 + (os.getpid() % 2000)), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('VIPNERF_DIST_BACKEND', None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--force-dist', '--verify-rows', '32768', '--steps', '2', '--warmup', '1', '--repeats', '1',
+           '--also', '', '--no-cpu-baseline', '--no-render', '--no-configs4', '--no-configs2', '--no-sizes']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    full = json.load(open(os.path.join(ROOT, res['full_report'])))
+    print('self-check at 32,768 rows on one rank:', full['sharding_check'])
+    assert full['sharding_check']['global_rows'] == 32768 and full['sharding_check']['passed'] is True
+    assert res['grad_allreduce_vs_whole_batch'] <= 1e-7 and full['sharding_check']['whole_norm'] > 0
 
 
 def test_uneven_row_classes_trim_instead_of_raising():

@@ -61,7 +61,7 @@ extern "C" {
  * Both store EVERY operand of the weight-gradient GEMMs (activations, gradients, encodings, head seeds) as 16-bit values in
  * 16-point x 16-feature tiles inside the `acts` / `bwd_ws` workspaces (vip-nerf_amd/csrc/vipnerf_bf16n.h: store_t16) and run all
  * weight-gradient GEMMs as single 16-bit MFMAs fed by DMA + ds_read_b64_tr_b16 (vipnerf_wgrad16.hip): 26 GB of HBM traffic per
- * 4096-ray step instead of 55.  Training calls need n_rays * samples to be a multiple of 32 (always true: samples are).  Errors
+ * 4096-ray step instead of 55.  Training calls in these modes need n_rays * samples of each level to be a multiple of 32 (refused with the reason otherwise).  Errors
  * ~1e-3 (fp16) / ~1e-2 (bf16) relative -- a separate accuracy class from everything above (BASELINE configs[4]). */
 #define VIPNERF_PREC_FP16   5
 #define VIPNERF_PREC_BF16   6
@@ -85,8 +85,8 @@ typedef void *vipnerf_stream_t;      /* hipStream_t */
  * (src/models/VipNeRF01.py:16-19,53,180-185,206-207,363,470). */
 typedef struct vipnerf_config {
     int32_t ndc;          /* configs['data_loader']['ndc']: sample in NDC space, depths converted back */
-    int32_t n_coarse;     /* coarse_mlp.num_samples (64); multiple of 32, <= 256 */
-    int32_t n_fine;       /* fine_mlp.num_samples (128); 0 = coarse pass only; n_coarse+n_fine mult. of 32, <= 256 */
+    int32_t n_coarse;     /* coarse_mlp.num_samples (64); any count 2..256 (>= 3 with n_fine > 0), as in the reference */
+    int32_t n_fine;       /* fine_mlp.num_samples (128); 0 = coarse pass only; n_coarse + n_fine <= 256 */
     int32_t n_sec;        /* V: secondary views whose visibility is predicted this call (0 if !sec_views_vis) */
     int32_t train;        /* model.training: sigma noise (if noise_std > 0) */
     int32_t lindisp;      /* configs['model']['lindisp'] */

@@ -59,7 +59,8 @@ def test_argument_validation_without_gpu():
     cfg.save_acts = 1
     assert lib.vipnerf_query_workspace(C.byref(cfg), 4096, C.byref(a), C.byref(b)) == 0
     assert a.value == 4 * 4096 * 256 * (9 * 256 + 8 * 8 + 2 * 128 + 64 + 2 * 32 + 2 * 4)      # (+ 2 x 4 words: the view hidden's ReLU bits per direction)
-    bad = ops.make_config(True, 60, 128, 1, False)
+    assert lib.vipnerf_query_workspace(C.byref(ops.make_config(True, 60, 127, 1, False)), 16, C.byref(a), C.byref(b)) == 0      # any sample counts (round 6), as in the reference
+    bad = ops.make_config(True, 200, 128, 1, False)                         # > 256 samples per ray on the fine level
     assert lib.vipnerf_query_workspace(C.byref(bad), 16, C.byref(a), C.byref(b)) == -2
     buf = C.create_string_buffer(256)
     lib.vipnerf_last_error(buf, 256)
@@ -353,5 +354,7 @@ def test_argument_checks_need_no_gpu():
     bad = ops.make_config(True, 64, 128, 1, True, topology=(8, 256, 10, 4, 7))
     a, b = C.c_size_t(0), C.c_size_t(0)
     assert lib.vipnerf_query_workspace(C.byref(bad), 16, C.byref(a), C.byref(b)) < 0 and 'head_variant' in last()
-    bad = ops.make_config(True, 48, 128, 1, True)
+    bad = ops.make_config(True, 1, 0, 1, True)                     # (any sample counts since round 6; a single coarse sample is not a ray)
     assert lib.vipnerf_query_workspace(C.byref(bad), 16, C.byref(a), C.byref(b)) < 0 and 'n_coarse' in last()
+    bad = ops.make_config(True, 2, 14, 1, True)                    # importance sampling needs three coarse samples (sample_pdf's bins)
+    assert lib.vipnerf_query_workspace(C.byref(bad), 16, C.byref(a), C.byref(b)) < 0 and 'n_fine' in last()

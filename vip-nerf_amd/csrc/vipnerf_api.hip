@@ -68,10 +68,15 @@ static bool precision_retired(int precision) { return precision == VIPNERF_PREC_
 static int check_cfg(const vipnerf_config *cfg) {
     clear_stale_hip_error();
     if (!cfg) { set_error("cfg is NULL"); return VIPNERF_E_ARG; }
-    if (cfg->n_coarse < 32 || cfg->n_coarse > 256 || cfg->n_coarse % 32) {
-        set_error("n_coarse=%d unsupported (multiple of 32 in [32,256])", cfg->n_coarse); return VIPNERF_E_UNSUPPORTED; }
-    if (cfg->n_fine < 0 || (cfg->n_fine > 0 && ((cfg->n_coarse + cfg->n_fine) % 32 || cfg->n_coarse + cfg->n_fine > 256))) {
-        set_error("n_fine=%d unsupported (n_coarse+n_fine multiple of 32, <= 256)", cfg->n_fine); return VIPNERF_E_UNSUPPORTED; }
+    // Any sample counts, as in the reference (VipNeRF01.py:173-216): the kernels index points, not 32-sample blocks (a point's ray is p / S per lane;
+    // the per-ray kernels give a lane ceil(S / 64) samples and predicate the tail).  Measured against the oracle for 5 + 11 ... 100 + 156, odd counts
+    // and odd ray numbers included (profiles/r06_sample_counts_probe.log).  Limits: <= 256 samples per ray and level (four per lane), >= 2 coarse
+    // samples, >= 3 with importance sampling (sample_pdf's bins).  The 16-bit TRAINING kernels additionally need a level's POINT count (rays x
+    // samples) to be a multiple of 32 -- their T16 tile storage -- and say so per call (launch_mlp_fwd_pt2, launch_wgrad16).
+    if (cfg->n_coarse < 2 || cfg->n_coarse > 256) {
+        set_error("n_coarse=%d unsupported (2..256)", cfg->n_coarse); return VIPNERF_E_UNSUPPORTED; }
+    if (cfg->n_fine < 0 || (cfg->n_fine > 0 && (cfg->n_coarse < 3 || cfg->n_coarse + cfg->n_fine > 256))) {
+        set_error("n_fine=%d with n_coarse=%d unsupported (n_coarse >= 3, n_coarse + n_fine <= 256)", cfg->n_fine, cfg->n_coarse); return VIPNERF_E_UNSUPPORTED; }
     if (cfg->n_sec < 0 || cfg->n_sec > VIPNERF_MAX_SEC) {
         set_error("n_sec=%d unsupported (0..%d)", cfg->n_sec, VIPNERF_MAX_SEC); return VIPNERF_E_UNSUPPORTED; }
     if (cfg->precision < 0 || cfg->precision > VIPNERF_PREC_BF16) {

@@ -27,12 +27,15 @@ for p in (ROOT, os.path.join(ROOT, 'vip-nerf_amd'), os.path.join(ROOT, 'vip-nerf
         sys.path.insert(0, p)
 
 N_DEV = torch.cuda.device_count() if torch.cuda.is_available() else 0
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(N_DEV < 2, reason='needs at least two GPUs (one rank per physical device over RCCL)')]
+pytestmark = pytest.mark.gpu
+needs_two = pytest.mark.skipif(N_DEV < 2, reason='needs at least two GPUs (one rank per physical device over RCCL)')
 WORLDS = [w for w in (2, 4, 8) if w <= N_DEV]
 N_NERF, N_SD, STEPS = 768, 256, 3
 
 
 def _env(rank, world, port):
+    if world == 1:
+        os.environ['VIPNERF_FORCE_DIST'] = '1'           # one rank: the collectives still run (RCCL at world size 1)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       VIPNERF_DIST_BACKEND='nccl', HSA_ENABLE_IPC_MODE_LEGACY='0')
 
@@ -90,6 +93,7 @@ def _worker(rank, world, port, ret):
     torch.distributed.destroy_process_group()
 
 
+@needs_two
 @pytest.mark.parametrize('world', WORLDS)
 def test_reduced_shard_gradients_equal_the_whole_batch_gradient(world):
     port = 35000 + (os.getpid() % 2000) + world
@@ -117,6 +121,7 @@ def _strip_worker(rank, world, port, ret):
     torch.distributed.destroy_process_group()
 
 
+@needs_two
 @pytest.mark.parametrize('world', WORLDS)
 def test_frame_as_one_strip_per_device_equals_one_device(world):
     from data_preprocessors.RayGeneratorHip01 import predict_frame
@@ -131,6 +136,7 @@ def test_frame_as_one_strip_per_device_equals_one_device(world):
             assert np.array_equal(ret[r][k], v.cpu().numpy()), f'world {world} rank {r}: {k}'
 
 
+@needs_two
 def test_bench_line_verifies_itself_on_distinct_devices():
     world = WORLDS[-1]
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR', 'VIPNERF_DIST_BACKEND')}
@@ -141,3 +147,16 @@ def test_bench_line_verifies_itself_on_distinct_devices():
     assert res['n_gpus'] == world and res['ranks_reduced'] == world
     assert 0 <= res['grad_allreduce_vs_whole_batch'] <= 1e-5 and res['ranks_param_identical'] is True
     assert res['allreduce_ms_per_step'] > 0
+
+
+def test_the_workers_run_with_one_rank_over_rccl():
+    """The box this suite usually sees has ONE device, so the tests above are skipped there -- their worker code must not meet a real node untested:
+    the same two workers with world size 1 over RCCL (forced collectives): every line of them executes, the checks hold trivially."""
+    port = 38000 + (os.getpid() % 2000)
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(1, port, ret), nprocs=1, join=True)
+    res = ret[0]
+    assert res['ranks'] == 1 and res['rel_l2'] <= 1e-7 and res['depths_are_the_global_rows'] and res['params']['identical'], res
+    ret2 = mp.Manager().dict()
+    mp.spawn(_strip_worker, args=(1, port + 1, ret2), nprocs=1, join=True)
+    assert ret2[0]['image'].dtype == np.uint8

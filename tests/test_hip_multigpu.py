@@ -117,7 +117,7 @@ def _strip_worker(rank, world, port, ret):
     torch.cuda.set_device(dev)
     model, gen = thd._render_setup(dev)
     full = predict_frame_sharded(model, gen, frame=1, rank=r, world=w)
-    ret[rank] = {k: v.numpy() for k, v in full.items()}
+    ret[rank] = {k: v.cpu().numpy() for k, v in full.items()}          # (world size 1 returns the strip on the device)
     torch.distributed.destroy_process_group()
 
 
